@@ -1,0 +1,275 @@
+#!/usr/bin/env python3
+"""bench.py -- frames of the ray-cast hot path on N MI355X GPUs of one node.
+
+A "step" is one frame: the per-pixel front-to-back ray march over the whole viewport (one
+pass of the hot path over one batch of synthetic input, volume resident in HBM).  At N>1
+the frame is split into interleaved image tiles (volume replicated per GPU) and gathered
+to rank 0 over RCCL -- strong scaling: the frame is fixed as N grows.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0).  `value` = samples actually taken (inner-loop bodies,
+after ESS/ERT) by all ranks in the K timed frames / wall time, in Msamples/s.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (kind, res, format, illum, tff, ess)
+    # headline: BASELINE.json metric config -- 2048^3 UCHAR at a 1024^2 viewport, reference
+    # defaults (default TF, central-difference Blinn-Phong, object-order ESS, ERT, rate 1.5)
+    "shells2048": ("shells", 2048, "UCHAR", 1, "default", True),
+    "sphere2048": ("sphere", 2048, "UCHAR", 1, "default", True),
+    "haze2048": ("sphere", 2048, "UCHAR", 1, "haze", True),     # dense regime: no ERT
+    "shells1024u16": ("shells", 1024, "USHORT", 1, "default", True),
+    "sphere256": ("sphere", 256, "UCHAR", 1, "default", True),
+    "sphere256_plain": ("sphere", 256, "UCHAR", 0, "default", False),
+    "sphere64": ("sphere", 64, "UCHAR", 1, "default", True),    # CI-sized
+}
+FMT = {"UCHAR": 0, "USHORT": 1, "FLOAT": 2}
+FMT_BYTES = {"UCHAR": 1, "USHORT": 2, "FLOAT": 4}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="shells2048", choices=sorted(WORKLOADS))
+    ap.add_argument("--viewport", type=int, default=1024)
+    ap.add_argument("--tile", type=int, default=64, help="tile edge for the multi-GPU split")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0,
+                    help="target CPU work for the bounded cpu_baseline sample")
+    ap.add_argument("--view", default="rot30", choices=["default", "rot30"])
+    return ap.parse_args()
+
+
+def cpu_baseline(vr, vol_host, bricks_host, tff, fmt, W, H, target_s):
+    """Oracle (CPU restatement, OpenMP over rows) timed on a bounded sample of the same
+    frame: evenly spaced 2-row stripes, grown until ~target_s of CPU work."""
+    from oracle import vro
+    cam, rp, rc, pt = vr.params()
+    ocam = vro.CameraParams.from_buffer_copy(bytes(cam))
+    orp = vro.RenderingParams.from_buffer_copy(bytes(rp))
+    orc = vro.RaycastParams.from_buffer_copy(bytes(rc))
+    opt = vro.PathtraceParams.from_buffer_copy(bytes(pt))
+    prefix = vro.prefix_sum(tff)
+    cores = vro.lib().vro_num_threads()
+    done_rows, samples, secs = 0, 0, 0.0
+    n_stripes = 8
+    rows_seen = set()
+    while True:
+        ys = [int((k + 0.5) * H / n_stripes) & ~1 for k in range(n_stripes)]
+        ys = [y for y in ys if y not in rows_seen]
+        for y in ys:
+            t0 = time.perf_counter()
+            _, st, _ = vro.render_tile(vol_host, fmt, tff, ocam, orp, orc, opt, use_ess=True,
+                                       W=W, H=H, tile=(0, y, W, 2), bricks=bricks_host,
+                                       prefix=prefix)
+            secs += time.perf_counter() - t0
+            samples += st["samples_taken"]
+            rows_seen.add(y)
+            done_rows += 2
+            if secs >= target_s:
+                break
+        if secs >= target_s or n_stripes * 2 >= H:
+            break
+        n_stripes *= 2
+    return {
+        "value": samples / secs / 1e6 if secs > 0 else 0.0,
+        "unit": "Msamples/s",
+        "cores": int(cores),
+        "kind": "port",
+        "sample": "%d of %d image rows (2-row stripes, evenly spaced) of the same frame, "
+                  "%.1f s of CPU work, %d samples" % (done_rows, H, secs, samples),
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from volumerenderercl_amd import VolumeRenderCL, frontend
+    from volumerenderercl_amd import tiles as vtiles
+
+    kind, res, fmt_name, illum, tff_name, ess = WORKLOADS[args.workload]
+    fmt, b = FMT[fmt_name], FMT_BYTES[fmt_name]
+    W = H = args.viewport
+    tff = {"default": frontend.tff_from_stops, "haze": frontend.haze_tff,
+           "opaque": frontend.opaque_ramp_tff}[tff_name]()
+
+    vr = VolumeRenderCL()
+    vr.initialize(device_id=local_rank)
+    stream = torch.cuda.current_stream(dev)
+    vr.set_stream(stream.cuda_stream)            # kernels + HIP events on torch's stream
+    vr.synthVolume(kind, (res, res, res), fmt)   # input generated in HBM
+    vr.setTransferFunction(tff)                  # also builds the ESS bricks (reference order)
+    bricks_s = vr.lastBricksSeconds()
+    vr.setIllumination(illum)
+    vr.setObjEss(ess)
+    view = frontend.view_matrix() if args.view == "default" else frontend.view_matrix(
+        frontend.quat_from_axis_angle((1, 1, 0), 30.0))
+    vr.updateView(view)
+
+    # frame k of the reference uses output k of a default-seeded std::mt19937
+    mt = frontend.Mt19937()
+    seeds = [mt() for _ in range(args.warmup + args.steps)]
+
+    split = vtiles.TileSplit(W, H, args.tile, args.tile, world, rank)
+    frame = torch.empty((H, W, 4), dtype=torch.float32, device=dev) if rank == 0 else None
+    driver = vtiles.TileDriver(vr, split, dev)
+
+    def render(seed):
+        vr.setSeed(seed)
+        vr.setIteration(0)
+        return driver.render_frame(frame)
+
+    for k in range(args.warmup):
+        render(seeds[k])
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for k in range(args.steps):
+        render(seeds[args.warmup + k])
+    ev1.record(stream)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    gpu_region_s = ev0.elapsed_time(ev1) * 1e-3
+    last_kernel_s = vr.getLastExecTime()
+    wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
+    wall = float(wall_t.item())
+
+    # ---- untimed: exact work counters of the K timed frames (instrumented kernel variant)
+    vr.setStatsEnabled(True)
+    tot = np.zeros(6, dtype=np.int64)
+    names = ["samples_taken", "samples_nominal", "samples_shaded", "bricks_visited",
+             "bricks_skipped", "rays_hit"]
+    for k in range(args.steps):
+        render(seeds[args.warmup + k])
+        st = vr.getStats()
+        tot += np.array([st[n] for n in names], dtype=np.int64)
+    vr.setStatsEnabled(False)
+    tot_t = torch.tensor(tot, dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(tot_t, op=dist.ReduceOp.SUM)
+    tot = tot_t.cpu().numpy()
+    work = dict(zip(names, [int(x) for x in tot]))
+
+    # ---- untimed: compulsory traffic of ONE launch on rank 0 (first timed seed)
+    roofline = None
+    cpu = None
+    if rank == 0:
+        vr.setSeed(seeds[args.warmup])
+        vr.setIteration(0)
+        if world == 1:
+            mb, _ = vr.countTouched(W, H)
+            n_pix = W * H
+        else:
+            mb = vr.countTouchedTiles(W, H, args.tile, args.tile, split.my_tiles)
+            n_pix = len(split.my_tiles) * args.tile * args.tile
+        st1 = vr.getStats()
+        # B_frame = b*64*|micro-bricks touched| + 2b*|bricks visited| + 16 B per pixel written
+        alg_bytes = b * 64 * mb + 2 * b * st1["bricks_visited"] + 16 * n_pix
+        kernel_s = gpu_region_s / args.steps if world == 1 else last_kernel_s
+        achieved = alg_bytes / kernel_s / 1e9
+        roofline = {
+            "kernel": "vr_raycast_kernel<%s, ESS=%s>" % (fmt_name.lower(), ess),
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,   # PMC HBM bytes: profiles/ (separate rocprofv3 --pmc pass)
+            "algorithmic_bytes_per_launch": int(alg_bytes),
+            "avg_launch_ms": kernel_s * 1e3,
+            "last_launch_ms_hip_events": last_kernel_s * 1e3,
+            "request_bytes_per_launch": int(b * 8 * (st1["samples_taken"] +
+                                                    6 * st1["samples_shaded"])),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            vol_host = vr.downloadVolume()
+            bricks_host = vr.downloadBricks()
+            cpu = cpu_baseline(vr, vol_host, bricks_host, tff, fmt, W, H, args.cpu_seconds)
+            del vol_host
+
+    if rank == 0:
+        out = {
+            "metric": "Msamples/s (samples taken, rays x steps after ESS/ERT) at %dx%d viewport, "
+                      "%d^3 %s" % (W, H, res, fmt_name),
+            "value": work["samples_taken"] / wall / 1e6,
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3,
+            "fps": args.steps / wall,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%s: %d^3 %s '%s' field generated in HBM, %dx%d viewport (launch grid "
+                            "%dx%d), view %s, TF %s, illumType %d, object-order ESS %s, ERT 0.98, "
+                            "samplingRate 1.5, per-frame mt19937 jitter seeds"
+                            % (args.workload, res, fmt_name, kind, W, H, W + (8 - W % 8),
+                               H + (8 - H % 8), args.view, tff_name, illum, "on" if ess else "off"),
+                "parallelism": "tiles%dx%d/%d ranks, volume replicated, RCCL gather" % (
+                    args.tile, args.tile, world) if world > 1 else "single GPU, full frame",
+            },
+            "msamples_nominal_per_s": work["samples_nominal"] / wall / 1e6,
+            "work_per_frame": {k: v // args.steps for k, v in work.items()},
+            "bricks_build": {
+                "seconds": bricks_s,
+                "GB/s": (b * res ** 3 + 2 * b * 64 ** 3) / bricks_s / 1e9 if bricks_s > 0 else None,
+                "frac_hbm_peak": ((b * res ** 3) / bricks_s / 1e9 / HBM_PEAK_GBS
+                                  if bricks_s > 0 else None),
+            },
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    vr.close()
+
+
+if __name__ == "__main__":
+    main()

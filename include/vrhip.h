@@ -1,0 +1,172 @@
+/*
+ * vrhip.h -- C ABI of the MI355X-native volume ray-caster (libvrhip.so).
+ *
+ * This is the drop-in boundary underneath the reference's C++ class
+ * `VolumeRenderCL` (/root/reference/src/core/volumerendercl.h:39-482): every entry
+ * point below replaces one OpenCL-side action of that class and cites it.  Plain
+ * pointers and sizes only; no C++/torch types.  All functions return VRHIP_OK (0)
+ * or an error code; vrhip_last_error() gives the message (the host class turns it
+ * into the std::runtime_error the reference throws, volumerendercl.cpp:83-89).
+ *
+ * Not thread-safe per renderer (like the reference's single in-order queue,
+ * volumerendercl.cpp:140).  One renderer == one GPU.
+ */
+#ifndef VRHIP_H
+#define VRHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VRHIP_ABI_VERSION 1
+
+enum vrhip_status {
+    VRHIP_OK = 0,
+    VRHIP_ERR_INVALID = 1,     /* bad argument (reference: std::invalid_argument)          */
+    VRHIP_ERR_HIP = 2,         /* HIP runtime failure (reference: cl::Error -> runtime_error) */
+    VRHIP_ERR_NODATA = 3,      /* no volume / TF / bricks yet                               */
+    VRHIP_ERR_UNSUPPORTED = 4  /* feature outside the hot path                  */
+};
+
+/* DatRawReader::data_format, src/io/datrawreader.h:41-48 */
+enum vrhip_format { VRHIP_UCHAR = 0, VRHIP_USHORT = 1, VRHIP_FLOAT = 2 };
+
+/* Kernel-argument structs: byte-identical to the reference's
+ * camera_params / rendering_params / raycast_params / pathtrace_params
+ * (src/core/volumerendercl.h:43-81 == src/kernel/volumeraycast.cl:540-582). */
+typedef struct vrhip_camera_params {
+    float viewMat[16];   /* row-major 4x4 (updateView, volumerendercl.cpp:379-390) */
+    float bbox_bl[4];    /* cl_float3 in a 16-byte slot */
+    float bbox_tr[4];
+    uint32_t ortho;
+    uint32_t _pad[7];
+} vrhip_camera_params;   /* 128 bytes */
+
+typedef struct vrhip_rendering_params {
+    float backgroundColor[4];
+    float modelScale[4]; /* cl_float3 in a 16-byte slot */
+    uint32_t illumType;  /* 0 off, 1 central differences (2-5: VRHIP_ERR_UNSUPPORTED) */
+    uint32_t imgEss;
+    uint32_t showEss;
+    uint32_t useLinear;
+    uint32_t useGradient;
+    uint32_t technique;  /* 0 ray cast, 1 path tracing */
+    uint32_t seed;
+    uint32_t iteration;
+} vrhip_rendering_params; /* 64 bytes */
+
+typedef struct vrhip_raycast_params {
+    float samplingRate;
+    uint32_t useAO;
+    uint32_t contours;
+    uint32_t aerial;
+    float brickRes[4];   /* volume_res / brick_edge; written by vrhip_build_bricks */
+} vrhip_raycast_params;  /* 32 bytes */
+
+typedef struct vrhip_pathtrace_params {
+    float max_extinction;
+} vrhip_pathtrace_params;
+
+/* Work counters of the last instrumented render (SURVEY 8d "sample" definitions). */
+typedef struct vrhip_stats {
+    uint64_t samples_taken;
+    uint64_t samples_nominal;
+    uint64_t samples_shaded;
+    uint64_t bricks_visited;
+    uint64_t bricks_skipped;
+    uint64_t rays_hit;
+} vrhip_stats;
+
+typedef struct vrhip_renderer vrhip_renderer;
+
+/* ---- life cycle: VolumeRenderCL::initialize (volumerendercl.cpp:95-159) -------- */
+int vrhip_abi_version(void);
+int vrhip_create(int device_id, vrhip_renderer **out);
+void vrhip_destroy(vrhip_renderer *r);
+/* message of the last failing call on `r` (or of vrhip_create when r == NULL) */
+const char *vrhip_last_error(const vrhip_renderer *r);
+/* getCurrentDeviceName (volumerendercl.cpp:1114-1117) */
+int vrhip_device_name(const vrhip_renderer *r, char *buf, size_t buf_len);
+/* Launch on a caller-owned hipStream_t (e.g. torch's current stream) instead of the
+ * renderer's own stream; NULL restores the own stream. */
+int vrhip_set_stream(vrhip_renderer *r, void *hip_stream);
+
+/* ---- volume: volDataToCLmem (volumerendercl.cpp:690-759) ----------------------- */
+/* Dense x-fastest scalar field (CL_R image) of `format`, host memory. */
+int vrhip_upload_volume(vrhip_renderer *r, const void *host_voxels, const uint32_t res[3],
+                        int format, uint32_t timestep);
+/* Same, source already in device memory (HBM). */
+int vrhip_upload_volume_device(vrhip_renderer *r, const void *dev_voxels, const uint32_t res[3],
+                               int format, uint32_t timestep);
+/* Synthetic inputs of SURVEY 8(d), generated on the GPU: kind 0 sphere, 1 shells. */
+int vrhip_synth_volume(vrhip_renderer *r, int kind, const uint32_t res[3], int format,
+                       uint32_t timestep);
+/* Copy timestep `t` back as a dense x-fastest array (bytes must equal its size). */
+int vrhip_download_volume(vrhip_renderer *r, uint32_t timestep, void *host_dst, size_t bytes);
+int vrhip_clear_volumes(vrhip_renderer *r);
+/* setTimestep (volumerendercl.cpp:1167-1174) */
+int vrhip_set_timestep(vrhip_renderer *r, uint32_t timestep);
+int vrhip_get_resolution(const vrhip_renderer *r, uint32_t res_xyzt[4]);
+
+/* ---- transfer function + ESS bricks: setTransferFunction (volumerendercl.cpp:864-891) */
+/* RGBA8 table upload only (:870-876); n_entries <= 4096. */
+int vrhip_set_transfer_function(vrhip_renderer *r, const uint8_t *rgba8, uint32_t n_entries);
+/* setTffPrefixSum (:898-916) */
+int vrhip_set_tff_prefix_sum(vrhip_renderer *r, const uint32_t *prefix, uint32_t n);
+/* generateBricks host part + kernel for every timestep (:614-684, volumeraycast.cl:932-961);
+ * also stores raycast.brickRes like :627-631. */
+int vrhip_build_bricks(vrhip_renderer *r);
+int vrhip_get_brick_info(const vrhip_renderer *r, uint32_t tex[3], float brick_res[3],
+                         uint32_t edge[3]);
+/* (min,max) pairs in the volume's own type, x-fastest; for tests. */
+int vrhip_download_bricks(vrhip_renderer *r, uint32_t timestep, void *host_dst, size_t bytes);
+double vrhip_last_bricks_seconds(const vrhip_renderer *r);
+
+/* ---- kernel arguments: setCameraArgs/.. (volumerendercl.cpp:406-449) ----------- */
+int vrhip_set_camera_params(vrhip_renderer *r, const vrhip_camera_params *p);
+int vrhip_set_rendering_params(vrhip_renderer *r, const vrhip_rendering_params *p);
+int vrhip_set_raycast_params(vrhip_renderer *r, const vrhip_raycast_params *p);
+int vrhip_set_pathtrace_params(vrhip_renderer *r, const vrhip_pathtrace_params *p);
+/* setObjEss (volumerendercl.cpp:1006-1019): the reference recompiles with/without -DESS;
+ * here it selects the kernel variant. Default on (:150). */
+int vrhip_set_object_ess(vrhip_renderer *r, int enabled);
+
+/* ---- render: runRaycast / runRaycastNoGL (volumerendercl.cpp:506-607) ---------- */
+/* Renders the whole width x height frame (launch grid padded like :513-514).
+ * out_rgba: width*height*4 floats, row 0 = top, or NULL to keep the frame on the GPU.
+ * out_is_device != 0: out_rgba is device memory. */
+int vrhip_render_frame(vrhip_renderer *r, uint32_t width, uint32_t height, float *out_rgba,
+                       int out_is_device);
+/* Image-tile decomposition for multi-GPU: renders n_tiles tiles of
+ * tile_w x tile_h pixels (tile id = ty * ceil(width/tile_w) + tx) into the compact
+ * DEVICE buffer out_tiles[n_tiles][tile_h][tile_w][4].  Pixels outside the frame are
+ * left untouched.  tile_w, tile_h must be multiples of 16. */
+int vrhip_render_tiles(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t tile_w,
+                       uint32_t tile_h, const uint32_t *tile_ids, uint32_t n_tiles,
+                       float *out_tiles_dev);
+/* getLastExecTime (volumerendercl.cpp:1053-1056): HIP-event time of the last ray-cast
+ * kernel launch, seconds. */
+double vrhip_last_kernel_seconds(const vrhip_renderer *r);
+
+/* ---- measurement helpers ------------------------------------------- */
+/* When enabled, render calls run the instrumented kernel variant that accumulates
+ * vrhip_stats (one atomic per wave). */
+int vrhip_set_stats_enabled(vrhip_renderer *r, int enabled);
+int vrhip_get_stats(const vrhip_renderer *r, vrhip_stats *out);
+/* Untimed instrumentation pass over the current frame set-up: number of distinct
+ * 4x4x4-voxel micro-bricks touched by at least one voxel fetch (compulsory traffic,
+ * SURVEY 8d B_frame). Optionally returns the bitmap (ceil(res/4)^3 bits). */
+int vrhip_count_touched(vrhip_renderer *r, uint32_t width, uint32_t height,
+                        uint64_t *microbricks_touched, uint8_t *bitmap_host, size_t bitmap_bytes);
+/* Same for a tile subset (arguments as vrhip_render_tiles); also fills vrhip_get_stats. */
+int vrhip_count_touched_tiles(vrhip_renderer *r, uint32_t width, uint32_t height,
+                              uint32_t tile_w, uint32_t tile_h, const uint32_t *tile_ids,
+                              uint32_t n_tiles, uint64_t *microbricks_touched);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VRHIP_H */

@@ -1,0 +1,219 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Bar: <= 1e-4 per channel (north_star); the kernels execute the oracle's
+fp32 operation sequences, so the observed difference is expected to be exactly 0 and the
+integer work counters must match bit for bit.
+"""
+import numpy as np
+import pytest
+
+from oracle import vro
+from tests import common
+from volumerenderercl_amd import FLOAT, UCHAR, USHORT, VolumeRenderCL, frontend
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4   # per channel, float RGBA (BASELINE.json north_star)
+SEED = 3499211612
+
+
+@pytest.fixture(scope="module")
+def vr():
+    r = VolumeRenderCL()
+    r.initialize()
+    yield r
+    r.close()
+
+
+def _setup(vr, vol, fmt, tff, view, **kw):
+    vr.loadVolumeArrays([vol], fmt, thickness=kw.get("thickness", (1.0, 1.0, 1.0)))
+    vr.setTransferFunction(tff)
+    vr.setSeed(kw.get("seed", SEED))
+    vr.setIllumination(kw.get("illum", 1))
+    vr.setLinearInterpolation(kw.get("linear", True))
+    vr.setCamOrtho(kw.get("ortho", False))
+    vr.setUseGradient(kw.get("gradient_bg", False))
+    vr.setContours(kw.get("contours", False))
+    vr.setAerial(kw.get("aerial", False))
+    vr.setObjEss(kw.get("ess", True))
+    vr.updateSamplingRate(kw.get("rate", 1.5))
+    bb = kw.get("bbox", (-1, -1, -1, 1, 1, 1))
+    vr.setBBox(*bb)
+    vr.updateView(view)
+    vr.setIteration(0)
+
+
+def _compare(vr, vol, fmt, tff, W, H, ess=True):
+    vr.setStatsEnabled(True)
+    got = vr.runRaycastNoGL(W, H)
+    gstats = vr.getStats()
+    vr.setIteration(0)
+    ref, rstats, _ = common.oracle_frame(vr, vol, fmt, tff, W, H, use_ess=ess)
+    diff = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+    assert np.isfinite(got).all()
+    assert diff.max() <= TOL, "max abs diff %.3g at %s" % (
+        diff.max(), np.unravel_index(diff.argmax(), diff.shape))
+    assert gstats == rstats
+    return got, ref, gstats
+
+
+CASES = [
+    # fmt, res, (W, H), view, tff, kwargs
+    (UCHAR, (48, 48, 48), (96, 80), "default", "default", {}),
+    (UCHAR, (48, 48, 48), (96, 80), "rot30", "default", {"ess": False}),
+    (UCHAR, (64, 40, 52), (120, 72), "rot30", "opaque", {"gradient_bg": True}),
+    (UCHAR, (33, 47, 29), (64, 64), "close", "haze", {"illum": 0}),
+    (UCHAR, (48, 48, 48), (64, 64), "inside", "default", {}),
+    (UCHAR, (48, 48, 48), (72, 56), "rot30", "default", {"linear": False}),
+    (UCHAR, (48, 48, 48), (72, 56), "rot30", "default", {"ortho": True}),
+    (UCHAR, (48, 48, 48), (64, 64), "default", "default",
+     {"bbox": (-0.5, -0.8, -1.0, 0.7, 0.6, 0.2)}),
+    (UCHAR, (40, 40, 40), (64, 48), "rot30", "haze", {"contours": True, "aerial": True}),
+    (UCHAR, (40, 40, 40), (64, 48), "close", "opaque", {"illum": 0, "contours": True}),
+    (UCHAR, (32, 32, 80), (64, 64), "rot30", "default", {"thickness": (1.0, 1.0, 2.5)}),
+    (UCHAR, (128, 128, 128), (128, 128), "rot30", "default", {"rate": 0.7}),
+    (USHORT, (48, 48, 48), (80, 64), "rot30", "default", {}),
+    (USHORT, (40, 56, 36), (64, 64), "close", "opaque", {"ess": False}),
+    (FLOAT, (48, 48, 48), (80, 64), "rot30", "default", {}),
+    (FLOAT, (36, 36, 36), (64, 64), "default", "haze", {"illum": 0}),
+]
+
+
+@pytest.mark.parametrize("fmt,res,size,view,tff,kw", CASES)
+def test_frame_matches_oracle(vr, fmt, res, size, view, tff, kw):
+    vol = common.noise_volume(res, fmt, seed=7, smooth=False)
+    table = common.tffs()[tff]
+    _setup(vr, vol, fmt, table, common.views()[view], **kw)
+    got, ref, stats = _compare(vr, vol, fmt, table, size[0], size[1], ess=kw.get("ess", True))
+    assert stats["rays_hit"] > 0 and stats["samples_taken"] > 0
+
+
+def test_empty_volume_is_background(vr):
+    """Analytic case: all-zero volume + default TF -> every pixel is the background."""
+    vol = np.zeros((32, 32, 32), dtype=np.uint8)
+    _setup(vr, vol, UCHAR, frontend.tff_from_stops(), common.views()["default"])
+    got = vr.runRaycastNoGL(64, 64)
+    np.testing.assert_array_equal(got[..., :3], np.ones((64, 64, 3), np.float32))
+    np.testing.assert_array_equal(got[..., 3], np.zeros((64, 64), np.float32))
+
+
+@pytest.mark.parametrize("fmt,res", [(UCHAR, (64, 64, 64)), (UCHAR, (100, 50, 30)),
+                                     (UCHAR, (129, 65, 250)), (USHORT, (96, 96, 96)),
+                                     (USHORT, (70, 130, 33)), (FLOAT, (64, 64, 64)),
+                                     (FLOAT, (130, 40, 77)), (UCHAR, (256, 256, 256))])
+def test_bricks_match_oracle(vr, fmt, res):
+    """generateBricks (volumeraycast.cl:932-961): bit-exact min/max grid, last plane excluded."""
+    vol = common.noise_volume(res, fmt, seed=3, smooth=False)
+    vr.loadVolumeArrays([vol], fmt)
+    vr.setTransferFunction(frontend.tff_from_stops())
+    tex, brf, edge = vr.brickInfo()
+    e_edge, e_brf, e_tex = vro.brick_layout(res)
+    assert tex == e_tex and edge == e_edge and brf == e_brf
+    got = vr.downloadBricks()
+    ref = vro.generate_bricks(vol, fmt)
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_bricks_known_answer_survey_app_e(vr):
+    """8^3 known-answer values recorded from the compiled reference.
+    The reference probe used a 2^3 brick image; here the grid comes from the host sizing
+    rule (8/64 -> edge 1 -> 8^3 bricks), so the KAT is checked through the oracle in
+    tests/test_oracle_golden.py; this test checks GPU == oracle on that same volume."""
+    z, y, x = np.meshgrid(np.arange(8), np.arange(8), np.arange(8), indexing="ij")
+    vol = ((x + 8 * y + 64 * z) % 256).astype(np.uint8)
+    vr.loadVolumeArrays([vol], UCHAR)
+    vr.setTransferFunction(frontend.tff_from_stops())
+    np.testing.assert_array_equal(vr.downloadBricks(), vro.generate_bricks(vol, UCHAR))
+
+
+def test_tiles_equal_full_frame(vr):
+    """Image-tile decomposition: any tile rendered alone equals the same pixels
+    of the full frame (the camera uses the padded full-frame size, App. A.2)."""
+    import torch
+    vol = common.noise_volume((48, 48, 48), UCHAR, seed=5)
+    tff = frontend.tff_from_stops()
+    W, H, TW, TH = 150, 100, 32, 48
+    _setup(vr, vol, UCHAR, tff, common.views()["rot30"])
+    full = vr.runRaycastNoGL(W, H)
+    vr.setIteration(0)
+    tiles_x, tiles_y = (W + TW - 1) // TW, (H + TH - 1) // TH
+    ids = np.array([t for t in range(tiles_x * tiles_y) if t % 3 != 1], dtype=np.uint32)
+    out = torch.zeros((len(ids), TH, TW, 4), dtype=torch.float32, device="cuda")
+    vr.render_tiles(W, H, TW, TH, ids, out.data_ptr())
+    torch.cuda.synchronize()
+    vr.getLastExecTime()
+    o = out.cpu().numpy()
+    for k, t in enumerate(ids):
+        tx, ty = int(t) % tiles_x, int(t) // tiles_x
+        x0, y0 = tx * TW, ty * TH
+        w, h = min(TW, W - x0), min(TH, H - y0)
+        np.testing.assert_array_equal(o[k, :h, :w], full[y0:y0 + h, x0:x0 + w])
+        # oracle agrees on the tile as well
+    ref, _, _ = common.oracle_frame(vr, vol, UCHAR, tff, W, H, tile=(32, 48, 32, 48))
+    assert np.abs(ref - full[48:96, 32:64]).max() <= TOL
+
+
+def test_accumulation_running_mean(vr):
+    """volumeraycast.cl:898-909 with fp32 accumulation: frame k is the
+    running mean of frames 0..k, each with its own jitter seed."""
+    vol = common.noise_volume((40, 40, 40), UCHAR, seed=9)
+    tff = frontend.tff_from_stops()
+    W, H = 64, 48
+    _setup(vr, vol, UCHAR, tff, common.views()["rot30"])
+    acc = None
+    for it, seed in enumerate(frontend.MT19937_FIRST_SEEDS):
+        vr.setSeed(seed)
+        vr.setIteration(it)
+        got = vr.runRaycastNoGL(W, H)
+        vr.setIteration(it)
+        ref, _, _ = common.oracle_frame(vr, vol, UCHAR, tff, W, H, in_accum=acc)
+        assert np.abs(got - ref).max() <= TOL
+        acc = ref
+
+
+def test_default_seed_sequence(vr):
+    """Without a pinned seed the frames use std::mt19937()'s outputs."""
+    r = VolumeRenderCL()
+    r.initialize()
+    vol = common.noise_volume((32, 32, 32), UCHAR, seed=1)
+    r.loadVolumeArrays([vol], UCHAR)
+    r.setTransferFunction(frontend.tff_from_stops())
+    r.updateView(frontend.view_matrix())
+    seeds = []
+    for _ in range(3):
+        r.runRaycastNoGL(32, 32)
+        seeds.append(int(r.params()[1].seed))
+    r.close()
+    assert tuple(seeds) == frontend.MT19937_FIRST_SEEDS
+
+
+def test_touched_microbricks_match_oracle(vr):
+    """Compulsory-traffic instrumentation (SURVEY 8d B_frame): the set of 4^3 micro-bricks
+    touched by any voxel fetch is identical on GPU and in the oracle."""
+    vol = common.noise_volume((64, 64, 64), UCHAR, seed=11)
+    tff = frontend.tff_from_stops()
+    W, H = 96, 96
+    _setup(vr, vol, UCHAR, tff, common.views()["rot30"])
+    n, bm = vr.countTouched(W, H, want_bitmap=True)
+    _, _, ref_bm = common.oracle_frame(vr, vol, UCHAR, tff, W, H, want_touched=True)
+    np.testing.assert_array_equal(bm, ref_bm)
+    assert n == int(np.unpackbits(ref_bm).sum()) and n > 0
+
+
+def test_error_behaviour(vr):
+    """Errors surface as exceptions with the reference's meaning."""
+    r = VolumeRenderCL()
+    r.initialize()
+    assert r.runRaycastNoGL(32, 32) is None          # silent no-op without data
+    r.setTransferFunction(np.zeros(4096, np.uint8))  # silent no-op without data
+    with pytest.raises(RuntimeError):
+        r.loadVolumeArrays([np.zeros(10, np.uint8)], UCHAR, res=(4, 4, 4))
+    vol = common.noise_volume((16, 16, 16), UCHAR)
+    r.loadVolumeArrays([vol], UCHAR)
+    with pytest.raises(RuntimeError):                # no TF yet -> bricks missing
+        r.runRaycastNoGL(32, 32)
+    r.setTransferFunction(frontend.tff_from_stops())
+    r.updateView(frontend.view_matrix())
+    r.setIllumination(3)
+    with pytest.raises(RuntimeError):                # outside the hot path, loud
+        r.runRaycastNoGL(32, 32)
+    r.close()

@@ -1,0 +1,81 @@
+"""Analytic closed forms that pin the oracle's march loop independently of any reference
+run: empty volume -> background; constant-density volume ->
+alpha = 1 - (1-a)^(n/rate) with n = number of samples the step rule yields."""
+import numpy as np
+
+from oracle import vro
+from volumerenderercl_amd import frontend
+
+
+def _params(view=None, illum=0, rate=1.5, seed=3499211612, res=(32, 32, 32)):
+    cam = vro.CameraParams()
+    cam.viewMat[:] = view or frontend.view_matrix()
+    cam.bbox_bl[:] = [-1, -1, -1, 0]
+    cam.bbox_tr[:] = [1, 1, 1, 0]
+    rp = vro.RenderingParams()
+    rp.backgroundColor[:] = [1, 1, 1, 1]
+    rp.modelScale[:] = [1, 1, 1, 0]
+    rp.illumType, rp.useLinear, rp.seed = illum, 1, seed
+    rc = vro.RaycastParams()
+    rc.samplingRate = rate
+    _, brf, _ = vro.brick_layout(res)
+    rc.brickRes[:] = brf + [0]
+    return cam, rp, rc
+
+
+def test_empty_volume_gives_background():
+    vol = np.zeros((32, 32, 32), np.uint8)
+    cam, rp, rc = _params()
+    for ess in (True, False):
+        img, st, _ = vro.render_tile(vol, vro.UCHAR, frontend.tff_from_stops(), cam, rp, rc,
+                                     use_ess=ess, W=48, H=40)
+        assert np.all(img[..., :3] == 1.0) and np.all(img[..., 3] == 0.0)
+        if ess:
+            assert st["samples_taken"] == 0 and st["bricks_skipped"] == st["bricks_visited"] > 0
+
+
+def test_constant_density_closed_form():
+    """Constant voxel value v, constant TF alpha a, no ESS: every ray takes n samples and
+    ends with alpha = 1 - (1-a)^(n/rate) (or stops once alpha > 0.98)."""
+    vol = np.full((24, 24, 24), 128, np.uint8)
+    tff = np.zeros((1024, 4), np.uint8)
+    a8 = 5
+    tff[:, 3] = a8
+    tff[:, 0] = 255   # colour: result = bg - (bg - c) * alpha
+    cam, rp, rc = _params(rate=1.5, res=(24, 24, 24))
+    img, st, _ = vro.render_tile(vol, vro.UCHAR, tff, cam, rp, rc, use_ess=False, W=40, H=40)
+    a = np.float64(np.float32(a8) / np.float32(255))
+    hit = img[..., 3] > 0
+    assert hit.sum() == st["rays_hit"] > 0
+    n = st["samples_taken"] / st["rays_hit"]
+    # per-ray check: alpha determines n_ray, and colour follows from alpha
+    alpha = img[..., 3][hit].astype(np.float64)
+    n_ray = np.log1p(-alpha) / np.log1p(-a) * 1.5
+    assert np.all(np.abs(n_ray - np.round(n_ray)) < 2e-3)      # integer sample counts
+    assert abs(n_ray.mean() - n) < 1e-2
+    # colour: bg=1, tf colour (1,0,0): result = 1 - (1 - c) * alpha
+    np.testing.assert_allclose(img[..., 0][hit], 1.0, atol=1e-6)
+    np.testing.assert_allclose(img[..., 1][hit], 1.0 - alpha, atol=2e-6)
+    np.testing.assert_allclose(img[..., 2][hit], 1.0 - alpha, atol=2e-6)
+
+
+def test_ert_stops_rays():
+    vol = np.full((24, 24, 24), 255, np.uint8)
+    tff = np.zeros((1024, 4), np.uint8)
+    tff[:, 3] = 200
+    cam, rp, rc = _params(res=(24, 24, 24))
+    img, st, _ = vro.render_tile(vol, vro.UCHAR, tff, cam, rp, rc, use_ess=False, W=32, H=32)
+    hit = img[..., 3] > 0
+    # grazing rays at the box silhouette take a single sample; all others terminate early
+    assert np.mean(img[..., 3][hit] >= np.float32(0.98)) > 0.9
+    assert st["samples_taken"] < 8 * st["rays_hit"]
+
+
+def test_tile_equals_full_frame_crop():
+    vol = vro.synth_volume("sphere", [32, 32, 32], vro.UCHAR)
+    cam, rp, rc = _params(view=frontend.view_matrix(frontend.quat_from_axis_angle((1, 1, 0), 30)),
+                          illum=1)
+    tff = frontend.tff_from_stops()
+    full, _, _ = vro.render_tile(vol, vro.UCHAR, tff, cam, rp, rc, W=70, H=50)
+    part, _, _ = vro.render_tile(vol, vro.UCHAR, tff, cam, rp, rc, W=70, H=50, tile=(16, 8, 33, 21))
+    np.testing.assert_array_equal(part, full[8:29, 16:49])

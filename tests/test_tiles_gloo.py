@@ -1,0 +1,92 @@
+"""Multi-GPU path on CPU: world_size-2 (and 3) `gloo` runs of the tile decomposition +
+gather + reassembly (volumerenderercl_amd/tiles.py), with the oracle standing in for the
+per-tile renderer.  The assembled frame must equal the single-rank frame exactly."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import vro
+from volumerenderercl_amd import frontend, tiles
+
+
+def _scene():
+    vol = vro.synth_volume("sphere", [32, 32, 32], vro.UCHAR)
+    cam = vro.CameraParams()
+    cam.viewMat[:] = frontend.view_matrix(frontend.quat_from_axis_angle((1, 1, 0), 30))
+    cam.bbox_bl[:] = [-1, -1, -1, 0]
+    cam.bbox_tr[:] = [1, 1, 1, 0]
+    rp = vro.RenderingParams()
+    rp.backgroundColor[:] = [1, 1, 1, 1]
+    rp.modelScale[:] = [1, 1, 1, 0]
+    rp.illumType, rp.useLinear, rp.seed = 1, 1, 581869302
+    rc = vro.RaycastParams()
+    rc.samplingRate = 1.5
+    _, brf, _ = vro.brick_layout([32, 32, 32])
+    rc.brickRes[:] = brf + [0]
+    return vol, frontend.tff_from_stops(), cam, rp, rc
+
+
+def _worker(rank, world, port, W, H, T, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    vol, tff, cam, rp, rc = _scene()
+    split = tiles.TileSplit(W, H, T, T, world, rank)
+
+    def render_tiles(ids, out):
+        for k, t in enumerate(ids):
+            x0, y0, w, h = split.tile_rect(t)
+            img, _, _ = vro.render_tile(vol, vro.UCHAR, tff, cam, rp, rc, W=W, H=H,
+                                        tile=(x0, y0, w, h), threads=1)
+            out[k, :h, :w] = torch.from_numpy(img)
+
+    drv = tiles.TileDriver(None, split, torch.device("cpu"), render_tiles_fn=render_tiles, dist=dist)
+    frame = torch.zeros((H, W, 4)) if rank == 0 else None
+    for _ in range(2):   # two frames: buffers are reusable
+        out = drv.render_frame(frame)
+    if rank == 0:
+        q.put(out.numpy().copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,W,H,T", [(2, 96, 64, 32), (3, 80, 56, 16)])
+def test_gloo_tile_gather_matches_single_rank(world, W, H, T):
+    vol, tff, cam, rp, rc = _scene()
+    ref, _, _ = vro.render_tile(vol, vro.UCHAR, tff, cam, rp, rc, W=W, H=H)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, T, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_tile_split_is_a_partition():
+    for world in (1, 2, 3, 4, 8):
+        s0 = tiles.TileSplit(1024, 1000, 64, 48, world, 0)
+        allt = np.concatenate(s0.tiles_of)
+        assert sorted(allt.tolist()) == list(range(s0.n_tiles))
+        counts = [len(t) for t in s0.tiles_of]
+        assert max(counts) - min(counts) <= max(2, s0.tiles_y)
+        assert s0.cap == max(counts)
+    with pytest.raises(ValueError):
+        tiles.TileSplit(64, 64, 24, 16, 2, 0)

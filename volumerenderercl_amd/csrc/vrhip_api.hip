@@ -1,0 +1,762 @@
+// vrhip_api.hip -- implementation of the C ABI in include/vrhip.h on the HIP runtime.
+// Owns every device allocation of one renderer (like VolumeRenderCL owns its cl::Image
+// objects, /root/reference/src/core/volumerendercl.h:446-463).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "vr_internal.h"
+
+namespace {
+
+struct VolumeSlot {
+    void *dev = nullptr;      // dense x-fastest voxels
+    void *bricks = nullptr;   // (min,max) grid
+};
+
+std::string g_create_error;
+
+} // namespace
+
+struct vrhip_renderer {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    mutable std::string err;
+    std::string devname;
+
+    uint32_t res[3] = {0, 0, 0};
+    int format = -1;
+    std::vector<VolumeSlot> vols;
+    uint32_t timestep = 0;
+
+    float4 *tff = nullptr;
+    uint32_t tff_n = 0;
+    uint32_t *prefix = nullptr;
+    uint32_t prefix_n = 0;
+
+    uint32_t brick_tex[3] = {0, 0, 0}, brick_edge[3] = {0, 0, 0};
+    float brick_res[3] = {1, 1, 1};
+    bool bricks_valid = false;
+
+    vrhip_camera_params cam;
+    vrhip_rendering_params render;
+    vrhip_raycast_params raycast;
+    vrhip_pathtrace_params pathtrace;
+    bool use_ess = true;
+
+    float4 *fb = nullptr;
+    uint32_t fb_w = 0, fb_h = 0;
+
+    DevStats *stats_dev = nullptr;
+    bool stats_enabled = false;
+    vrhip_stats last_stats;
+
+    uint32_t *tile_ids_dev = nullptr;
+    std::vector<uint32_t> tile_ids_host;
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evb0 = nullptr, evb1 = nullptr;
+    bool timed = false, bricks_timed = false;
+
+    vrhip_renderer()
+    {
+        // defaults of volumerendercl.h:43-81
+        std::memset(&cam, 0, sizeof cam);
+        std::memset(&render, 0, sizeof render);
+        std::memset(&raycast, 0, sizeof raycast);
+        std::memset(&last_stats, 0, sizeof last_stats);
+        const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        std::memcpy(cam.viewMat, ident, sizeof ident);
+        for (int i = 0; i < 3; ++i) { cam.bbox_bl[i] = -1.f; cam.bbox_tr[i] = 1.f; }
+        for (int i = 0; i < 4; ++i) render.backgroundColor[i] = 1.f;
+        for (int i = 0; i < 3; ++i) render.modelScale[i] = 1.f;
+        render.illumType = 1;
+        render.useLinear = 1;
+        render.seed = 42;
+        raycast.samplingRate = 1.5f;
+        for (int i = 0; i < 3; ++i) raycast.brickRes[i] = 1.f;
+        pathtrace.max_extinction = 100.f;
+    }
+};
+
+namespace {
+
+int fail(const vrhip_renderer *r, int code, const std::string &msg)
+{
+    if (r) r->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+#define VR_HIP(r, call)                                                                       \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(r, VRHIP_ERR_HIP,                                                     \
+                        std::string("ERROR: " #call " (") + hipGetErrorString(e_) + ")");     \
+    } while (0)
+
+#define VR_REQUIRE(r, cond, code, msg)                                                        \
+    do {                                                                                      \
+        if (!(cond)) return fail(r, code, msg);                                               \
+    } while (0)
+
+size_t fmt_bytes(int format) { return format == VRHIP_UCHAR ? 1 : format == VRHIP_USHORT ? 2 : 4; }
+
+size_t volume_bytes(const vrhip_renderer *r)
+{
+    return (size_t)r->res[0] * r->res[1] * r->res[2] * fmt_bytes(r->format);
+}
+
+size_t bricks_bytes(const vrhip_renderer *r)
+{
+    return 2 * (size_t)r->brick_tex[0] * r->brick_tex[1] * r->brick_tex[2] * fmt_bytes(r->format);
+}
+
+// volumerendercl.cpp:39-54
+uint32_t round_pow2(uint32_t n)
+{
+    uint32_t val = n - 1u;
+    val |= val >> 1;
+    val |= val >> 2;
+    val |= val >> 4;
+    val |= val >> 8;
+    val |= val >> 16;
+    val++;
+    uint32_t x = val >> 1;
+    return (val - n) > (n - x) ? x : val;
+}
+
+VolView make_vol_view(const vrhip_renderer *r, const void *data)
+{
+    VolView v;
+    v.data = data;
+    v.w = (int)r->res[0]; v.h = (int)r->res[1]; v.d = (int)r->res[2];
+    v.fw = (float)v.w; v.fh = (float)v.h; v.fd = (float)v.d;
+    v.inv_max = r->format == VRHIP_UCHAR ? 1.0f / 255.0f
+                : r->format == VRHIP_USHORT ? 1.0f / 65535.0f : 1.0f;
+    v.row = (unsigned long long)v.w;
+    v.slice = (unsigned long long)v.w * (unsigned long long)v.h;
+    v.mbx = (v.w + 3) / 4;
+    v.mby = (v.h + 3) / 4;
+    return v;
+}
+
+int set_device(const vrhip_renderer *r)
+{
+    VR_HIP(r, hipSetDevice(r->device));
+    return VRHIP_OK;
+}
+
+// (re)allocate a slot for `timestep`, checking that res/format agree with other timesteps
+int prepare_slot(vrhip_renderer *r, const uint32_t res[3], int format, uint32_t timestep,
+                 VolumeSlot **slot)
+{
+    VR_REQUIRE(r, res && res[0] && res[1] && res[2], VRHIP_ERR_INVALID,
+               "Volume resolution must be non-zero.");
+    VR_REQUIRE(r, format >= VRHIP_UCHAR && format <= VRHIP_FLOAT, VRHIP_ERR_INVALID,
+               "Unknown or invalid volume data format.");   // volumerendercl.cpp:730
+    VR_REQUIRE(r, res[0] <= 8192 && res[1] <= 8192 && res[2] <= 8192, VRHIP_ERR_INVALID,
+               "Volume resolution above 8192 per axis is not supported.");
+    bool same = r->format == format && r->res[0] == res[0] && r->res[1] == res[1] &&
+                r->res[2] == res[2];
+    if (!same) {
+        VR_REQUIRE(r, timestep == 0 || r->vols.empty(), VRHIP_ERR_INVALID,
+                   "Volume size does not match size of the other time steps.");
+        int rc = vrhip_clear_volumes(r);
+        if (rc) return rc;
+        std::memcpy(r->res, res, sizeof r->res);
+        r->format = format;
+    }
+    if (r->vols.size() <= timestep) r->vols.resize(timestep + 1);
+    VolumeSlot &s = r->vols[timestep];
+    if (!s.dev) VR_HIP(r, hipMalloc(&s.dev, volume_bytes(r)));
+    r->bricks_valid = false;
+    *slot = &s;
+    return VRHIP_OK;
+}
+
+int ensure_fb(vrhip_renderer *r, uint32_t w, uint32_t h)
+{
+    if (r->fb && r->fb_w == w && r->fb_h == h) return VRHIP_OK;
+    if (r->fb) VR_HIP(r, hipFree(r->fb));
+    r->fb = nullptr;
+    VR_HIP(r, hipMalloc((void **)&r->fb, (size_t)w * h * sizeof(float4)));
+    VR_HIP(r, hipMemsetAsync(r->fb, 0, (size_t)w * h * sizeof(float4), r->stream));
+    r->fb_w = w;
+    r->fb_h = h;
+    return VRHIP_OK;
+}
+
+int check_renderable(vrhip_renderer *r, uint32_t width, uint32_t height)
+{
+    VR_REQUIRE(r, width > 0 && height > 0 && width <= 16384 && height <= 16384,
+               VRHIP_ERR_INVALID, "Invalid output image size.");
+    VR_REQUIRE(r, !r->vols.empty() && r->timestep < r->vols.size() && r->vols[r->timestep].dev,
+               VRHIP_ERR_NODATA, "No volume data is loaded.");
+    VR_REQUIRE(r, r->tff && r->tff_n, VRHIP_ERR_NODATA, "No transfer function set.");
+    if (r->use_ess && r->render.technique == 0) {
+        VR_REQUIRE(r, r->bricks_valid && r->vols[r->timestep].bricks, VRHIP_ERR_NODATA,
+                   "ESS bricks not built: call vrhip_build_bricks after the volume upload.");
+        VR_REQUIRE(r, r->prefix && r->prefix_n, VRHIP_ERR_NODATA,
+                   "No transfer function prefix sum set.");
+    }
+    VR_REQUIRE(r, r->render.illumType <= 1, VRHIP_ERR_UNSUPPORTED,
+               "illumType 2-5 are outside the hot path (SURVEY 8f2).");
+    VR_REQUIRE(r, !r->render.imgEss && !r->render.showEss && !r->raycast.useAO,
+               VRHIP_ERR_UNSUPPORTED,
+               "image-order ESS / showEss / ambient occlusion are outside the hot path (SURVEY 8f).");
+    VR_REQUIRE(r, r->render.technique == 0, VRHIP_ERR_UNSUPPORTED,
+               "path tracing technique not available in this build.");
+    return VRHIP_OK;
+}
+
+void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, RaycastLaunch *a)
+{
+    std::memset(a, 0, sizeof *a);
+    const VolumeSlot &s = r->vols[r->timestep];
+    a->vol = make_vol_view(r, s.dev);
+    a->bricks.data = s.bricks;
+    a->bricks.bw = (int)r->brick_tex[0];
+    a->bricks.bh = (int)r->brick_tex[1];
+    a->bricks.bd = (int)r->brick_tex[2];
+    a->tf.tff = r->tff;
+    a->tf.tff_n = r->tff_n;
+    a->tf.prefix = r->prefix;
+    a->tf.prefix_n = r->prefix_n;
+    a->frame.W = width;
+    a->frame.H = height;
+    // padded NDRange of the reference (volumerendercl.cpp:513-514): a full extra group
+    // when the size is already a multiple of 8; the camera is derived from it.
+    a->frame.gsx = width + (8u - width % 8u);
+    a->frame.gsy = height + (8u - height % 8u);
+    a->frame.blocks_x = (width + 15u) / 16u;
+    a->frame.fb = r->fb;
+    a->cam = r->cam;
+    a->render = r->render;
+    a->raycast = r->raycast;
+    a->pathtrace = r->pathtrace;
+    a->format = r->format;
+    a->use_ess = r->use_ess ? 1 : 0;
+    a->instr = r->stats_enabled ? 1 : 0;
+    a->stats = r->stats_dev;
+    a->n_blocks = a->frame.blocks_x * ((height + 15u) / 16u);
+}
+
+int launch_timed(vrhip_renderer *r, const RaycastLaunch &a)
+{
+    if (a.instr) VR_HIP(r, hipMemsetAsync(r->stats_dev, 0, sizeof(DevStats), r->stream));
+    VR_HIP(r, hipEventRecord(r->ev0, r->stream));
+    VR_HIP(r, vr_launch_raycast(a, r->stream));
+    VR_HIP(r, hipEventRecord(r->ev1, r->stream));
+    r->timed = true;
+    return VRHIP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int vrhip_abi_version(void) { return VRHIP_ABI_VERSION; }
+
+int vrhip_create(int device_id, vrhip_renderer **out)
+{
+    if (!out) return fail(nullptr, VRHIP_ERR_INVALID, "vrhip_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return fail(nullptr, VRHIP_ERR_HIP,
+                    std::string("ERROR: no HIP device available (") + hipGetErrorString(e) + ")");
+    if (device_id < 0 || device_id >= n)
+        return fail(nullptr, VRHIP_ERR_INVALID, "vrhip_create: device id out of range");
+    vrhip_renderer *r = new vrhip_renderer();
+    r->device = device_id;
+    hipDeviceProp_t prop;
+    if ((e = hipSetDevice(device_id)) != hipSuccess ||
+        (e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&r->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&r->ev0)) != hipSuccess || (e = hipEventCreate(&r->ev1)) != hipSuccess ||
+        (e = hipEventCreate(&r->evb0)) != hipSuccess ||
+        (e = hipEventCreate(&r->evb1)) != hipSuccess ||
+        (e = hipMalloc((void **)&r->stats_dev, sizeof(DevStats))) != hipSuccess) {
+        std::string msg = std::string("ERROR: vrhip_create (") + hipGetErrorString(e) + ")";
+        delete r;
+        return fail(nullptr, VRHIP_ERR_HIP, msg);
+    }
+    r->stream = r->own_stream;
+    r->devname = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+    *out = r;
+    return VRHIP_OK;
+}
+
+void vrhip_destroy(vrhip_renderer *r)
+{
+    if (!r) return;
+    (void)hipSetDevice(r->device);
+    (void)hipStreamSynchronize(r->stream);
+    vrhip_clear_volumes(r);
+    if (r->tff) (void)hipFree(r->tff);
+    if (r->prefix) (void)hipFree(r->prefix);
+    if (r->fb) (void)hipFree(r->fb);
+    if (r->stats_dev) (void)hipFree(r->stats_dev);
+    if (r->tile_ids_dev) (void)hipFree(r->tile_ids_dev);
+    if (r->ev0) (void)hipEventDestroy(r->ev0);
+    if (r->ev1) (void)hipEventDestroy(r->ev1);
+    if (r->evb0) (void)hipEventDestroy(r->evb0);
+    if (r->evb1) (void)hipEventDestroy(r->evb1);
+    if (r->own_stream) (void)hipStreamDestroy(r->own_stream);
+    delete r;
+}
+
+const char *vrhip_last_error(const vrhip_renderer *r)
+{
+    return r ? r->err.c_str() : g_create_error.c_str();
+}
+
+int vrhip_device_name(const vrhip_renderer *r, char *buf, size_t buf_len)
+{
+    if (!r || !buf || !buf_len) return VRHIP_ERR_INVALID;
+    std::snprintf(buf, buf_len, "%s", r->devname.c_str());
+    return VRHIP_OK;
+}
+
+int vrhip_set_stream(vrhip_renderer *r, void *hip_stream)
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    if (set_device(r)) return VRHIP_ERR_HIP;
+    VR_HIP(r, hipStreamSynchronize(r->stream));
+    r->stream = hip_stream ? (hipStream_t)hip_stream : r->own_stream;
+    return VRHIP_OK;
+}
+
+int vrhip_upload_volume(vrhip_renderer *r, const void *host_voxels, const uint32_t res[3],
+                        int format, uint32_t timestep)
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    VR_REQUIRE(r, host_voxels, VRHIP_ERR_INVALID, "vrhip_upload_volume: NULL voxel pointer");
+    if (set_device(r)) return VRHIP_ERR_HIP;
+    VolumeSlot *s;
+    int rc = prepare_slot(r, res, format, timestep, &s);
+    if (rc) return rc;
+    VR_HIP(r, hipMemcpyAsync(s->dev, host_voxels, volume_bytes(r), hipMemcpyHostToDevice,
+                             r->stream));
+    VR_HIP(r, hipStreamSynchronize(r->stream));
+    return VRHIP_OK;
+}
+
+int vrhip_upload_volume_device(vrhip_renderer *r, const void *dev_voxels, const uint32_t res[3],
+                               int format, uint32_t timestep)
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    VR_REQUIRE(r, dev_voxels, VRHIP_ERR_INVALID, "vrhip_upload_volume_device: NULL pointer");
+    if (set_device(r)) return VRHIP_ERR_HIP;
+    VolumeSlot *s;
+    int rc = prepare_slot(r, res, format, timestep, &s);
+    if (rc) return rc;
+    VR_HIP(r, hipMemcpyAsync(s->dev, dev_voxels, volume_bytes(r), hipMemcpyDeviceToDevice,
+                             r->stream));
+    VR_HIP(r, hipStreamSynchronize(r->stream));
+    return VRHIP_OK;
+}
+
+int vrhip_synth_volume(vrhip_renderer *r, int kind, const uint32_t res[3], int format,
+                       uint32_t timestep)
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    VR_REQUIRE(r, kind == 0 || kind == 1, VRHIP_ERR_INVALID, "vrhip_synth_volume: kind must be 0/1");
+    if (set_device(r)) return VRHIP_ERR_HIP;
+    VolumeSlot *s;
+    int rc = prepare_slot(r, res, format, timestep, &s);
+    if (rc) return rc;
+    VR_HIP(r, vr_launch_synth(kind, s->dev, res, format, r->stream));
+    VR_HIP(r, hipStreamSynchronize(r->stream));
+    return VRHIP_OK;
+}
+
+int vrhip_download_volume(vrhip_renderer *r, uint32_t timestep, void *host_dst, size_t bytes)
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    VR_REQUIRE(r, timestep < r->vols.size() && r->vols[timestep].dev, VRHIP_ERR_NODATA,
+               "No volume data is loaded.");
+    VR_REQUIRE(r, host_dst && bytes == volume_bytes(r), VRHIP_ERR_INVALID,
+               "vrhip_download_volume: size mismatch");
+    if (set_device(r)) return VRHIP_ERR_HIP;
+    VR_HIP(r, hipMemcpyAsync(host_dst, r->vols[timestep].dev, bytes, hipMemcpyDeviceToHost,
+                             r->stream));
+    VR_HIP(r, hipStreamSynchronize(r->stream));
+    return VRHIP_OK;
+}
+
+int vrhip_clear_volumes(vrhip_renderer *r)
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    (void)hipSetDevice(r->device);
+    (void)hipStreamSynchronize(r->stream);
+    for (VolumeSlot &s : r->vols) {
+        if (s.dev) (void)hipFree(s.dev);
+        if (s.bricks) (void)hipFree(s.bricks);
+    }
+    r->vols.clear();
+    r->bricks_valid = false;
+    r->format = -1;
+    r->res[0] = r->res[1] = r->res[2] = 0;
+    r->timestep = 0;
+    return VRHIP_OK;
+}
+
+int vrhip_set_timestep(vrhip_renderer *r, uint32_t timestep)
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    // volumerendercl.cpp:1169-1170: silently ignored when out of range
+    if (!r->vols.empty() && timestep >= r->vols.size()) return VRHIP_OK;
+    r->timestep = timestep;
+    return VRHIP_OK;
+}
+
+int vrhip_get_resolution(const vrhip_renderer *r, uint32_t res_xyzt[4])
+{
+    if (!r || !res_xyzt) return VRHIP_ERR_INVALID;
+    res_xyzt[0] = r->res[0];
+    res_xyzt[1] = r->res[1];
+    res_xyzt[2] = r->res[2];
+    res_xyzt[3] = r->vols.empty() ? 1u : (uint32_t)r->vols.size();
+    return VRHIP_OK;
+}
+
+int vrhip_set_transfer_function(vrhip_renderer *r, const uint8_t *rgba8, uint32_t n_entries)
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    VR_REQUIRE(r, rgba8 && n_entries > 0, VRHIP_ERR_INVALID, "Empty transfer function.");
+    VR_REQUIRE(r, n_entries <= 4096, VRHIP_ERR_UNSUPPORTED,
+               "Transfer functions above 4096 entries are not supported.");
+    if (set_device(r)) return VRHIP_ERR_HIP;
+    // CL_UNORM_INT8 -> float: c / 255.0f (OpenCL 1.2 spec 8.3.1.1)
+    std::vector<float4> table(n_entries);
+    for (uint32_t i = 0; i < n_entries; ++i) {
+        table[i].x = (float)rgba8[4 * i + 0] / 255.0f;
+        table[i].y = (float)rgba8[4 * i + 1] / 255.0f;
+        table[i].z = (float)rgba8[4 * i + 2] / 255.0f;
+        table[i].w = (float)rgba8[4 * i + 3] / 255.0f;
+    }
+    if (r->tff_n != n_entries) {
+        VR_HIP(r, hipStreamSynchronize(r->stream));
+        if (r->tff) VR_HIP(r, hipFree(r->tff));
+        r->tff = nullptr;
+        r->tff_n = 0;
+        VR_HIP(r, hipMalloc((void **)&r->tff, n_entries * sizeof(float4)));
+        r->tff_n = n_entries;
+    }
+    VR_HIP(r, hipMemcpyAsync(r->tff, table.data(), n_entries * sizeof(float4),
+                             hipMemcpyHostToDevice, r->stream));
+    VR_HIP(r, hipStreamSynchronize(r->stream));
+    return VRHIP_OK;
+}
+
+int vrhip_set_tff_prefix_sum(vrhip_renderer *r, const uint32_t *prefix, uint32_t n)
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    VR_REQUIRE(r, prefix && n > 0, VRHIP_ERR_INVALID, "Empty prefix sum.");
+    if (set_device(r)) return VRHIP_ERR_HIP;
+    if (r->prefix_n != n) {
+        VR_HIP(r, hipStreamSynchronize(r->stream));
+        if (r->prefix) VR_HIP(r, hipFree(r->prefix));
+        r->prefix = nullptr;
+        r->prefix_n = 0;
+        VR_HIP(r, hipMalloc((void **)&r->prefix, n * sizeof(uint32_t)));
+        r->prefix_n = n;
+    }
+    VR_HIP(r, hipMemcpyAsync(r->prefix, prefix, n * sizeof(uint32_t), hipMemcpyHostToDevice,
+                             r->stream));
+    VR_HIP(r, hipStreamSynchronize(r->stream));
+    return VRHIP_OK;
+}
+
+int vrhip_build_bricks(vrhip_renderer *r)
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    VR_REQUIRE(r, !r->vols.empty(), VRHIP_ERR_NODATA, "No volume data is loaded.");
+    if (set_device(r)) return VRHIP_ERR_HIP;
+    // brick size / grid: volumerendercl.cpp:620-636
+    for (int i = 0; i < 3; ++i) {
+        uint32_t e = round_pow2(r->res[i] / 64u);
+        r->brick_edge[i] = e > 1u ? e : 1u;
+        r->brick_res[i] = (float)r->res[i] / (float)r->brick_edge[i];
+        r->brick_tex[i] = (uint32_t)std::ceil((double)r->brick_res[i]);
+        r->raycast.brickRes[i] = r->brick_res[i];   // :630-631
+    }
+    VR_HIP(r, hipEventRecord(r->evb0, r->stream));
+    for (VolumeSlot &s : r->vols) {
+        if (!s.dev) return fail(r, VRHIP_ERR_NODATA,
+                                "Error loading timeseries data: size mismatch.");   // :227
+        if (s.bricks) VR_HIP(r, hipFree(s.bricks));
+        s.bricks = nullptr;
+        VR_HIP(r, hipMalloc(&s.bricks, bricks_bytes(r)));
+        VolView v = make_vol_view(r, s.dev);
+        VR_HIP(r, vr_launch_build_bricks(v, r->format, r->brick_tex, s.bricks, r->stream));
+    }
+    VR_HIP(r, hipEventRecord(r->evb1, r->stream));
+    VR_HIP(r, hipStreamSynchronize(r->stream));   // reference: _queueCL.finish() (:670)
+    r->bricks_valid = true;
+    r->bricks_timed = true;
+    return VRHIP_OK;
+}
+
+int vrhip_get_brick_info(const vrhip_renderer *r, uint32_t tex[3], float brick_res[3],
+                         uint32_t edge[3])
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    VR_REQUIRE(r, r->bricks_valid, VRHIP_ERR_NODATA, "ESS bricks not built.");
+    for (int i = 0; i < 3; ++i) {
+        if (tex) tex[i] = r->brick_tex[i];
+        if (brick_res) brick_res[i] = r->brick_res[i];
+        if (edge) edge[i] = r->brick_edge[i];
+    }
+    return VRHIP_OK;
+}
+
+int vrhip_download_bricks(vrhip_renderer *r, uint32_t timestep, void *host_dst, size_t bytes)
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    VR_REQUIRE(r, r->bricks_valid && timestep < r->vols.size() && r->vols[timestep].bricks,
+               VRHIP_ERR_NODATA, "ESS bricks not built.");
+    VR_REQUIRE(r, host_dst && bytes == bricks_bytes(r), VRHIP_ERR_INVALID,
+               "vrhip_download_bricks: size mismatch");
+    if (set_device(r)) return VRHIP_ERR_HIP;
+    VR_HIP(r, hipMemcpyAsync(host_dst, r->vols[timestep].bricks, bytes, hipMemcpyDeviceToHost,
+                             r->stream));
+    VR_HIP(r, hipStreamSynchronize(r->stream));
+    return VRHIP_OK;
+}
+
+double vrhip_last_bricks_seconds(const vrhip_renderer *r)
+{
+    if (!r || !r->bricks_timed) return 0.0;
+    float ms = 0.f;
+    if (hipEventSynchronize(r->evb1) != hipSuccess) return 0.0;
+    if (hipEventElapsedTime(&ms, r->evb0, r->evb1) != hipSuccess) return 0.0;
+    return (double)ms * 1e-3;
+}
+
+int vrhip_set_camera_params(vrhip_renderer *r, const vrhip_camera_params *p)
+{
+    if (!r || !p) return VRHIP_ERR_INVALID;
+    r->cam = *p;
+    return VRHIP_OK;
+}
+
+int vrhip_set_rendering_params(vrhip_renderer *r, const vrhip_rendering_params *p)
+{
+    if (!r || !p) return VRHIP_ERR_INVALID;
+    r->render = *p;
+    return VRHIP_OK;
+}
+
+int vrhip_set_raycast_params(vrhip_renderer *r, const vrhip_raycast_params *p)
+{
+    if (!r || !p) return VRHIP_ERR_INVALID;
+    r->raycast = *p;
+    return VRHIP_OK;
+}
+
+int vrhip_set_pathtrace_params(vrhip_renderer *r, const vrhip_pathtrace_params *p)
+{
+    if (!r || !p) return VRHIP_ERR_INVALID;
+    r->pathtrace = *p;
+    return VRHIP_OK;
+}
+
+int vrhip_set_object_ess(vrhip_renderer *r, int enabled)
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    r->use_ess = enabled != 0;
+    return VRHIP_OK;
+}
+
+int vrhip_render_frame(vrhip_renderer *r, uint32_t width, uint32_t height, float *out_rgba,
+                       int out_is_device)
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    if (set_device(r)) return VRHIP_ERR_HIP;
+    int rc = check_renderable(r, width, height);
+    if (rc) return rc;
+    rc = ensure_fb(r, width, height);
+    if (rc) return rc;
+    RaycastLaunch a;
+    fill_launch(r, width, height, &a);
+    if (out_rgba && out_is_device) a.frame.out = (float4 *)out_rgba;
+    rc = launch_timed(r, a);
+    if (rc) return rc;
+    if (out_rgba && !out_is_device) {
+        VR_HIP(r, hipMemcpyAsync(out_rgba, r->fb, (size_t)width * height * sizeof(float4),
+                                 hipMemcpyDeviceToHost, r->stream));
+        VR_HIP(r, hipStreamSynchronize(r->stream));
+    }
+    return VRHIP_OK;
+}
+
+int vrhip_render_tiles(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t tile_w,
+                       uint32_t tile_h, const uint32_t *tile_ids, uint32_t n_tiles,
+                       float *out_tiles_dev)
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    if (set_device(r)) return VRHIP_ERR_HIP;
+    int rc = check_renderable(r, width, height);
+    if (rc) return rc;
+    VR_REQUIRE(r, tile_w && tile_h && tile_w % 16 == 0 && tile_h % 16 == 0, VRHIP_ERR_INVALID,
+               "Tile size must be a positive multiple of 16.");
+    VR_REQUIRE(r, out_tiles_dev, VRHIP_ERR_INVALID, "vrhip_render_tiles: NULL output");
+    if (n_tiles == 0) return VRHIP_OK;
+    VR_REQUIRE(r, tile_ids, VRHIP_ERR_INVALID, "vrhip_render_tiles: NULL tile list");
+    const uint32_t tiles_x = (width + tile_w - 1) / tile_w, tiles_y = (height + tile_h - 1) / tile_h;
+    for (uint32_t i = 0; i < n_tiles; ++i)
+        VR_REQUIRE(r, tile_ids[i] < tiles_x * tiles_y, VRHIP_ERR_INVALID, "Tile id out of range.");
+    rc = ensure_fb(r, width, height);
+    if (rc) return rc;
+    // upload the tile list unless it is the one already resident
+    if (r->tile_ids_host.size() != n_tiles ||
+        std::memcmp(r->tile_ids_host.data(), tile_ids, n_tiles * sizeof(uint32_t)) != 0) {
+        VR_HIP(r, hipStreamSynchronize(r->stream));
+        if (r->tile_ids_host.size() < n_tiles || !r->tile_ids_dev) {
+            if (r->tile_ids_dev) VR_HIP(r, hipFree(r->tile_ids_dev));
+            r->tile_ids_dev = nullptr;
+            VR_HIP(r, hipMalloc((void **)&r->tile_ids_dev, n_tiles * sizeof(uint32_t)));
+        }
+        r->tile_ids_host.assign(tile_ids, tile_ids + n_tiles);
+        VR_HIP(r, hipMemcpyAsync(r->tile_ids_dev, r->tile_ids_host.data(),
+                                 n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice, r->stream));
+    }
+    RaycastLaunch a;
+    fill_launch(r, width, height, &a);
+    a.frame.tile_ids = r->tile_ids_dev;
+    a.frame.tile_w = tile_w;
+    a.frame.tile_h = tile_h;
+    a.frame.tiles_x = tiles_x;
+    a.frame.bpt_x = tile_w / 16;
+    a.frame.bpt = (tile_w / 16) * (tile_h / 16);
+    a.frame.out = (float4 *)out_tiles_dev;
+    a.n_blocks = n_tiles * a.frame.bpt;
+    return launch_timed(r, a);
+}
+
+double vrhip_last_kernel_seconds(const vrhip_renderer *r)
+{
+    if (!r || !r->timed) return 0.0;
+    float ms = 0.f;
+    if (hipEventSynchronize(r->ev1) != hipSuccess) return 0.0;
+    if (hipEventElapsedTime(&ms, r->ev0, r->ev1) != hipSuccess) return 0.0;
+    return (double)ms * 1e-3;
+}
+
+int vrhip_set_stats_enabled(vrhip_renderer *r, int enabled)
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    r->stats_enabled = enabled != 0;
+    return VRHIP_OK;
+}
+
+int vrhip_get_stats(const vrhip_renderer *r, vrhip_stats *out)
+{
+    if (!r || !out) return VRHIP_ERR_INVALID;
+    if (hipSetDevice(r->device) != hipSuccess) return VRHIP_ERR_HIP;
+    DevStats s;
+    VR_HIP(r, hipStreamSynchronize(r->stream));
+    VR_HIP(r, hipMemcpy(&s, r->stats_dev, sizeof s, hipMemcpyDeviceToHost));
+    out->samples_taken = s.v[0];
+    out->samples_nominal = s.v[1];
+    out->samples_shaded = s.v[2];
+    out->bricks_visited = s.v[3];
+    out->bricks_skipped = s.v[4];
+    out->rays_hit = s.v[5];
+    return VRHIP_OK;
+}
+
+static int count_touched_impl(vrhip_renderer *r, uint32_t width, uint32_t height,
+                              uint32_t tile_w, uint32_t tile_h, const uint32_t *tile_ids,
+                              uint32_t n_tiles, uint64_t *microbricks_touched,
+                              uint8_t *bitmap_host, size_t bitmap_bytes)
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    if (set_device(r)) return VRHIP_ERR_HIP;
+    int rc = check_renderable(r, width, height);
+    if (rc) return rc;
+    rc = ensure_fb(r, width, height);
+    if (rc) return rc;
+    uint32_t *ids_dev = nullptr;
+    if (tile_ids) {
+        VR_REQUIRE(r, n_tiles && tile_w && tile_h && tile_w % 16 == 0 && tile_h % 16 == 0,
+                   VRHIP_ERR_INVALID, "Tile size must be a positive multiple of 16.");
+        const uint32_t nt = ((width + tile_w - 1) / tile_w) * ((height + tile_h - 1) / tile_h);
+        for (uint32_t i = 0; i < n_tiles; ++i)
+            VR_REQUIRE(r, tile_ids[i] < nt, VRHIP_ERR_INVALID, "Tile id out of range.");
+        VR_HIP(r, hipMalloc((void **)&ids_dev, n_tiles * sizeof(uint32_t)));
+        VR_HIP(r, hipMemcpy(ids_dev, tile_ids, n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    const size_t mb = (size_t)((r->res[0] + 3) / 4) * ((r->res[1] + 3) / 4) * ((r->res[2] + 3) / 4);
+    const size_t words = (mb + 31) / 32;
+    VR_REQUIRE(r, !bitmap_host || bitmap_bytes == (mb + 7) / 8, VRHIP_ERR_INVALID,
+               "vrhip_count_touched: bitmap size mismatch");
+    uint32_t *bits = nullptr;
+    VR_HIP(r, hipMalloc((void **)&bits, words * sizeof(uint32_t)));
+    hipError_t e = hipMemsetAsync(bits, 0, words * sizeof(uint32_t), r->stream);
+    RaycastLaunch a;
+    fill_launch(r, width, height, &a);
+    a.instr = 2;
+    a.touched = bits;
+    // the instrumented pass must not disturb the accumulate buffer: render into a scratch
+    float4 *scratch = nullptr;
+    if (e == hipSuccess) e = hipMalloc((void **)&scratch, (size_t)width * height * sizeof(float4));
+    if (e == hipSuccess && r->render.iteration != 0)
+        e = hipMemcpyAsync(scratch, r->fb, (size_t)width * height * sizeof(float4),
+                           hipMemcpyDeviceToDevice, r->stream);
+    a.frame.fb = scratch;
+    if (ids_dev) {
+        a.frame.tile_ids = ids_dev;
+        a.frame.tile_w = tile_w;
+        a.frame.tile_h = tile_h;
+        a.frame.tiles_x = (width + tile_w - 1) / tile_w;
+        a.frame.bpt_x = tile_w / 16;
+        a.frame.bpt = (tile_w / 16) * (tile_h / 16);
+        a.n_blocks = n_tiles * a.frame.bpt;
+    }
+    if (e == hipSuccess) e = hipMemsetAsync(r->stats_dev, 0, sizeof(DevStats), r->stream);
+    if (e == hipSuccess) e = vr_launch_raycast(a, r->stream);
+    std::vector<uint32_t> host(words);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(host.data(), bits, words * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                           r->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
+    (void)hipFree(bits);
+    if (scratch) (void)hipFree(scratch);
+    if (ids_dev) (void)hipFree(ids_dev);
+    if (e != hipSuccess)
+        return fail(r, VRHIP_ERR_HIP,
+                    std::string("ERROR: vrhip_count_touched (") + hipGetErrorString(e) + ")");
+    uint64_t cnt = 0;
+    for (size_t i = 0; i < words; ++i) cnt += (uint64_t)__builtin_popcount(host[i]);
+    if (microbricks_touched) *microbricks_touched = cnt;
+    if (bitmap_host) std::memcpy(bitmap_host, host.data(), bitmap_bytes);
+    return VRHIP_OK;
+}
+
+int vrhip_count_touched(vrhip_renderer *r, uint32_t width, uint32_t height,
+                        uint64_t *microbricks_touched, uint8_t *bitmap_host, size_t bitmap_bytes)
+{
+    return count_touched_impl(r, width, height, 0, 0, nullptr, 0, microbricks_touched,
+                              bitmap_host, bitmap_bytes);
+}
+
+int vrhip_count_touched_tiles(vrhip_renderer *r, uint32_t width, uint32_t height,
+                              uint32_t tile_w, uint32_t tile_h, const uint32_t *tile_ids,
+                              uint32_t n_tiles, uint64_t *microbricks_touched)
+{
+    if (r && !tile_ids) return fail(r, VRHIP_ERR_INVALID, "vrhip_count_touched_tiles: NULL tile list");
+    return count_touched_impl(r, width, height, tile_w, tile_h, tile_ids, n_tiles,
+                              microbricks_touched, nullptr, 0);
+}
+
+} // extern "C"

@@ -1,0 +1,150 @@
+"""Front-end formulas that feed the hot path: the 16-float view
+matrix and the 1024-entry RGBA8 transfer-function table the reference's Qt widget hands to
+`VolumeRenderCL::updateView` / `setTransferFunction`.
+
+Restated from Qt 5 semantics (QMatrix4x4 / QPropertyAnimation); Qt is not available here,
+so these two are PARITY UNPINNED -- the pinned contract of the hot path is its numeric
+inputs (16 floats, 4096 bytes), which every test feeds identically to oracle and GPU.
+"""
+import math
+
+import numpy as np
+
+# resetCam, volumerenderwidget.cpp:91-92,1069-1074
+DEFAULT_ROTATION = (1.0, 0.0, 0.0, 0.0)     # quaternion w, x, y, z
+DEFAULT_TRANSLATION = (0.0, 0.0, 2.0)
+
+# TransferFunctionWidget::resetTransferFunction, transferfunctionwidget.cpp:338-346
+DEFAULT_STOPS = [(0.00, (0, 0, 0, 0)), (0.10, (125, 125, 125, 0)), (1.00, (0, 0, 0, 255))]
+
+# first outputs of a default-seeded std::mt19937 (reference frame seeds)
+MT19937_FIRST_SEEDS = (3499211612, 581869302, 3890346734)
+
+
+class Mt19937:
+    """std::mt19937 (32-bit Mersenne twister, init_genrand seeding); default seed 5489.
+    The reference draws one output per frame as the jitter seed (volumerendercl.cpp:212)."""
+
+    def __init__(self, seed=5489):
+        self.mt = [0] * 624
+        self.mt[0] = seed & 0xFFFFFFFF
+        for i in range(1, 624):
+            self.mt[i] = (1812433253 * (self.mt[i - 1] ^ (self.mt[i - 1] >> 30)) + i) & 0xFFFFFFFF
+        self.idx = 624
+
+    def __call__(self):
+        if self.idx >= 624:
+            mt = self.mt
+            for k in range(624):
+                y = (mt[k] & 0x80000000) | (mt[(k + 1) % 624] & 0x7FFFFFFF)
+                mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ (0x9908B0DF if y & 1 else 0)
+            self.idx = 0
+        y = self.mt[self.idx]
+        self.idx += 1
+        y ^= y >> 11
+        y ^= (y << 7) & 0x9D2C5680
+        y ^= (y << 15) & 0xEFC60000
+        y ^= y >> 18
+        return y & 0xFFFFFFFF
+
+
+def quat_from_axis_angle(axis, degrees):
+    """QQuaternion::fromAxisAndAngle (axis normalised)."""
+    a = np.asarray(axis, dtype=np.float64)
+    a = a / np.linalg.norm(a)
+    h = math.radians(degrees) / 2.0
+    s = math.sin(h)
+    return (math.cos(h), a[0] * s, a[1] * s, a[2] * s)
+
+
+def quat_mul(p, q):
+    pw, px, py, pz = p
+    qw, qx, qy, qz = q
+    return (pw * qw - px * qx - py * qy - pz * qz,
+            pw * qx + px * qw + py * qz - pz * qy,
+            pw * qy - px * qz + py * qw + pz * qx,
+            pw * qz + px * qy - py * qx + pz * qw)
+
+
+def rotation_matrix(q):
+    w, x, y, z = q
+    n = math.sqrt(w * w + x * x + y * y + z * z)
+    w, x, y, z = w / n, x / n, y / n, z / n
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def view_matrix(rotation=DEFAULT_ROTATION, translation=DEFAULT_TRANSLATION):
+    """updateViewMatrix, volumerenderwidget.cpp:1079-1098: M = R(q) * T(t) * S(t.z), handed
+    over row-major.  Upper 3x3 = t.z * R, last column = R * t."""
+    R = rotation_matrix(rotation)
+    t = np.asarray(translation, dtype=np.float64)
+    M = np.eye(4)
+    M[:3, :3] = R * t[2]
+    M[:3, 3] = R @ t
+    return [float(np.float32(v)) for v in M.reshape(-1)]
+
+
+def _ease(kind, p):
+    if kind == "linear":
+        return p
+    if kind == "quad":     # QEasingCurve::InOutQuad
+        return 2 * p * p if p < 0.5 else -2 * p * p + 4 * p - 1
+    if kind == "cubic":    # QEasingCurve::InOutCubic
+        return 4 * p * p * p if p < 0.5 else 0.5 * ((2 * p - 2) ** 3) + 1
+    raise ValueError(kind)
+
+
+def tff_from_stops(stops=DEFAULT_STOPS, n=1024, easing="linear"):
+    """updateTransferFunction, volumerenderwidget.cpp:916-938: entry i samples the key-value
+    animation at time qRound(i/n*8192) of 8192; QColor channels interpolate as
+    int(f + (t - f) * p) (QVariantAnimation's _q_interpolate), then max(0, c - 3)."""
+    stops = sorted(stops, key=lambda s: s[0])
+    if stops[0][0] > 0.0:
+        stops = [(0.0, stops[0][1])] + stops
+    if stops[-1][0] < 1.0:
+        stops = stops + [(1.0, stops[-1][1])]
+    out = np.zeros((n, 4), dtype=np.uint8)
+    for i in range(n):
+        time = int(math.floor(i / n * 8192.0 + 0.5))
+        p = _ease(easing, time / 8192.0)
+        k = 0
+        while k + 2 < len(stops) and p >= stops[k + 1][0]:
+            k += 1
+        (p0, c0), (p1, c1) = stops[k], stops[k + 1]
+        lp = 0.0 if p1 == p0 else (p - p0) / (p1 - p0)
+        for c in range(4):
+            v = int(c0[c] + (c1[c] - c0[c]) * lp)
+            v = min(255, max(0, v))
+            out[i, c] = max(0, v - 3)
+    return out
+
+
+def opaque_ramp_tff(n=1024):
+    """ERT stress table of SURVEY 8(d): alpha = clamp(4*(x - 0.25)), grey ramp colour."""
+    x = (np.arange(n) + 0.5) / n
+    out = np.zeros((n, 4), dtype=np.uint8)
+    out[:, 3] = np.clip(np.round(255 * np.clip(4 * (x - 0.25), 0, 1)), 0, 255)
+    out[:, 0] = np.round(255 * x)
+    out[:, 1] = np.round(255 * (1 - x))
+    out[:, 2] = 128
+    return out
+
+
+def haze_tff(n=1024, alpha=12):
+    """Semi-transparent table (no ERT, every sample shaded or not by `alpha`): keeps rays
+    alive through the whole volume -- the dense-sampling regime of SURVEY 7."""
+    x = (np.arange(n) + 0.5) / n
+    out = np.zeros((n, 4), dtype=np.uint8)
+    out[:, 0] = np.round(255 * x)
+    out[:, 1] = np.round(200 * (1 - x))
+    out[:, 2] = 90
+    out[:, 3] = np.where(x > 0.05, alpha, 0)
+    return out
+
+
+def prefix_sum(tff):
+    """volumerendercl.cpp:879-884."""
+    tff = np.asarray(tff, dtype=np.uint8).reshape(-1, 4)
+    return np.cumsum(tff[:, 3].astype(np.uint64)).astype(np.uint32)

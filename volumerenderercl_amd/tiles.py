@@ -1,0 +1,88 @@
+"""Image-tile decomposition of one frame over the GPUs of a node.
+
+The reference is single-GPU; this layer is new.  Pixels are independent, so the frame is
+cut into tile_w x tile_h tiles dealt to ranks in a diagonal interleave (load balance under
+ESS/ERT: neighbouring tiles -- similar cost -- go to different ranks), every rank holds the
+whole volume, renders its tiles into a compact buffer and rank 0 gathers them over
+RCCL/xGMI (torch.distributed `gather`, backend "nccl" == RCCL; "gloo" in the CPU tests).
+One collective per frame, 16*W*H/N bytes per peer.
+"""
+import numpy as np
+
+
+class TileSplit:
+    def __init__(self, width, height, tile_w, tile_h, world, rank):
+        if tile_w % 16 or tile_h % 16:
+            raise ValueError("Tile size must be a positive multiple of 16.")
+        self.W, self.H, self.tw, self.th = int(width), int(height), int(tile_w), int(tile_h)
+        self.world, self.rank = int(world), int(rank)
+        self.tiles_x = (self.W + self.tw - 1) // self.tw
+        self.tiles_y = (self.H + self.th - 1) // self.th
+        self.n_tiles = self.tiles_x * self.tiles_y
+        ids = np.arange(self.n_tiles, dtype=np.uint32)
+        self.owner = ((ids % self.tiles_x) + (ids // self.tiles_x)) % self.world
+        self.tiles_of = [ids[self.owner == r] for r in range(self.world)]
+        self.cap = max(len(t) for t in self.tiles_of)     # slots per rank (equal-size gather)
+        self.my_tiles = self.tiles_of[self.rank]
+
+    def tile_rect(self, t):
+        tx, ty = int(t) % self.tiles_x, int(t) // self.tiles_x
+        x0, y0 = tx * self.tw, ty * self.th
+        return x0, y0, min(self.tw, self.W - x0), min(self.th, self.H - y0)
+
+
+class TileDriver:
+    """Renders one frame: full-frame launch at world == 1, tiles + gather otherwise.
+
+    `render_tiles_fn(tile_ids, out)` fills out[k] (tile_h x tile_w x 4 floats) for tile k;
+    the default drives vrhip_render_tiles on the renderer's GPU."""
+
+    def __init__(self, vr, split, device, render_tiles_fn=None, dist=None):
+        import torch
+        self.torch = torch
+        self.vr, self.split, self.device = vr, split, device
+        self.render_tiles_fn = render_tiles_fn
+        s = split
+        if dist is None and s.world > 1:
+            import torch.distributed as dist
+        self.dist = dist
+        if s.world > 1:
+            self.local = torch.zeros((s.cap, s.th, s.tw, 4), dtype=torch.float32, device=device)
+            if s.rank == 0:
+                self.staging = [torch.zeros_like(self.local) for _ in range(s.world)]
+                # padded frame viewed as [tiles_y, tiles_x, th, tw, 4]
+                self.padded = torch.zeros((s.tiles_y * s.th, s.tiles_x * s.tw, 4),
+                                          dtype=torch.float32, device=device)
+                self.tile_view = self.padded.view(s.tiles_y, s.th, s.tiles_x, s.tw, 4).permute(
+                    0, 2, 1, 3, 4)
+                self.idx = []
+                for r in range(s.world):
+                    t = torch.as_tensor(s.tiles_of[r].astype(np.int64), device=device)
+                    self.idx.append((t // s.tiles_x, t % s.tiles_x))
+
+    def render_frame(self, frame):
+        """Returns the assembled H x W x 4 frame on rank 0 (None elsewhere)."""
+        s = self.split
+        if s.world == 1:
+            if self.render_tiles_fn is None:
+                self.vr.runRaycast(s.W, s.H, out_dev_ptr=frame.data_ptr())
+                return frame
+            out = self.torch.zeros((s.n_tiles, s.th, s.tw, 4), dtype=self.torch.float32,
+                                   device=self.device)
+            self.render_tiles_fn(s.my_tiles, out)
+            for k, t in enumerate(s.my_tiles):
+                x0, y0, w, h = s.tile_rect(t)
+                frame[y0:y0 + h, x0:x0 + w] = out[k, :h, :w]
+            return frame
+        if self.render_tiles_fn is None:
+            self.vr.render_tiles(s.W, s.H, s.tw, s.th, s.my_tiles, self.local.data_ptr())
+        else:
+            self.render_tiles_fn(s.my_tiles, self.local)
+        self.dist.gather(self.local, self.staging if s.rank == 0 else None, dst=0)
+        if s.rank != 0:
+            return None
+        for r in range(s.world):
+            ty, tx = self.idx[r]
+            self.tile_view[ty, tx] = self.staging[r][: len(s.tiles_of[r])]
+        frame.copy_(self.padded[: s.H, : s.W])
+        return frame
