@@ -58,9 +58,9 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(vr, vol_host, bricks_host, tff, fmt, W, H, target_s):
+def cpu_baseline(vr, vol_host, bricks_host, tff, fmt, W, H, target_s, use_ess=True):
     """Oracle (CPU restatement, OpenMP over rows) timed on a bounded sample of the same
-    frame: evenly spaced 2-row stripes, grown until ~target_s of CPU work."""
+    frame: evenly spaced 8-row stripes, grown until ~target_s of CPU work."""
     from oracle import vro
     cam, rp, rc, pt = vr.params()
     ocam = vro.CameraParams.from_buffer_copy(bytes(cam))
@@ -68,25 +68,28 @@ def cpu_baseline(vr, vol_host, bricks_host, tff, fmt, W, H, target_s):
     orc = vro.RaycastParams.from_buffer_copy(bytes(rc))
     opt = vro.PathtraceParams.from_buffer_copy(bytes(pt))
     prefix = vro.prefix_sum(tff)
-    cores = vro.lib().vro_num_threads()
+    cores = host_cpu_share()
+    SH = 8   # stripe height (rows); the oracle parallelises over 8-pixel row chunks
     done_rows, samples, secs = 0, 0, 0.0
-    n_stripes = 8
+    n_stripes = 4
     rows_seen = set()
+    passes = 0
     while True:
-        ys = [int((k + 0.5) * H / n_stripes) & ~1 for k in range(n_stripes)]
-        ys = [y for y in ys if y not in rows_seen]
+        ys = [(int((k + 0.5) * H / n_stripes) // SH) * SH for k in range(n_stripes)]
+        ys = [y for y in ys if y not in rows_seen and y + SH <= H]
         for y in ys:
             t0 = time.perf_counter()
-            _, st, _ = vro.render_tile(vol_host, fmt, tff, ocam, orp, orc, opt, use_ess=True,
-                                       W=W, H=H, tile=(0, y, W, 2), bricks=bricks_host,
-                                       prefix=prefix)
+            _, st, _ = vro.render_tile(vol_host, fmt, tff, ocam, orp, orc, opt, use_ess=use_ess,
+                                       W=W, H=H, tile=(0, y, W, SH), bricks=bricks_host,
+                                       prefix=prefix, threads=cores)
             secs += time.perf_counter() - t0
             samples += st["samples_taken"]
             rows_seen.add(y)
-            done_rows += 2
+            done_rows += SH
             if secs >= target_s:
                 break
-        if secs >= target_s or n_stripes * 2 >= H:
+        passes += 1
+        if secs >= target_s or n_stripes * SH >= H:
             break
         n_stripes *= 2
     return {
@@ -94,9 +97,21 @@ def cpu_baseline(vr, vol_host, bricks_host, tff, fmt, W, H, target_s):
         "unit": "Msamples/s",
         "cores": int(cores),
         "kind": "port",
-        "sample": "%d of %d image rows (2-row stripes, evenly spaced) of the same frame, "
-                  "%.1f s of CPU work, %d samples" % (done_rows, H, secs, samples),
+        "sample": "%d of %d image rows (%d-row stripes, evenly spaced) of the same frame and "
+                  "seed, %.1f s of CPU work, %d samples taken" % (done_rows, H, SH, secs, samples),
     }
+
+
+def host_cpu_share():
+    """Threads this process may actually use: min(affinity mask, cgroup cpu quota)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
 
 
 def main():
@@ -225,7 +240,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             vol_host = vr.downloadVolume()
             bricks_host = vr.downloadBricks()
-            cpu = cpu_baseline(vr, vol_host, bricks_host, tff, fmt, W, H, args.cpu_seconds)
+            cpu = cpu_baseline(vr, vol_host, bricks_host, tff, fmt, W, H, args.cpu_seconds, use_ess=ess)
             del vol_host
 
     if rank == 0:

@@ -90,9 +90,9 @@ void vrhip_destroy(vrhip_renderer *r);
 const char *vrhip_last_error(const vrhip_renderer *r);
 /* getCurrentDeviceName (volumerendercl.cpp:1114-1117) */
 int vrhip_device_name(const vrhip_renderer *r, char *buf, size_t buf_len);
-/* Launch on a caller-owned hipStream_t (e.g. torch's current stream) instead of the
- * renderer's own stream; NULL restores the own stream. */
-int vrhip_set_stream(vrhip_renderer *r, void *hip_stream);
+/* Launch on a caller-owned hipStream_t (e.g. torch's current stream; NULL is the legacy
+ * default stream) instead of the renderer's own stream; use_own != 0 restores the latter. */
+int vrhip_set_stream(vrhip_renderer *r, void *hip_stream, int use_own);
 
 /* ---- volume: volDataToCLmem (volumerendercl.cpp:690-759) ----------------------- */
 /* Dense x-fastest scalar field (CL_R image) of `format`, host memory. */

@@ -341,17 +341,48 @@ int vro_intersect_bbox(const float o[3], const float d[3], const float lower[3],
     return minTmax > maxTmin;
 }
 
-/* volumeraycast.cl:159-178; returns -gradient.xyz as used by the caller (:814) */
+/* Trilinear blend of the 2x2x2 texels (xi, yi, zi) with weights (a, b, c): the filter of
+ * vol_linear() on explicit texel indices. */
+static float vol_tri(const vol_t *v, const int xi[2], const int yi[2], const int zi[2], float a,
+                     float b, float c)
+{
+    float c00 = lerpf(vox_raw(v, xi[0], yi[0], zi[0]), vox_raw(v, xi[1], yi[0], zi[0]), a);
+    float c10 = lerpf(vox_raw(v, xi[0], yi[1], zi[0]), vox_raw(v, xi[1], yi[1], zi[0]), a);
+    float c01 = lerpf(vox_raw(v, xi[0], yi[0], zi[1]), vox_raw(v, xi[1], yi[0], zi[1]), a);
+    float c11 = lerpf(vox_raw(v, xi[0], yi[1], zi[1]), vox_raw(v, xi[1], yi[1], zi[1]), a);
+    float c0 = lerpf(c00, c10, b);
+    float c1 = lerpf(c01, c11, b);
+    return lerpf(c0, c1, c) * v->inv_max;
+}
+
+/* volumeraycast.cl:159-178; returns -gradient.xyz as used by the caller (:814).
+ *
+ * The six taps sit at pos -+ 1/volRes per axis (:162-171), i.e. exactly one texel away
+ * from the centre sample.  They are evaluated in texel space: the centre sample's filter
+ * weights (a, b, c) with the texel indices shifted by -+1 and clamped to the edge
+ * (CLAMP_TO_EDGE).  This equals the literal form up to the fp32 rounding of the
+ * coordinate add (<= 2^-12 texel at 2048^3, below the 8-bit weight precision of the
+ * texture units the reference ran on) and is the parity definition shared with the HIP
+ * kernel, which reuses the 4x4x4-neighbourhood loads between taps (32 instead of 56). */
 static f3 neg_gradient_central_diff(const vol_t *v, f3 pos)
 {
-    f3 off = mk3(1.0f / v->fw, 1.0f / v->fh, 1.0f / v->fd);
+    float ub = pos.x * v->fw - 0.5f, vb = pos.y * v->fh - 0.5f, wb = pos.z * v->fd - 0.5f;
+    float fx = floorf(ub), fy = floorf(vb), fz = floorf(wb);
+    float a = ub - fx, b = vb - fy, c = wb - fz;
+    int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+    int X[4], Y[4], Z[4]; /* texel indices i-1, i, i+1, i+2, clamped to the edge */
+    for (int k = 0; k < 4; ++k) {
+        X[k] = iclamp(ix - 1 + k, 0, v->w - 1);
+        Y[k] = iclamp(iy - 1 + k, 0, v->h - 1);
+        Z[k] = iclamp(iz - 1 + k, 0, v->d - 1);
+    }
     f3 s1, s2;
-    s1.x = vol_linear(v, pos.x + (-off.x), pos.y + 0.0f, pos.z + 0.0f);
-    s1.y = vol_linear(v, pos.x + 0.0f, pos.y + (-off.y), pos.z + 0.0f);
-    s1.z = vol_linear(v, pos.x + 0.0f, pos.y + 0.0f, pos.z + (-off.z));
-    s2.x = vol_linear(v, pos.x + off.x, pos.y + 0.0f, pos.z + 0.0f);
-    s2.y = vol_linear(v, pos.x + 0.0f, pos.y + off.y, pos.z + 0.0f);
-    s2.z = vol_linear(v, pos.x + 0.0f, pos.y + 0.0f, pos.z + off.z);
+    s1.x = vol_tri(v, X + 0, Y + 1, Z + 1, a, b, c);
+    s2.x = vol_tri(v, X + 2, Y + 1, Z + 1, a, b, c);
+    s1.y = vol_tri(v, X + 1, Y + 0, Z + 1, a, b, c);
+    s2.y = vol_tri(v, X + 1, Y + 2, Z + 1, a, b, c);
+    s1.z = vol_tri(v, X + 1, Y + 1, Z + 0, a, b, c);
+    s2.z = vol_tri(v, X + 1, Y + 1, Z + 2, a, b, c);
     f3 g = sub3(s2, s1);
     f3 n = normalize3(g);
     if (dot3(g, g) == 0.0f) /* length(normal) == 0 <=> g == 0, given normalize(0) = 0 */
@@ -854,13 +885,18 @@ int vro_render_tile(const vro_scene *scene, const vro_camera_params *cam,
     {
         vro_stats st;
         memset(&st, 0, sizeof st);
-#pragma omp for schedule(dynamic, 1)
-        for (int64_t ly = 0; ly < (int64_t)h; ++ly)
-            for (uint32_t lx = 0; lx < w; ++lx) {
+        /* work unit = 8 consecutive pixels of a row, handed out dynamically */
+        const int64_t cw = ((int64_t)w + 7) / 8;
+#pragma omp for schedule(dynamic, 4)
+        for (int64_t u = 0; u < (int64_t)h * cw; ++u) {
+            const int64_t ly = u / cw;
+            const uint32_t xb = (uint32_t)(u % cw) * 8u;
+            for (uint32_t lx = xb; lx < xb + 8u && lx < w; ++lx) {
                 size_t o = ((size_t)ly * w + lx) * 4;
                 render_pixel(&v, &k, x0 + lx, y0 + (uint32_t)ly, in_accum ? in_accum + o : NULL,
                              out + o, &st);
             }
+        }
 #pragma omp critical
         {
             total.samples_taken += st.samples_taken;

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvrhip.so")
+# VRHIP_LIB_PATH selects an alternative build of the same library (A/B kernel experiments)
+LIB_PATH = os.environ.get("VRHIP_LIB_PATH") or os.path.join(_HERE, "libvrhip.so")
 
 OK, ERR_INVALID, ERR_HIP, ERR_NODATA, ERR_UNSUPPORTED = range(5)
 UCHAR, USHORT, FLOAT = 0, 1, 2
@@ -61,7 +62,7 @@ SYMBOLS = {
     "vrhip_destroy": (None, [_H]),
     "vrhip_last_error": (C.c_char_p, [_H]),
     "vrhip_device_name": (C.c_int, [_H, C.c_char_p, C.c_size_t]),
-    "vrhip_set_stream": (C.c_int, [_H, C.c_void_p]),
+    "vrhip_set_stream": (C.c_int, [_H, C.c_void_p, C.c_int]),
     "vrhip_upload_volume": (C.c_int, [_H, C.c_void_p, _U3, C.c_int, C.c_uint32]),
     "vrhip_upload_volume_device": (C.c_int, [_H, C.c_void_p, _U3, C.c_int, C.c_uint32]),
     "vrhip_synth_volume": (C.c_int, [_H, C.c_int, _U3, C.c_int, C.c_uint32]),

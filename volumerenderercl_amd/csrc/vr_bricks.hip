@@ -109,7 +109,8 @@ hipError_t build_typed(const VolView &vol, const uint32_t tex[3], void *out, hip
     const int dim[3] = {vol.w, vol.h, vol.d};
     for (int i = 0; i < 3; ++i) vpc[i] = (int)ceilf((float)dim[i] / (float)tex[i]);
     constexpr int VEC = 16 / (int)sizeof(VT);
-    const bool fast = ((size_t)vol.w * sizeof(VT)) % 16 == 0 && vpc[0] % VEC == 0 &&
+    const bool fast = ((size_t)vol.row * sizeof(VT)) % 16 == 0 &&
+                      (vol.row - (unsigned long long)vol.w) * sizeof(VT) >= 16 && vpc[0] % VEC == 0 &&
                       ((uintptr_t)vol.data % 16) == 0;
     dim3 grid(tex[1] * tex[2]), block(kThreads);
     size_t lds = 2 * (size_t)tex[0] * sizeof(uint32_t);
@@ -127,7 +128,9 @@ hipError_t build_typed(const VolView &vol, const uint32_t tex[3], void *out, hip
 // SURVEY 8(d) synthetic fields: p = 2(i+0.5)/N - 1; sphere d = max(0, 1-|p|/0.9);
 // shells = d*(0.5+0.5cos(24 pi |p|)) with values < 0.35 zeroed.
 template <typename VT>
-__global__ __launch_bounds__(kThreads) void vr_synth_kernel(VT *dst, int w, int h, int d, int kind)
+__global__ __launch_bounds__(kThreads) void vr_synth_kernel(VT *dst, int w, int h, int d,
+                                                             unsigned long long row,
+                                                             unsigned long long slice, int kind)
 {
     const size_t n = (size_t)w * h * d;
     for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n;
@@ -145,9 +148,10 @@ __global__ __launch_bounds__(kThreads) void vr_synth_kernel(VT *dst, int w, int 
             dv = dv * (0.5 + 0.5 * cos(24.0 * 3.14159265358979323846 * rr));
             if (dv < 0.35) dv = 0.0;
         }
-        if (sizeof(VT) == 1) dst[i] = (VT)llround(255.0 * dv);
-        else if (sizeof(VT) == 2) dst[i] = (VT)llround(65535.0 * dv);
-        else dst[i] = (VT)dv;
+        const size_t o = (size_t)z * slice + (size_t)y * row + (size_t)x;
+        if (sizeof(VT) == 1) dst[o] = (VT)llround(255.0 * dv);
+        else if (sizeof(VT) == 2) dst[o] = (VT)llround(65535.0 * dv);
+        else dst[o] = (VT)dv;
     }
 }
 
@@ -164,22 +168,22 @@ hipError_t vr_launch_build_bricks(const VolView &vol, int format, const uint32_t
     }
 }
 
-hipError_t vr_launch_synth(int kind, void *dst, const uint32_t res[3], int format,
-                           hipStream_t stream)
+hipError_t vr_launch_synth(int kind, void *dst, const uint32_t res[3], unsigned long long row,
+                           unsigned long long slice, int format, hipStream_t stream)
 {
     dim3 grid(256 * 32), block(kThreads);
     switch (format) {
     case VRHIP_UCHAR:
         hipLaunchKernelGGL(vr_synth_kernel<uint8_t>, grid, block, 0, stream, (uint8_t *)dst,
-                           (int)res[0], (int)res[1], (int)res[2], kind);
+                           (int)res[0], (int)res[1], (int)res[2], row, slice, kind);
         break;
     case VRHIP_USHORT:
         hipLaunchKernelGGL(vr_synth_kernel<uint16_t>, grid, block, 0, stream, (uint16_t *)dst,
-                           (int)res[0], (int)res[1], (int)res[2], kind);
+                           (int)res[0], (int)res[1], (int)res[2], row, slice, kind);
         break;
     case VRHIP_FLOAT:
         hipLaunchKernelGGL(vr_synth_kernel<float>, grid, block, 0, stream, (float *)dst,
-                           (int)res[0], (int)res[1], (int)res[2], kind);
+                           (int)res[0], (int)res[1], (int)res[2], row, slice, kind);
         break;
     default: return hipErrorInvalidValue;
     }

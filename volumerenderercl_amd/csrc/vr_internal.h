@@ -29,13 +29,30 @@ struct TfView {
     uint32_t prefix_n;
 };
 
+// ESS decision per brick, precomputed from (bricks, TF, prefix sum): bit = 1 when the
+// reference's test `TF(max).a < 1e-6 && prefix[min] == prefix[max]` (volumeraycast.cl:
+// 777-787) holds.  x-fastest bit index; `oob_skip` is the decision for the (0,0) value
+// defined for out-of-range cells.
+struct SkipView {
+    const uint32_t *bits;
+    uint32_t n_words;
+    uint32_t oob_skip;
+    uint32_t in_lds;       // bitmap is staged in LDS by every workgroup
+};
+
+// One 8x8-pixel patch (= one wave64) of the work queue.
+struct WaveTile {
+    uint16_t tx8, ty8;     // patch origin / 8 in the frame
+    uint32_t out_base;     // index of its first pixel in FrameView::out
+};
+
 struct FrameView {
     uint32_t W, H;         // frame size in pixels
     uint32_t gsx, gsy;     // padded launch size the reference derives the camera from
-    uint32_t blocks_x;     // 16x16-pixel blocks per row (full-frame mode)
-    // tile mode (tile_ids != nullptr): compact output [n_tiles][tile_h][tile_w]
-    const uint32_t *tile_ids;
-    uint32_t tile_w, tile_h, tiles_x, bpt_x, bpt;
+    const WaveTile *queue; // n_wave_tiles entries, processed in order (centre first)
+    uint32_t n_wave_tiles;
+    uint32_t out_stride;   // pixels per row of `out`
+    uint32_t *queue_head;  // zeroed before each launch
     float4 *fb;            // W*H frame / accumulate buffer (always written)
     float4 *out;           // optional second destination (device), frame or tile layout
 };
@@ -48,6 +65,7 @@ struct RaycastLaunch {
     VolView vol;
     BrickView bricks;
     TfView tf;
+    SkipView skip;
     FrameView frame;
     vrhip_camera_params cam;
     vrhip_rendering_params render;
@@ -58,12 +76,17 @@ struct RaycastLaunch {
     int instr;             // 0 none, 1 stats, 2 stats + touched bitmap
     DevStats *stats;
     uint32_t *touched;
-    uint32_t n_blocks;
+    int num_cus;
 };
 
 hipError_t vr_launch_raycast(const RaycastLaunch &a, hipStream_t stream);
 
+// skip bitmap from bricks + TF + prefix
+hipError_t vr_launch_skipmap(const BrickView &bricks, int format, float inv_max, const TfView &tf,
+                             uint32_t *bits, uint32_t n_words, uint32_t *oob_skip_dev,
+                             hipStream_t stream);
+
 hipError_t vr_launch_build_bricks(const VolView &vol, int format, const uint32_t tex[3],
                                   void *bricks_out, hipStream_t stream);
-hipError_t vr_launch_synth(int kind, void *dst, const uint32_t res[3], int format,
-                           hipStream_t stream);
+hipError_t vr_launch_synth(int kind, void *dst, const uint32_t res[3], unsigned long long row,
+                           unsigned long long slice, int format, hipStream_t stream);

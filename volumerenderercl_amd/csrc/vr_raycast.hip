@@ -4,16 +4,59 @@
 // (/root/reference/src/kernel/volumeraycast.cl:589-926).  CDNA has no image/sampler
 // hardware (__HIP_NO_IMAGE_SUPPORT), so every read_imagef of the reference is restated
 // as explicit address arithmetic + loads following the OpenCL 1.2 image rules
-// (SURVEY.md App. B).  Work decomposition: one lane per pixel, one wave64 per 8x8-pixel
-// patch (the reference's work-group), four waves (16x16 pixels) per workgroup sharing
-// the transfer function in LDS.
+// (SURVEY.md App. B).
+//
+// Execution design (DESIGN.md "Kernels"):
+//  * one lane per pixel, one wave64 per 8x8-pixel patch (the reference's work-group);
+//  * PERSISTENT workgroups (4 waves), sized to fill the 256 CUs once; every wave pulls
+//    8x8 patches from a global queue ordered centre-first, so the expensive rays start
+//    first and the tail is filled with cheap ones (dynamic load balance);
+//  * the transfer function (float4 table) and the ESS skip bitmap (1 bit per brick,
+//    precomputed from bricks + TF + prefix sum) live in LDS: a DDA step over an empty
+//    brick touches no global memory at all;
+//  * the reference's nested loops (DDA over bricks / samples inside a brick) are flattened
+//    into a per-lane state machine driven by wave ballots: in every round all lanes that
+//    have a sample to take take it together; lanes that need brick steps take a bounded
+//    number of them first.  The per-ray sequence of t values, and therefore the image, is
+//    exactly the reference's.
+#include <cstdio>
+#include <cstdlib>
+
 #include "vr_device_math.h"
 #include "vr_internal.h"
 
 namespace {
 
-constexpr int kBlockDim = 256;   // 4 waves, 16x16 pixels
-constexpr int kBlockPix = 16;
+constexpr int kBlockDim = 256;       // 4 waves
+constexpr int kMaxBrickSteps = 4;    // DDA steps per round while other lanes wait to sample
+#ifndef VR_BATCH
+#define VR_BATCH 4
+#endif
+constexpr int kBatch = VR_BATCH;     // consecutive samples of a ray evaluated per round
+
+enum : int { S_DONE = 0, S_BRICK = 1, S_SAMPLE = 2 };
+
+// Diagnostic build only (-DVR_STAMPS, tools/stamps.sh): per-phase shader-clock totals summed
+// over all waves.  Every stamp drains the memory queues, so only the SHARES are meaningful;
+// the stamp values leave the kernel through g_stamps alone and feed no output.
+#ifdef VR_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define VR_STAMP_DECL unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = vr_stamp(), st_first = st_last
+#define VR_STAMP(i) do { unsigned long long n_ = vr_stamp(); st_acc[i] += n_ - st_last; st_last = n_; } while (0)
+#define VR_COUNT(i) st_acc[i] += 1
+#define VR_STAMP_FLUSH do { if ((threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_stamps[i_], st_acc[i_]); atomicAdd(&g_stamps[12], vr_stamp() - st_first); } } while (0)
+__device__ __forceinline__ unsigned long long vr_stamp()
+{
+    unsigned long long t;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#else
+#define VR_STAMP_DECL
+#define VR_STAMP(i)
+#define VR_COUNT(i)
+#define VR_STAMP_FLUSH
+#endif
 
 // ------------------------------------------------------------------ volume reads
 
@@ -71,6 +114,50 @@ struct Vol {
         return lerpf(c0, c1, c) * inv_max;
     }
 
+    // -gradientCentralDiff(vol, pos).xyz (volumeraycast.cl:159-178, :814).  The six taps sit
+    // exactly one texel from the centre sample (offset = 1/volRes, :162): they are evaluated
+    // in texel space -- the centre's filter weights with indices shifted by -+1 and clamped to
+    // the edge -- so the 4x4x4 neighbourhood is loaded once: 32 voxel loads and one set of
+    // coordinate arithmetic instead of 6 x (8 loads + coordinates).  DESIGN.md "Numerics".
+    VR_DEV f3 neg_gradient(float px, float py, float pz) const
+    {
+        float ub = px * fw - 0.5f, vb = py * fh - 0.5f, sb = pz * fd - 0.5f;
+        float fx = floorf(ub), fy = floorf(vb), fz = floorf(sb);
+        float a = ub - fx, b = vb - fy, c = sb - fz;
+        int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+        int X[4], Y[4], Z[4];
+        unsigned long long zo[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            X[k] = iclamp(ix - 1 + k, 0, w1);
+            Y[k] = iclamp(iy - 1 + k, 0, h1);
+            Z[k] = iclamp(iz - 1 + k, 0, d1);
+            zo[k] = (unsigned long long)Z[k] * slice;
+        }
+#define VR_L(xi, yi, zi) raw(X[xi], Y[yi], zo[zi], Z[zi])
+#define VR_R(yi, zi) lerpf(VR_L(1, yi, zi), VR_L(2, yi, zi), a)   /* texels (x0, x1)   */
+#define VR_M(yi, zi) lerpf(VR_L(0, yi, zi), VR_L(1, yi, zi), a)   /* texels (x0-1, x0) */
+#define VR_P(yi, zi) lerpf(VR_L(2, yi, zi), VR_L(3, yi, zi), a)   /* texels (x1, x1+1) */
+        const float r01 = VR_R(0, 1), r11 = VR_R(1, 1), r21 = VR_R(2, 1), r31 = VR_R(3, 1);
+        const float r02 = VR_R(0, 2), r12 = VR_R(1, 2), r22 = VR_R(2, 2), r32 = VR_R(3, 2);
+        const float r10 = VR_R(1, 0), r20 = VR_R(2, 0), r13 = VR_R(1, 3), r23 = VR_R(2, 3);
+        f3 s1, s2;
+        s1.x = lerpf(lerpf(VR_M(1, 1), VR_M(2, 1), b), lerpf(VR_M(1, 2), VR_M(2, 2), b), c) * inv_max;
+        s2.x = lerpf(lerpf(VR_P(1, 1), VR_P(2, 1), b), lerpf(VR_P(1, 2), VR_P(2, 2), b), c) * inv_max;
+        s1.y = lerpf(lerpf(r01, r11, b), lerpf(r02, r12, b), c) * inv_max;
+        s2.y = lerpf(lerpf(r21, r31, b), lerpf(r22, r32, b), c) * inv_max;
+        s1.z = lerpf(lerpf(r10, r20, b), lerpf(r11, r21, b), c) * inv_max;
+        s2.z = lerpf(lerpf(r12, r22, b), lerpf(r13, r23, b), c) * inv_max;
+#undef VR_L
+#undef VR_R
+#undef VR_M
+#undef VR_P
+        f3 g = sub3(s2, s1);
+        f3 n = normalize3(g);
+        if (dot3(g, g) == 0.0f) n = mk3(0.57735f, 0.57735f, 0.57735f);
+        return neg3(n);
+    }
+
     // read_imagef(vol, nearestSmp, pos).x -- normalised, CLAMP (border 0), NEAREST
     VR_DEV float nearest(float px, float py, float pz) const
     {
@@ -83,7 +170,7 @@ struct Vol {
     }
 };
 
-// read_imagef(tffData, linearSmp, x) on the LDS copy of the float4 table
+// read_imagef(tffData, linearSmp, x) on the float4 table
 VR_DEV float4 tff_linear(const float4 *tff, int n, float x)
 {
     float ub = x * (float)n - 0.5f;
@@ -117,19 +204,35 @@ VR_DEV uint32_t prefix_nearest(const uint32_t *prefix, uint32_t n, float x)
     return prefix[(int)fi];
 }
 
-template <typename VT>
-VR_DEV void brick_minmax(const BrickView &b, float inv_max, int cx, int cy, int cz, float *mn,
-                         float *mx)
+// The reference's per-brick skip test (volumeraycast.cl:777-787) on one (min,max) pair.
+VR_DEV bool skip_test(const TfView &tf, float mn, float mx)
 {
-    if (cx < 0 || cy < 0 || cz < 0 || cx >= b.bw || cy >= b.bh || cz >= b.bd) {
-        *mn = 0.0f;
-        *mx = 0.0f;
-        return;
+    float alphaMax = tff_linear_alpha(tf.tff, (int)tf.tff_n, mx);
+    if (!(alphaMax < 1e-6f)) return false;
+    return prefix_nearest(tf.prefix, tf.prefix_n, mn) == prefix_nearest(tf.prefix, tf.prefix_n, mx);
+}
+
+// One bit per brick + one trailing word for out-of-range cells, which the reference reads
+// with undefined result and SURVEY A.6 defines as (min,max) = (0,0).
+template <typename VT>
+__global__ __launch_bounds__(kBlockDim) void vr_skipmap_kernel(BrickView b, float inv_max,
+                                                               TfView tf, uint32_t *bits,
+                                                               uint32_t n_words)
+{
+    const size_t n = (size_t)b.bw * b.bh * b.bd;
+    const size_t i = (size_t)blockIdx.x * kBlockDim + threadIdx.x;
+    bool s = false;
+    if (i < n) {
+        const VT *p = (const VT *)b.data;
+        s = skip_test(tf, (float)p[2 * i] * inv_max, (float)p[2 * i + 1] * inv_max);
     }
-    size_t i = 2 * (((size_t)cz * (size_t)b.bh + (size_t)cy) * (size_t)b.bw + (size_t)cx);
-    const VT *p = (const VT *)b.data;
-    *mn = (float)p[i] * inv_max;
-    *mx = (float)p[i + 1] * inv_max;
+    unsigned long long m = __ballot(s);
+    if ((threadIdx.x & 63) == 0) {
+        size_t w = (i >> 6) * 2;
+        if (w < n_words) bits[w] = (uint32_t)m;
+        if (w + 1 < n_words) bits[w + 1] = (uint32_t)(m >> 32);
+    }
+    if (i == 0) bits[n_words] = skip_test(tf, 0.0f, 0.0f) ? 1u : 0u;
 }
 
 // ------------------------------------------------------------------ ray set-up
@@ -202,40 +305,6 @@ VR_DEV Ray make_ray(uint32_t gx, uint32_t gy, const FrameView &fr, const vrhip_c
     return r;
 }
 
-// pixel owned by this lane + where it lands in fb / out
-struct PixelMap {
-    uint32_t gx, gy;
-    size_t out_index;
-    bool inside;
-};
-
-VR_DEV PixelMap map_pixel(const FrameView &fr)
-{
-    const uint32_t tid = threadIdx.x;
-    const uint32_t wave = tid >> 6, lane = tid & 63u;
-    const uint32_t lx = (lane & 7u) + 8u * (wave & 1u);
-    const uint32_t ly = (lane >> 3) + 8u * (wave >> 1);
-    PixelMap m;
-    if (fr.tile_ids) {
-        uint32_t b = blockIdx.x;
-        uint32_t ti = b / fr.bpt, sub = b - ti * fr.bpt;
-        uint32_t tile = fr.tile_ids[ti];
-        uint32_t tx = tile % fr.tiles_x, ty = tile / fr.tiles_x;
-        uint32_t px = (sub % fr.bpt_x) * kBlockPix + lx, py = (sub / fr.bpt_x) * kBlockPix + ly;
-        m.gx = tx * fr.tile_w + px;
-        m.gy = ty * fr.tile_h + py;
-        m.out_index = ((size_t)ti * fr.tile_h + py) * fr.tile_w + px;
-    } else {
-        uint32_t b = blockIdx.x;
-        uint32_t by = b / fr.blocks_x, bx = b - by * fr.blocks_x;
-        m.gx = bx * kBlockPix + lx;
-        m.gy = by * kBlockPix + ly;
-        m.out_index = (size_t)m.gy * fr.W + m.gx;
-    }
-    m.inside = m.gx < fr.W && m.gy < fr.H;
-    return m;
-}
-
 VR_DEV unsigned long long wave_sum(unsigned long long v)
 {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -244,74 +313,98 @@ VR_DEV unsigned long long wave_sum(unsigned long long v)
 
 // ------------------------------------------------------------------ ray cast
 
-template <typename VT, bool ESS, int INSTR>
+template <typename VT, bool ESS, int INSTR, bool SKIP_LDS>
 __global__ __launch_bounds__(kBlockDim) void vr_raycast_kernel(
-    VolView vv, BrickView bricks, TfView tf, FrameView fr, vrhip_camera_params cam,
+    VolView vv, BrickView bricks, TfView tf, SkipView skip, FrameView fr, vrhip_camera_params cam,
     vrhip_rendering_params rp, vrhip_raycast_params rc, DevStats *stats, uint32_t *touched)
 {
-    extern __shared__ float4 s_tff[];
+    // LDS: [tff_n float4][skip words + 1]
+    extern __shared__ float4 s_mem[];
+    VR_STAMP_DECL;
+    float4 *s_tff = s_mem;
+    uint32_t *s_skip = reinterpret_cast<uint32_t *>(s_mem + tf.tff_n);
     for (uint32_t i = threadIdx.x; i < tf.tff_n; i += kBlockDim) s_tff[i] = tf.tff[i];
+    if (ESS && SKIP_LDS)
+        for (uint32_t i = threadIdx.x; i <= skip.n_words; i += kBlockDim) s_skip[i] = skip.bits[i];
     __syncthreads();
+    VR_STAMP(8);
 
-    const PixelMap pm = map_pixel(fr);
+    const uint32_t lane = threadIdx.x & 63u;
+    const int tffn = (int)tf.tff_n;
     unsigned long long c_taken = 0, c_nominal = 0, c_shaded = 0, c_bricks = 0, c_skipped = 0,
                        c_hit = 0;
 
-    if (pm.inside) {
-        Vol<VT, INSTR> vol;
-        vol.p = (const VT *)vv.data;
-        vol.w1 = vv.w - 1; vol.h1 = vv.h - 1; vol.d1 = vv.d - 1;
-        vol.fw = vv.fw; vol.fh = vv.fh; vol.fd = vv.fd;
-        vol.inv_max = vv.inv_max;
-        vol.row = vv.row; vol.slice = vv.slice;
-        vol.mbx = vv.mbx; vol.mby = vv.mby;
-        vol.touched = touched;
-        const int tffn = (int)tf.tff_n;
+    Vol<VT, INSTR> vol;
+    vol.p = (const VT *)vv.data;
+    vol.w1 = vv.w - 1; vol.h1 = vv.h - 1; vol.d1 = vv.d - 1;
+    vol.fw = vv.fw; vol.fh = vv.fh; vol.fd = vv.fd;
+    vol.inv_max = vv.inv_max;
+    vol.row = vv.row; vol.slice = vv.slice;
+    vol.mbx = vv.mbx; vol.mby = vv.mby;
+    vol.touched = touched;
+    const f3 voxLen = mk3(1.f / vol.fw, 1.f / vol.fh, 1.f / vol.fd);
+    const float refInterval = 1.f / rc.samplingRate;
+    const int bw = bricks.bw, bh = bricks.bh, bd = bricks.bd;
+    float brickLen[3] = {0.f, 0.f, 0.f}, brickDia = 0.f;
+    if (ESS) {
+        for (int i = 0; i < 3; ++i) brickLen[i] = 1.f / rc.brickRes[i];
+        brickDia = sqrtf(((brickLen[0] * brickLen[0]) + (brickLen[1] * brickLen[1])) +
+                         (brickLen[2] * brickLen[2])) * 2.f;
+    }
 
-        const Ray ray = make_ray(pm.gx, pm.gy, fr, cam, rp);
-        float result[4] = {ray.env[0], ray.env[1], ray.env[2], ray.env[3]};
+    // every wave pulls 8x8 patches until the queue is drained (exit condition reached by
+    // every wave: the head only grows)
+    // The next ticket is drawn while the current patch is marched, so the ~microseconds of the
+    // contended atomic are hidden; every wave draws exactly one ticket past the end.
+    uint32_t q_next = 0;
+    if (lane == 0) q_next = atomicAdd(fr.queue_head, 1u);
+    for (;;) {
+        const uint32_t q = __builtin_amdgcn_readfirstlane(q_next);
+        if (q >= fr.n_wave_tiles) break;
+        const WaveTile wt = fr.queue[q];
+        if (lane == 0) q_next = atomicAdd(fr.queue_head, 1u);
+        VR_STAMP(0);
+        VR_COUNT(11);
+        const uint32_t lx = lane & 7u, ly = lane >> 3;
+        const uint32_t gx = (uint32_t)wt.tx8 * 8u + lx, gy = (uint32_t)wt.ty8 * 8u + ly;
+        const bool inside = gx < fr.W && gy < fr.H;
+
+        const Ray ray = make_ray(gx, gy, fr, cam, rp);
+        float res0 = ray.env[0], res1 = ray.env[1], res2 = ray.env[2], alpha = 0.f;
         float tnear = ray.tnear;
         const float tfar = ray.tfar;
         const float sampleDist = tfar - tnear;
-        if (ray.hit && sampleDist > 0.f) {
-            c_hit = 1;
-            const f3 camPos = ray.cam, rayDir = ray.dir;
+        const f3 camPos = ray.cam, rayDir = ray.dir;
+
+        int state = S_DONE;
+        float t = 0.f, t_exit = tfar, stepSize = 0.f, offset = 0.f;
+        int stepv[3] = {0, 0, 0}, cell[3] = {0, 0, 0}, exitc[3] = {0, 0, 0};
+        float tv[3] = {0, 0, 0}, deltaT[3] = {0, 0, 0};
+        // per-ray invariants of illumination()/specularBlinnPhong() (:280-303)
+        const f3 toLight = neg3(rayDir);
+        const f3 lgt = normalize3(toLight);
+        f3 hv = add3(toLight, lgt);
+        const bool hvalid = !(dot3(hv, hv) < 1.e-6f);
+        hv = normalize3(hv);
+
+        if (inside && ray.hit && sampleDist > 0.f) {
+            if (INSTR) c_hit++;
             // volumeraycast.cl:709-733
             f3 resf = mk3(vol.fw, vol.fh, vol.fd);
-            float stepSize = vmin(sampleDist,
-                                  sampleDist / (rc.samplingRate *
-                                                len3(mul3(scale3(rayDir, sampleDist), resf))));
+            stepSize = vmin(sampleDist, sampleDist / (rc.samplingRate *
+                                                      len3(mul3(scale3(rayDir, sampleDist), resf))));
             float samples = ceilf(sampleDist / stepSize);
             stepSize = sampleDist / samples;
-            c_nominal = (unsigned long long)samples;
-
+            if (INSTR) c_nominal += (unsigned long long)samples;
             tnear = vmax(0.f, tnear);
-            float alpha = 0.f;
-            float t = tnear;
-            f3 voxLen = mk3(1.f / vol.fw, 1.f / vol.fh, 1.f / vol.fd);
-            const float refInterval = 1.f / rc.samplingRate;
-            float t_exit = tfar;
-            const float offset = (len3(voxLen) * ray.rnd) * 2.0f;
-
-            // per-ray invariants of illumination()/specularBlinnPhong() (:280-303):
-            // l = fast_normalize(-rayDir), h = normalize(-rayDir + l)
-            const f3 toLight = neg3(rayDir);
-            const f3 lgt = normalize3(toLight);
-            f3 hv = add3(toLight, lgt);
-            const bool hvalid = !(dot3(hv, hv) < 1.e-6f);
-            hv = normalize3(hv);
-            const f3 goff = voxLen;   // gradientCentralDiff: offset = 1/volRes (:162)
-
-            // 3-D DDA set-up (:737-760)
-            int stepv[3] = {0, 0, 0}, cell[3] = {0, 0, 0}, exitc[3] = {0, 0, 0};
-            float tv[3] = {0, 0, 0}, deltaT[3] = {0, 0, 0}, brickDia = 0.f;
-            if (ESS) {
-                const int bres[3] = {bricks.bw, bricks.bh, bricks.bd};
-                float brickLen[3];
+            t = tnear;
+            offset = (len3(voxLen) * ray.rnd) * 2.0f;
+            state = ESS ? S_BRICK : S_SAMPLE;
+            if (ESS) {   // 3-D DDA set-up (:737-760)
+                const int bres[3] = {bw, bh, bd};
                 const float dirv[3] = {rayDir.x, rayDir.y, rayDir.z};
                 const float camv[3] = {camPos.x, camPos.y, camPos.z};
                 for (int i = 0; i < 3; ++i) {
-                    brickLen[i] = 1.f / rc.brickRes[i];
                     float invRay = 1.f / dirv[i];
                     stepv[i] = dirv[i] > 0.f ? 1 : (dirv[i] < 0.f ? -1 : 0);
                     deltaT[i] = (float)stepv[i] * ((brickLen[i] * 2.f) * invRay);
@@ -322,145 +415,265 @@ __global__ __launch_bounds__(kBlockDim) void vr_raycast_kernel(
                     exitc[i] = stepv[i] * bres[i];
                     if (exitc[i] < 0) exitc[i] = -1;
                 }
-                brickDia = sqrtf(((brickLen[0] * brickLen[0]) + (brickLen[1] * brickLen[1])) +
-                                 (brickLen[2] * brickLen[2])) * 2.f;
             }
+        }
 
-            bool first = true;
-            while (ESS ? (t < tfar) : first) {
-                first = false;
-                if (ESS) {
-                    float mn, mx;
-                    brick_minmax<VT>(bricks, vol.inv_max, cell[0], cell[1], cell[2], &mn, &mx);
-                    if (INSTR) c_bricks++;
-                    float inc0 = (tv[0] <= tv[1]) && (tv[0] <= tv[2]) ? 1.f : 0.f;
-                    float inc1 = (tv[1] <= tv[0]) && (tv[1] <= tv[2]) ? 1.f : 0.f;
-                    float inc2 = (tv[2] <= tv[0]) && (tv[2] <= tv[1]) ? 1.f : 0.f;
-                    cell[0] += (int)inc0 * stepv[0];
-                    cell[1] += (int)inc1 * stepv[1];
-                    cell[2] += (int)inc2 * stepv[2];
-                    t_exit = ((tv[0] * inc0) + (tv[1] * inc1)) + (tv[2] * inc2);
-                    t_exit = vclamp(t_exit, t + stepSize, t + brickDia);
-                    tv[0] += inc0 * deltaT[0];
-                    tv[1] += inc1 * deltaT[1];
-                    tv[2] += inc2 * deltaT[2];
-                    float alphaMax = tff_linear_alpha(s_tff, tffn, mx);
-                    if (alphaMax < 1e-6f) {
-                        uint32_t pmin = prefix_nearest(tf.prefix, tf.prefix_n, mn);
-                        uint32_t pmax = prefix_nearest(tf.prefix, tf.prefix_n, mx);
-                        if (pmin == pmax) {
-                            if (INSTR) c_skipped++;
-                            t = t_exit;
-                            continue;
+        VR_STAMP(1);
+        // ---- flattened DDA / sample state machine
+        for (;;) {
+            VR_COUNT(10);
+            if (ESS) {
+                for (int it = 0;; ++it) {
+                    const bool inB = state == S_BRICK;
+                    if (!__ballot(inB)) break;
+                    if (it >= kMaxBrickSteps && __ballot(state == S_SAMPLE)) break;
+                    if (inB) {
+                        if (!(t < tfar)) {   // outer loop condition (:763)
+                            state = S_DONE;
+                        } else {
+                            bool skp;
+                            const int cx = cell[0], cy = cell[1], cz = cell[2];
+                            const uint32_t *sb = SKIP_LDS ? s_skip : skip.bits;
+                            if (cx < 0 || cy < 0 || cz < 0 || cx >= bw || cy >= bh || cz >= bd) {
+                                skp = sb[skip.n_words] != 0u;
+                            } else {
+                                uint32_t idx = ((uint32_t)cz * (uint32_t)bh + (uint32_t)cy) *
+                                                   (uint32_t)bw + (uint32_t)cx;
+                                skp = (sb[idx >> 5] >> (idx & 31u)) & 1u;
+                            }
+                            if (INSTR) c_bricks++;
+                            float inc0 = (tv[0] <= tv[1]) && (tv[0] <= tv[2]) ? 1.f : 0.f;
+                            float inc1 = (tv[1] <= tv[0]) && (tv[1] <= tv[2]) ? 1.f : 0.f;
+                            float inc2 = (tv[2] <= tv[0]) && (tv[2] <= tv[1]) ? 1.f : 0.f;
+                            cell[0] += (int)inc0 * stepv[0];
+                            cell[1] += (int)inc1 * stepv[1];
+                            cell[2] += (int)inc2 * stepv[2];
+                            t_exit = ((tv[0] * inc0) + (tv[1] * inc1)) + (tv[2] * inc2);
+                            t_exit = vclamp(t_exit, t + stepSize, t + brickDia);
+                            tv[0] += inc0 * deltaT[0];
+                            tv[1] += inc1 * deltaT[1];
+                            tv[2] += inc2 * deltaT[2];
+                            if (skp) {
+                                if (INSTR) c_skipped++;
+                                t = t_exit;   // :784-785 `continue`
+                            } else {
+                                state = S_SAMPLE;
+                            }
                         }
                     }
                 }
-                // inner sample loop (:790-880)
-                while (t < t_exit) {
-                    if (INSTR) c_taken++;
-                    f3 pos = add3(camPos, scale3(rayDir, t - offset));
-                    pos = mk3(pos.x * 0.5f + 0.5f, pos.y * 0.5f + 0.5f, pos.z * 0.5f + 0.5f);
-                    float density = rp.useLinear ? vol.linear(pos.x, pos.y, pos.z)
-                                                 : vol.nearest(pos.x, pos.y, pos.z);
-                    float4 tfc = tff_linear(s_tff, tffn, density);
+            }
+            VR_STAMP(2);
+            if (state == S_SAMPLE) {
+                // ---- up to kBatch consecutive samples of this ray per round (inner loop,
+                // :790-880).  Colour and opacity of a sample do not depend on the running
+                // alpha, so the batch is evaluated as independent straight-line code (loads of
+                // all its fetches in flight together) and only the cheap front-to-back
+                // compositing below is sequential.  Samples past ERT / t_exit are speculative:
+                // fetched from clamped (always valid) addresses and never composited.
+                float tk[kBatch];
+                bool vk[kBatch], litk[kBatch];
+                tk[0] = t;
+                vk[0] = t < t_exit;   // inner loop condition (:790)
+#pragma unroll
+                for (int k = 1; k < kBatch; ++k) {
+                    tk[k] = tk[k - 1] + stepSize;                                   // :879
+                    vk[k] = vk[k - 1] && !(tk[k - 1] >= tfar) && (tk[k] < t_exit);  // :868, :790
+                    // the traffic-instrumented variant must not touch speculative voxels
+                    if (INSTR == 2) vk[k] = false;
+                }
+                f3 pk[kBatch];
+                float dens[kBatch];
+#pragma unroll
+                for (int k = 0; k < kBatch; ++k) {
+                    f3 pos = add3(camPos, scale3(rayDir, tk[k] - offset));
+                    pk[k] = mk3(pos.x * 0.5f + 0.5f, pos.y * 0.5f + 0.5f, pos.z * 0.5f + 0.5f);
+                    dens[k] = 0.f;
+                }
+                if (rp.useLinear) {
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k)
+                        if (INSTR != 2 || vk[k]) dens[k] = vol.linear(pk[k].x, pk[k].y, pk[k].z);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k)
+                        if (INSTR != 2 || vk[k]) dens[k] = vol.nearest(pk[k].x, pk[k].y, pk[k].z);
+                }
+                VR_STAMP(3);
+                float4 tfc[kBatch];
+                float opk[kBatch];
+#pragma unroll
+                for (int k = 0; k < kBatch; ++k) tfc[k] = tff_linear(s_tff, tffn, dens[k]);
+                VR_STAMP(4);
+#pragma unroll
+                for (int k = 0; k < kBatch; ++k) {
                     f3 grad = mk3(0.f, 0.f, 0.f);
-                    const bool lit = tfc.w > 0.1f;
-                    if (lit && (rp.illumType == 1 || (rc.contours && !rp.illumType))) {
-                        // -gradientCentralDiff (:159-178, :814)
-                        f3 s1, s2;
-                        s1.x = vol.linear(pos.x + (-goff.x), pos.y + 0.0f, pos.z + 0.0f);
-                        s1.y = vol.linear(pos.x + 0.0f, pos.y + (-goff.y), pos.z + 0.0f);
-                        s1.z = vol.linear(pos.x + 0.0f, pos.y + 0.0f, pos.z + (-goff.z));
-                        s2.x = vol.linear(pos.x + goff.x, pos.y + 0.0f, pos.z + 0.0f);
-                        s2.y = vol.linear(pos.x + 0.0f, pos.y + goff.y, pos.z + 0.0f);
-                        s2.z = vol.linear(pos.x + 0.0f, pos.y + 0.0f, pos.z + goff.z);
-                        f3 g = sub3(s2, s1);
-                        f3 n = normalize3(g);
-                        if (dot3(g, g) == 0.0f) n = mk3(0.57735f, 0.57735f, 0.57735f);
-                        grad = neg3(n);
-                    }
+                    const bool lit = vk[k] && tfc[k].w > 0.1f;
+                    litk[k] = lit && rp.illumType == 1;
+                    if (lit && (rp.illumType == 1 || (rc.contours && !rp.illumType)))
+                        grad = vol.neg_gradient(pk[k].x, pk[k].y, pk[k].z);
                     if (lit && rp.illumType == 1) {
-                        if (INSTR) c_shaded++;
                         // illumination (:294-303)
                         float ndl = vmax(0.f, dot3(grad, lgt));
                         float sp = hvalid ? vr_powr(vmax(dot3(grad, hv), 0.f), 40.f) : 0.0f;
                         sp = sp * 0.15f;
-                        tfc.x = ((tfc.x * 0.15f) + ((tfc.x * ndl) * 0.7f)) + sp;
-                        tfc.y = ((tfc.y * 0.15f) + ((tfc.y * ndl) * 0.7f)) + sp;
-                        tfc.z = ((tfc.z * 0.15f) + ((tfc.z * ndl) * 0.7f)) + sp;
+                        tfc[k].x = ((tfc[k].x * 0.15f) + ((tfc[k].x * ndl) * 0.7f)) + sp;
+                        tfc[k].y = ((tfc[k].y * 0.15f) + ((tfc[k].y * ndl) * 0.7f)) + sp;
+                        tfc[k].z = ((tfc[k].z * 0.15f) + ((tfc[k].z * ndl) * 0.7f)) + sp;
                     }
                     if (lit && rc.contours) {
                         float e = fabsf(dot3(rayDir, grad));
-                        tfc.x *= e; tfc.y *= e; tfc.z *= e;
+                        tfc[k].x *= e; tfc[k].y *= e; tfc[k].z *= e;
                     }
-                    tfc.x = ray.env[0] - tfc.x;
-                    tfc.y = ray.env[1] - tfc.y;
-                    tfc.z = ray.env[2] - tfc.z;
+                    tfc[k].x = ray.env[0] - tfc[k].x;
+                    tfc[k].y = ray.env[1] - tfc[k].y;
+                    tfc[k].z = ray.env[2] - tfc[k].z;
                     if (rc.aerial) {
-                        float depthCue = 1.f - (t - tnear) / sampleDist;
-                        tfc.w *= depthCue;
+                        float depthCue = 1.f - (tk[k] - tnear) / sampleDist;
+                        tfc[k].w *= depthCue;
                     }
-                    float opacity = 1.f - vr_powr(1.f - tfc.w, refInterval);
-                    float oma = 1.f - alpha;
-                    result[0] = result[0] - (tfc.x * opacity) * oma;
-                    result[1] = result[1] - (tfc.y * opacity) * oma;
-                    result[2] = result[2] - (tfc.z * opacity) * oma;
-                    alpha = alpha + opacity * oma;
-                    if (t >= tfar) break;
-                    if (alpha >= 0.98f) break;   // (double)alpha > 0.98, ERT_THRESHOLD (:28,:869)
-                    t += stepSize;
                 }
-                if (!ESS) break;
-                if (t >= tfar || alpha >= 0.98f) break;
-                if (cell[0] == exitc[0] || cell[1] == exitc[1] || cell[2] == exitc[2]) break;
-                t = t_exit;
+                VR_STAMP(5);
+#pragma unroll
+                for (int k = 0; k < kBatch; ++k) {
+                    // opacity correction (:864).  alpha == 0 gives 1 - powr(1, y) == 0 exactly,
+                    // so the whole wave skips the powr when no lane has a non-zero alpha.
+                    opk[k] = 0.f;
+                    if (__ballot(vk[k] && tfc[k].w != 0.f))
+                        opk[k] = 1.f - vr_powr(1.f - tfc[k].w, refInterval);
+                }
+                // sequential front-to-back compositing (:865-879)
+#pragma unroll
+                for (int k = 0; k < kBatch; ++k) {
+                    if (vk[k] && state == S_SAMPLE) {
+                        if (INSTR) { c_taken++; if (litk[k]) c_shaded++; }
+                        float oma = 1.f - alpha;
+                        res0 = res0 - (tfc[k].x * opk[k]) * oma;
+                        res1 = res1 - (tfc[k].y * opk[k]) * oma;
+                        res2 = res2 - (tfc[k].z * opk[k]) * oma;
+                        alpha = alpha + opk[k] * oma;
+                        // (double)alpha > 0.98 <=> alpha >= 0.98f (ERT_THRESHOLD, :28)
+                        if (tk[k] >= tfar || alpha >= 0.98f) state = S_DONE;   // break; :882 breaks
+                        else t = tk[k] + stepSize;
+                    }
+                }
+                if (state == S_SAMPLE && !(t < t_exit)) {   // inner loop left by its condition
+                    if (!ESS) state = S_DONE;
+                    else if (t >= tfar || alpha >= 0.98f) state = S_DONE;                  // :882
+                    else if (cell[0] == exitc[0] || cell[1] == exitc[1] || cell[2] == exitc[2])
+                        state = S_DONE;                                                     // :883
+                    else { t = t_exit; state = S_BRICK; }                                   // :884
+                }
+                VR_STAMP(6);
             }
-            result[3] = alpha;
-            // running mean over iterations (:898-909), fp32 accumulate buffer
-            if (rp.iteration != 0) {
-                float4 prev = fr.fb[(size_t)pm.gy * fr.W + pm.gx];
-                float it1 = (float)(rp.iteration + 1u);
-                result[0] = prev.x + (result[0] - prev.x) / it1;
-                result[1] = prev.y + (result[1] - prev.y) / it1;
-                result[2] = prev.z + (result[2] - prev.z) / it1;
-            }
+            if (!__ballot(state != S_DONE)) break;
         }
-        float4 o = make_float4(result[0], result[1], result[2], result[3]);
-        fr.fb[(size_t)pm.gy * fr.W + pm.gx] = o;
-        if (fr.out) fr.out[pm.out_index] = o;
+
+        if (inside) {
+            // running mean over iterations (:898-909), fp32 accumulate buffer
+            const size_t fi = (size_t)gy * fr.W + gx;
+            if (rp.iteration != 0 && ray.hit && sampleDist > 0.f) {
+                float4 prev = fr.fb[fi];
+                float it1 = (float)(rp.iteration + 1u);
+                res0 = prev.x + (res0 - prev.x) / it1;
+                res1 = prev.y + (res1 - prev.y) / it1;
+                res2 = prev.z + (res2 - prev.z) / it1;
+            }
+            float4 o = make_float4(res0, res1, res2, (ray.hit && sampleDist > 0.f) ? alpha : ray.env[3]);
+            fr.fb[fi] = o;
+            if (fr.out) fr.out[(size_t)wt.out_base + (size_t)ly * fr.out_stride + lx] = o;
+        }
+        VR_STAMP(7);
     }
+    VR_STAMP_FLUSH;
 
     if (INSTR) {
         unsigned long long c[6] = {c_taken, c_nominal, c_shaded, c_bricks, c_skipped, c_hit};
         for (int i = 0; i < 6; ++i) {
             unsigned long long s = wave_sum(c[i]);
-            if ((threadIdx.x & 63) == 0 && s) atomicAdd(&stats->v[i], s);
+            if (lane == 0 && s) atomicAdd(&stats->v[i], s);
         }
     }
+}
+
+template <typename K>
+int blocks_per_cu(K kernel, size_t lds)
+{
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kBlockDim, lds) != hipSuccess ||
+        nb < 1)
+        nb = 1;
+    return nb;
+}
+
+template <typename VT, bool ESS, int INSTR, bool SKIP_LDS>
+hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
+{
+    auto kernel = vr_raycast_kernel<VT, ESS, INSTR, SKIP_LDS>;
+    size_t lds = (size_t)a.tf.tff_n * sizeof(float4);
+    if (ESS && SKIP_LDS) lds += ((size_t)a.skip.n_words + 1) * sizeof(uint32_t);
+    static int cached_nb = 0;
+    static size_t cached_lds = ~(size_t)0;
+    if (cached_lds != lds) {
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void *)kernel,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        cached_nb = blocks_per_cu(kernel, lds);
+        if (const char *e = getenv("VRHIP_BLOCKS_PER_CU")) {   // tuning / experiments
+            int v = atoi(e);
+            if (v > 0) cached_nb = v;
+        }
+        if (getenv("VRHIP_DEBUG"))
+            fprintf(stderr, "[vrhip] raycast variant: lds=%zu B, blocks/CU=%d, CUs=%d\n", lds,
+                    cached_nb, a.num_cus);
+        cached_lds = lds;
+    }
+    uint32_t want = (a.frame.n_wave_tiles + 3u) / 4u;
+    uint32_t cap = (uint32_t)(a.num_cus > 0 ? a.num_cus : 256) * (uint32_t)cached_nb;
+    dim3 grid(want < cap ? want : cap), block(kBlockDim);
+    if (grid.x == 0) return hipSuccess;
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, a.vol, a.bricks, a.tf, a.skip, a.frame,
+                       a.cam, a.render, a.raycast, a.stats, a.touched);
+    return hipGetLastError();
 }
 
 template <typename VT>
 hipError_t launch_typed(const RaycastLaunch &a, hipStream_t stream)
 {
-    dim3 grid(a.n_blocks), block(kBlockDim);
-    size_t lds = (size_t)a.tf.tff_n * sizeof(float4);
-#define VR_LAUNCH(ESS, INSTR)                                                                 \
-    hipLaunchKernelGGL((vr_raycast_kernel<VT, ESS, INSTR>), grid, block, lds, stream, a.vol,  \
-                       a.bricks, a.tf, a.frame, a.cam, a.render, a.raycast, a.stats, a.touched)
+    const bool lds = a.skip.in_lds != 0;
     if (a.use_ess) {
-        if (a.instr == 0) VR_LAUNCH(true, 0);
-        else if (a.instr == 1) VR_LAUNCH(true, 1);
-        else VR_LAUNCH(true, 2);
-    } else {
-        if (a.instr == 0) VR_LAUNCH(false, 0);
-        else if (a.instr == 1) VR_LAUNCH(false, 1);
-        else VR_LAUNCH(false, 2);
+        if (lds) {
+            if (a.instr == 0) return launch_variant<VT, true, 0, true>(a, stream);
+            if (a.instr == 1) return launch_variant<VT, true, 1, true>(a, stream);
+            return launch_variant<VT, true, 2, true>(a, stream);
+        }
+        if (a.instr == 0) return launch_variant<VT, true, 0, false>(a, stream);
+        if (a.instr == 1) return launch_variant<VT, true, 1, false>(a, stream);
+        return launch_variant<VT, true, 2, false>(a, stream);
     }
-#undef VR_LAUNCH
-    return hipGetLastError();
+    if (a.instr == 0) return launch_variant<VT, false, 0, false>(a, stream);
+    if (a.instr == 1) return launch_variant<VT, false, 1, false>(a, stream);
+    return launch_variant<VT, false, 2, false>(a, stream);
 }
 
 } // namespace
+
+#ifdef VR_STAMPS
+// diagnostic builds only: read (and optionally clear) the per-phase cycle totals
+extern "C" int vrhip_debug_stamps(unsigned long long out[16], int reset)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), 16 * sizeof(unsigned long long)) != hipSuccess)
+        return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 hipError_t vr_launch_raycast(const RaycastLaunch &a, hipStream_t stream)
 {
@@ -470,4 +683,27 @@ hipError_t vr_launch_raycast(const RaycastLaunch &a, hipStream_t stream)
     case VRHIP_FLOAT: return launch_typed<float>(a, stream);
     default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t vr_launch_skipmap(const BrickView &bricks, int format, float inv_max, const TfView &tf,
+                             uint32_t *bits, uint32_t n_words, uint32_t *, hipStream_t stream)
+{
+    const size_t n = (size_t)bricks.bw * bricks.bh * bricks.bd;
+    dim3 grid((unsigned)((n + kBlockDim - 1) / kBlockDim)), block(kBlockDim);
+    switch (format) {
+    case VRHIP_UCHAR:
+        hipLaunchKernelGGL(vr_skipmap_kernel<uint8_t>, grid, block, 0, stream, bricks, inv_max, tf,
+                           bits, n_words);
+        break;
+    case VRHIP_USHORT:
+        hipLaunchKernelGGL(vr_skipmap_kernel<uint16_t>, grid, block, 0, stream, bricks, inv_max, tf,
+                           bits, n_words);
+        break;
+    case VRHIP_FLOAT:
+        hipLaunchKernelGGL(vr_skipmap_kernel<float>, grid, block, 0, stream, bricks, inv_max, tf,
+                           bits, n_words);
+        break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }

@@ -3,8 +3,10 @@
 // objects, /root/reference/src/core/volumerendercl.h:446-463).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -20,10 +22,13 @@ struct VolumeSlot {
 
 std::string g_create_error;
 
+constexpr uint32_t kSkipLdsMaxBytes = 64 * 1024;   // bitmap staged in LDS up to this size
+
 } // namespace
 
 struct vrhip_renderer {
     int device = 0;
+    int num_cus = 256;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     mutable std::string err;
@@ -31,6 +36,10 @@ struct vrhip_renderer {
 
     uint32_t res[3] = {0, 0, 0};
     int format = -1;
+    // HBM layout of a time step: dense x-fastest rows with padded, non-power-of-two row and
+    // slice pitches (elements) so that neighbouring rows / slices spread over the memory
+    // channels (DESIGN.md "Data layout")
+    unsigned long long row_pitch = 0, slice_pitch = 0;
     std::vector<VolumeSlot> vols;
     uint32_t timestep = 0;
 
@@ -43,6 +52,11 @@ struct vrhip_renderer {
     float brick_res[3] = {1, 1, 1};
     bool bricks_valid = false;
 
+    // ESS skip bitmap of the current timestep (derived from bricks + TF + prefix)
+    uint32_t *skip_bits = nullptr;
+    uint32_t skip_words = 0, skip_cap = 0;
+    bool skip_dirty = true;
+
     vrhip_camera_params cam;
     vrhip_rendering_params render;
     vrhip_raycast_params raycast;
@@ -54,10 +68,12 @@ struct vrhip_renderer {
 
     DevStats *stats_dev = nullptr;
     bool stats_enabled = false;
-    vrhip_stats last_stats;
 
-    uint32_t *tile_ids_dev = nullptr;
-    std::vector<uint32_t> tile_ids_host;
+    // work queue of 8x8 wave tiles (centre first) for the current frame/tile set
+    WaveTile *queue_dev = nullptr;
+    uint32_t queue_n = 0, queue_cap = 0;
+    uint32_t *queue_head = nullptr;
+    std::vector<uint32_t> queue_key;   // W, H, tile_w, tile_h, tile ids...
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evb0 = nullptr, evb1 = nullptr;
     bool timed = false, bricks_timed = false;
@@ -68,7 +84,6 @@ struct vrhip_renderer {
         std::memset(&cam, 0, sizeof cam);
         std::memset(&render, 0, sizeof render);
         std::memset(&raycast, 0, sizeof raycast);
-        std::memset(&last_stats, 0, sizeof last_stats);
         const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
         std::memcpy(cam.viewMat, ident, sizeof ident);
         for (int i = 0; i < 3; ++i) { cam.bbox_bl[i] = -1.f; cam.bbox_tr[i] = 1.f; }
@@ -107,9 +122,42 @@ int fail(const vrhip_renderer *r, int code, const std::string &msg)
 
 size_t fmt_bytes(int format) { return format == VRHIP_UCHAR ? 1 : format == VRHIP_USHORT ? 2 : 4; }
 
-size_t volume_bytes(const vrhip_renderer *r)
+size_t volume_bytes(const vrhip_renderer *r)   // dense (host-side) size
 {
     return (size_t)r->res[0] * r->res[1] * r->res[2] * fmt_bytes(r->format);
+}
+
+size_t volume_alloc_bytes(const vrhip_renderer *r)
+{
+    return (size_t)r->slice_pitch * r->res[2] * fmt_bytes(r->format);
+}
+
+void set_pitches(vrhip_renderer *r)
+{
+    const size_t bpv = fmt_bytes(r->format);
+    size_t pad = 64;   // bytes per row; VRHIP_PITCH_PAD=0 gives the dense power-of-two layout
+    if (const char *e = getenv("VRHIP_PITCH_PAD")) pad = (size_t)atoi(e);
+    size_t row_b = (((size_t)r->res[0] * bpv + 63) / 64) * 64 + (pad / 16) * 16;
+    if (pad == 0) row_b = (size_t)r->res[0] * bpv;
+    r->row_pitch = row_b / bpv;
+    r->slice_pitch = r->row_pitch * ((size_t)r->res[1] + (pad ? 1 : 0));
+}
+
+// dense host/device array <-> pitched device volume
+hipError_t copy_volume(const vrhip_renderer *r, void *pitched_dev, void *dense, bool to_device,
+                       hipMemcpyKind kind, hipStream_t stream)
+{
+    const size_t bpv = fmt_bytes(r->format);
+    hipMemcpy3DParms p;
+    std::memset(&p, 0, sizeof p);
+    hipPitchedPtr dev = make_hipPitchedPtr(pitched_dev, r->row_pitch * bpv, r->res[0] * bpv,
+                                           r->slice_pitch / r->row_pitch);
+    hipPitchedPtr den = make_hipPitchedPtr(dense, r->res[0] * bpv, r->res[0] * bpv, r->res[1]);
+    p.srcPtr = to_device ? den : dev;
+    p.dstPtr = to_device ? dev : den;
+    p.extent = make_hipExtent(r->res[0] * bpv, r->res[1], r->res[2]);
+    p.kind = kind;
+    return hipMemcpy3DAsync(&p, stream);
 }
 
 size_t bricks_bytes(const vrhip_renderer *r)
@@ -131,19 +179,43 @@ uint32_t round_pow2(uint32_t n)
     return (val - n) > (n - x) ? x : val;
 }
 
+float inv_max_of(int format)
+{
+    return format == VRHIP_UCHAR ? 1.0f / 255.0f : format == VRHIP_USHORT ? 1.0f / 65535.0f : 1.0f;
+}
+
 VolView make_vol_view(const vrhip_renderer *r, const void *data)
 {
     VolView v;
     v.data = data;
     v.w = (int)r->res[0]; v.h = (int)r->res[1]; v.d = (int)r->res[2];
     v.fw = (float)v.w; v.fh = (float)v.h; v.fd = (float)v.d;
-    v.inv_max = r->format == VRHIP_UCHAR ? 1.0f / 255.0f
-                : r->format == VRHIP_USHORT ? 1.0f / 65535.0f : 1.0f;
-    v.row = (unsigned long long)v.w;
-    v.slice = (unsigned long long)v.w * (unsigned long long)v.h;
+    v.inv_max = inv_max_of(r->format);
+    v.row = r->row_pitch;
+    v.slice = r->slice_pitch;
     v.mbx = (v.w + 3) / 4;
     v.mby = (v.h + 3) / 4;
     return v;
+}
+
+BrickView make_brick_view(const vrhip_renderer *r, const void *data)
+{
+    BrickView b;
+    b.data = data;
+    b.bw = (int)r->brick_tex[0];
+    b.bh = (int)r->brick_tex[1];
+    b.bd = (int)r->brick_tex[2];
+    return b;
+}
+
+TfView make_tf_view(const vrhip_renderer *r)
+{
+    TfView t;
+    t.tff = r->tff;
+    t.tff_n = r->tff_n;
+    t.prefix = r->prefix;
+    t.prefix_n = r->prefix_n;
+    return t;
 }
 
 int set_device(const vrhip_renderer *r)
@@ -171,11 +243,13 @@ int prepare_slot(vrhip_renderer *r, const uint32_t res[3], int format, uint32_t 
         if (rc) return rc;
         std::memcpy(r->res, res, sizeof r->res);
         r->format = format;
+        set_pitches(r);
     }
     if (r->vols.size() <= timestep) r->vols.resize(timestep + 1);
     VolumeSlot &s = r->vols[timestep];
-    if (!s.dev) VR_HIP(r, hipMalloc(&s.dev, volume_bytes(r)));
+    if (!s.dev) VR_HIP(r, hipMalloc(&s.dev, volume_alloc_bytes(r)));
     r->bricks_valid = false;
+    r->skip_dirty = true;
     *slot = &s;
     return VRHIP_OK;
 }
@@ -183,6 +257,7 @@ int prepare_slot(vrhip_renderer *r, const uint32_t res[3], int format, uint32_t 
 int ensure_fb(vrhip_renderer *r, uint32_t w, uint32_t h)
 {
     if (r->fb && r->fb_w == w && r->fb_h == h) return VRHIP_OK;
+    VR_HIP(r, hipStreamSynchronize(r->stream));
     if (r->fb) VR_HIP(r, hipFree(r->fb));
     r->fb = nullptr;
     VR_HIP(r, hipMalloc((void **)&r->fb, (size_t)w * h * sizeof(float4)));
@@ -215,26 +290,102 @@ int check_renderable(vrhip_renderer *r, uint32_t width, uint32_t height)
     return VRHIP_OK;
 }
 
-void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, RaycastLaunch *a)
+// Recompute the ESS skip bitmap when bricks, TF, prefix sum or timestep changed.
+int ensure_skipmap(vrhip_renderer *r)
+{
+    if (!r->use_ess || !r->skip_dirty) return VRHIP_OK;
+    const size_t n = (size_t)r->brick_tex[0] * r->brick_tex[1] * r->brick_tex[2];
+    const uint32_t words = (uint32_t)(2 * ((n + 63) / 64));
+    if (words + 1 > r->skip_cap) {
+        VR_HIP(r, hipStreamSynchronize(r->stream));
+        if (r->skip_bits) VR_HIP(r, hipFree(r->skip_bits));
+        r->skip_bits = nullptr;
+        VR_HIP(r, hipMalloc((void **)&r->skip_bits, ((size_t)words + 1) * sizeof(uint32_t)));
+        r->skip_cap = words + 1;
+    }
+    r->skip_words = words;
+    VR_HIP(r, vr_launch_skipmap(make_brick_view(r, r->vols[r->timestep].bricks), r->format,
+                                inv_max_of(r->format), make_tf_view(r), r->skip_bits, words,
+                                nullptr, r->stream));
+    r->skip_dirty = false;
+    return VRHIP_OK;
+}
+
+// Build (or reuse) the centre-first queue of 8x8 wave tiles.  tile_ids == nullptr: the whole
+// frame, `out` in frame layout; else the listed tiles, `out` compact [n][tile_h][tile_w].
+int ensure_queue(vrhip_renderer *r, uint32_t W, uint32_t H, uint32_t tile_w, uint32_t tile_h,
+                 const uint32_t *tile_ids, uint32_t n_tiles)
+{
+    std::vector<uint32_t> key = {W, H, tile_w, tile_h, tile_ids ? 1u : 0u};
+    if (tile_ids) key.insert(key.end(), tile_ids, tile_ids + n_tiles);
+    if (key == r->queue_key && r->queue_dev) return VRHIP_OK;
+
+    struct Item { float d2; WaveTile wt; };
+    std::vector<Item> items;
+    const float cx = 0.5f * (float)W, cy = 0.5f * (float)H;
+    auto push = [&](uint32_t px0, uint32_t py0, uint32_t out_base) {
+        if (px0 >= W || py0 >= H) return;
+        Item it;
+        float dx = (float)px0 + 4.f - cx, dy = (float)py0 + 4.f - cy;
+        it.d2 = dx * dx + dy * dy;
+        it.wt.tx8 = (uint16_t)(px0 / 8);
+        it.wt.ty8 = (uint16_t)(py0 / 8);
+        it.wt.out_base = out_base;
+        items.push_back(it);
+    };
+    if (!tile_ids) {
+        for (uint32_t y = 0; y < H; y += 8)
+            for (uint32_t x = 0; x < W; x += 8) push(x, y, y * W + x);
+    } else {
+        const uint32_t tiles_x = (W + tile_w - 1) / tile_w;
+        for (uint32_t k = 0; k < n_tiles; ++k) {
+            const uint32_t tx = tile_ids[k] % tiles_x, ty = tile_ids[k] / tiles_x;
+            for (uint32_t y = 0; y < tile_h; y += 8)
+                for (uint32_t x = 0; x < tile_w; x += 8)
+                    push(tx * tile_w + x, ty * tile_h + y, (k * tile_h + y) * tile_w + x);
+        }
+    }
+    std::stable_sort(items.begin(), items.end(),
+                     [](const Item &a, const Item &b) { return a.d2 < b.d2; });
+    std::vector<WaveTile> q(items.size());
+    for (size_t i = 0; i < items.size(); ++i) q[i] = items[i].wt;
+
+    VR_HIP(r, hipStreamSynchronize(r->stream));
+    if (q.size() > r->queue_cap) {
+        if (r->queue_dev) VR_HIP(r, hipFree(r->queue_dev));
+        r->queue_dev = nullptr;
+        VR_HIP(r, hipMalloc((void **)&r->queue_dev, q.size() * sizeof(WaveTile)));
+        r->queue_cap = (uint32_t)q.size();
+    }
+    if (!q.empty())
+        VR_HIP(r, hipMemcpy(r->queue_dev, q.data(), q.size() * sizeof(WaveTile),
+                            hipMemcpyHostToDevice));
+    r->queue_n = (uint32_t)q.size();
+    r->queue_key.swap(key);
+    return VRHIP_OK;
+}
+
+void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t out_stride,
+                 RaycastLaunch *a)
 {
     std::memset(a, 0, sizeof *a);
     const VolumeSlot &s = r->vols[r->timestep];
     a->vol = make_vol_view(r, s.dev);
-    a->bricks.data = s.bricks;
-    a->bricks.bw = (int)r->brick_tex[0];
-    a->bricks.bh = (int)r->brick_tex[1];
-    a->bricks.bd = (int)r->brick_tex[2];
-    a->tf.tff = r->tff;
-    a->tf.tff_n = r->tff_n;
-    a->tf.prefix = r->prefix;
-    a->tf.prefix_n = r->prefix_n;
+    a->bricks = make_brick_view(r, s.bricks);
+    a->tf = make_tf_view(r);
+    a->skip.bits = r->skip_bits;
+    a->skip.n_words = r->skip_words;
+    a->skip.in_lds = ((size_t)r->skip_words + 1) * sizeof(uint32_t) <= kSkipLdsMaxBytes ? 1u : 0u;
     a->frame.W = width;
     a->frame.H = height;
     // padded NDRange of the reference (volumerendercl.cpp:513-514): a full extra group
     // when the size is already a multiple of 8; the camera is derived from it.
     a->frame.gsx = width + (8u - width % 8u);
     a->frame.gsy = height + (8u - height % 8u);
-    a->frame.blocks_x = (width + 15u) / 16u;
+    a->frame.queue = r->queue_dev;
+    a->frame.n_wave_tiles = r->queue_n;
+    a->frame.out_stride = out_stride;
+    a->frame.queue_head = r->queue_head;
     a->frame.fb = r->fb;
     a->cam = r->cam;
     a->render = r->render;
@@ -244,16 +395,82 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, RaycastLaun
     a->use_ess = r->use_ess ? 1 : 0;
     a->instr = r->stats_enabled ? 1 : 0;
     a->stats = r->stats_dev;
-    a->n_blocks = a->frame.blocks_x * ((height + 15u) / 16u);
+    a->num_cus = r->num_cus;
 }
 
 int launch_timed(vrhip_renderer *r, const RaycastLaunch &a)
 {
     if (a.instr) VR_HIP(r, hipMemsetAsync(r->stats_dev, 0, sizeof(DevStats), r->stream));
+    VR_HIP(r, hipMemsetAsync(r->queue_head, 0, sizeof(uint32_t), r->stream));
     VR_HIP(r, hipEventRecord(r->ev0, r->stream));
     VR_HIP(r, vr_launch_raycast(a, r->stream));
     VR_HIP(r, hipEventRecord(r->ev1, r->stream));
     r->timed = true;
+    return VRHIP_OK;
+}
+
+int prepare_render(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t tile_w,
+                   uint32_t tile_h, const uint32_t *tile_ids, uint32_t n_tiles)
+{
+    int rc = check_renderable(r, width, height);
+    if (rc) return rc;
+    if (tile_ids) {
+        VR_REQUIRE(r, tile_w && tile_h && tile_w % 16 == 0 && tile_h % 16 == 0, VRHIP_ERR_INVALID,
+                   "Tile size must be a positive multiple of 16.");
+        const uint32_t nt = ((width + tile_w - 1) / tile_w) * ((height + tile_h - 1) / tile_h);
+        for (uint32_t i = 0; i < n_tiles; ++i)
+            VR_REQUIRE(r, tile_ids[i] < nt, VRHIP_ERR_INVALID, "Tile id out of range.");
+    }
+    rc = ensure_fb(r, width, height);
+    if (rc) return rc;
+    rc = ensure_skipmap(r);
+    if (rc) return rc;
+    return ensure_queue(r, width, height, tile_w, tile_h, tile_ids, n_tiles);
+}
+
+int count_touched_impl(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t tile_w,
+                       uint32_t tile_h, const uint32_t *tile_ids, uint32_t n_tiles,
+                       uint64_t *microbricks_touched, uint8_t *bitmap_host, size_t bitmap_bytes)
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    if (set_device(r)) return VRHIP_ERR_HIP;
+    int rc = prepare_render(r, width, height, tile_w, tile_h, tile_ids, n_tiles);
+    if (rc) return rc;
+    const size_t mb = (size_t)((r->res[0] + 3) / 4) * ((r->res[1] + 3) / 4) * ((r->res[2] + 3) / 4);
+    const size_t words = (mb + 31) / 32;
+    VR_REQUIRE(r, !bitmap_host || bitmap_bytes == (mb + 7) / 8, VRHIP_ERR_INVALID,
+               "vrhip_count_touched: bitmap size mismatch");
+    uint32_t *bits = nullptr;
+    VR_HIP(r, hipMalloc((void **)&bits, words * sizeof(uint32_t)));
+    hipError_t e = hipMemsetAsync(bits, 0, words * sizeof(uint32_t), r->stream);
+    RaycastLaunch a;
+    fill_launch(r, width, height, tile_ids ? tile_w : width, &a);
+    a.instr = 2;
+    a.touched = bits;
+    // the instrumented pass must not disturb the accumulate buffer: render into a scratch
+    float4 *scratch = nullptr;
+    if (e == hipSuccess) e = hipMalloc((void **)&scratch, (size_t)width * height * sizeof(float4));
+    if (e == hipSuccess && r->render.iteration != 0)
+        e = hipMemcpyAsync(scratch, r->fb, (size_t)width * height * sizeof(float4),
+                           hipMemcpyDeviceToDevice, r->stream);
+    a.frame.fb = scratch;
+    if (e == hipSuccess) e = hipMemsetAsync(r->stats_dev, 0, sizeof(DevStats), r->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(r->queue_head, 0, sizeof(uint32_t), r->stream);
+    if (e == hipSuccess) e = vr_launch_raycast(a, r->stream);
+    std::vector<uint32_t> host(words);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(host.data(), bits, words * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                           r->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
+    (void)hipFree(bits);
+    if (scratch) (void)hipFree(scratch);
+    if (e != hipSuccess)
+        return fail(r, VRHIP_ERR_HIP,
+                    std::string("ERROR: vrhip_count_touched (") + hipGetErrorString(e) + ")");
+    uint64_t cnt = 0;
+    for (size_t i = 0; i < words; ++i) cnt += (uint64_t)__builtin_popcount(host[i]);
+    if (microbricks_touched) *microbricks_touched = cnt;
+    if (bitmap_host) std::memcpy(bitmap_host, host.data(), bitmap_bytes);
     return VRHIP_OK;
 }
 
@@ -283,12 +500,14 @@ int vrhip_create(int device_id, vrhip_renderer **out)
         (e = hipEventCreate(&r->ev0)) != hipSuccess || (e = hipEventCreate(&r->ev1)) != hipSuccess ||
         (e = hipEventCreate(&r->evb0)) != hipSuccess ||
         (e = hipEventCreate(&r->evb1)) != hipSuccess ||
-        (e = hipMalloc((void **)&r->stats_dev, sizeof(DevStats))) != hipSuccess) {
+        (e = hipMalloc((void **)&r->stats_dev, sizeof(DevStats))) != hipSuccess ||
+        (e = hipMalloc((void **)&r->queue_head, sizeof(uint32_t))) != hipSuccess) {
         std::string msg = std::string("ERROR: vrhip_create (") + hipGetErrorString(e) + ")";
         delete r;
         return fail(nullptr, VRHIP_ERR_HIP, msg);
     }
     r->stream = r->own_stream;
+    r->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     r->devname = std::string(prop.name) + " (" + prop.gcnArchName + ")";
     *out = r;
     return VRHIP_OK;
@@ -304,7 +523,9 @@ void vrhip_destroy(vrhip_renderer *r)
     if (r->prefix) (void)hipFree(r->prefix);
     if (r->fb) (void)hipFree(r->fb);
     if (r->stats_dev) (void)hipFree(r->stats_dev);
-    if (r->tile_ids_dev) (void)hipFree(r->tile_ids_dev);
+    if (r->queue_dev) (void)hipFree(r->queue_dev);
+    if (r->queue_head) (void)hipFree(r->queue_head);
+    if (r->skip_bits) (void)hipFree(r->skip_bits);
     if (r->ev0) (void)hipEventDestroy(r->ev0);
     if (r->ev1) (void)hipEventDestroy(r->ev1);
     if (r->evb0) (void)hipEventDestroy(r->evb0);
@@ -325,12 +546,12 @@ int vrhip_device_name(const vrhip_renderer *r, char *buf, size_t buf_len)
     return VRHIP_OK;
 }
 
-int vrhip_set_stream(vrhip_renderer *r, void *hip_stream)
+int vrhip_set_stream(vrhip_renderer *r, void *hip_stream, int use_own)
 {
     if (!r) return VRHIP_ERR_INVALID;
     if (set_device(r)) return VRHIP_ERR_HIP;
     VR_HIP(r, hipStreamSynchronize(r->stream));
-    r->stream = hip_stream ? (hipStream_t)hip_stream : r->own_stream;
+    r->stream = use_own ? r->own_stream : (hipStream_t)hip_stream;
     return VRHIP_OK;
 }
 
@@ -343,8 +564,8 @@ int vrhip_upload_volume(vrhip_renderer *r, const void *host_voxels, const uint32
     VolumeSlot *s;
     int rc = prepare_slot(r, res, format, timestep, &s);
     if (rc) return rc;
-    VR_HIP(r, hipMemcpyAsync(s->dev, host_voxels, volume_bytes(r), hipMemcpyHostToDevice,
-                             r->stream));
+    VR_HIP(r, copy_volume(r, s->dev, const_cast<void *>(host_voxels), true, hipMemcpyHostToDevice,
+                          r->stream));
     VR_HIP(r, hipStreamSynchronize(r->stream));
     return VRHIP_OK;
 }
@@ -358,8 +579,8 @@ int vrhip_upload_volume_device(vrhip_renderer *r, const void *dev_voxels, const 
     VolumeSlot *s;
     int rc = prepare_slot(r, res, format, timestep, &s);
     if (rc) return rc;
-    VR_HIP(r, hipMemcpyAsync(s->dev, dev_voxels, volume_bytes(r), hipMemcpyDeviceToDevice,
-                             r->stream));
+    VR_HIP(r, copy_volume(r, s->dev, const_cast<void *>(dev_voxels), true,
+                          hipMemcpyDeviceToDevice, r->stream));
     VR_HIP(r, hipStreamSynchronize(r->stream));
     return VRHIP_OK;
 }
@@ -373,7 +594,7 @@ int vrhip_synth_volume(vrhip_renderer *r, int kind, const uint32_t res[3], int f
     VolumeSlot *s;
     int rc = prepare_slot(r, res, format, timestep, &s);
     if (rc) return rc;
-    VR_HIP(r, vr_launch_synth(kind, s->dev, res, format, r->stream));
+    VR_HIP(r, vr_launch_synth(kind, s->dev, res, r->row_pitch, r->slice_pitch, format, r->stream));
     VR_HIP(r, hipStreamSynchronize(r->stream));
     return VRHIP_OK;
 }
@@ -386,8 +607,8 @@ int vrhip_download_volume(vrhip_renderer *r, uint32_t timestep, void *host_dst, 
     VR_REQUIRE(r, host_dst && bytes == volume_bytes(r), VRHIP_ERR_INVALID,
                "vrhip_download_volume: size mismatch");
     if (set_device(r)) return VRHIP_ERR_HIP;
-    VR_HIP(r, hipMemcpyAsync(host_dst, r->vols[timestep].dev, bytes, hipMemcpyDeviceToHost,
-                             r->stream));
+    VR_HIP(r, copy_volume(r, r->vols[timestep].dev, host_dst, false, hipMemcpyDeviceToHost,
+                          r->stream));
     VR_HIP(r, hipStreamSynchronize(r->stream));
     return VRHIP_OK;
 }
@@ -403,6 +624,7 @@ int vrhip_clear_volumes(vrhip_renderer *r)
     }
     r->vols.clear();
     r->bricks_valid = false;
+    r->skip_dirty = true;
     r->format = -1;
     r->res[0] = r->res[1] = r->res[2] = 0;
     r->timestep = 0;
@@ -414,6 +636,7 @@ int vrhip_set_timestep(vrhip_renderer *r, uint32_t timestep)
     if (!r) return VRHIP_ERR_INVALID;
     // volumerendercl.cpp:1169-1170: silently ignored when out of range
     if (!r->vols.empty() && timestep >= r->vols.size()) return VRHIP_OK;
+    if (r->timestep != timestep) r->skip_dirty = true;
     r->timestep = timestep;
     return VRHIP_OK;
 }
@@ -443,17 +666,16 @@ int vrhip_set_transfer_function(vrhip_renderer *r, const uint8_t *rgba8, uint32_
         table[i].z = (float)rgba8[4 * i + 2] / 255.0f;
         table[i].w = (float)rgba8[4 * i + 3] / 255.0f;
     }
+    VR_HIP(r, hipStreamSynchronize(r->stream));
     if (r->tff_n != n_entries) {
-        VR_HIP(r, hipStreamSynchronize(r->stream));
         if (r->tff) VR_HIP(r, hipFree(r->tff));
         r->tff = nullptr;
         r->tff_n = 0;
         VR_HIP(r, hipMalloc((void **)&r->tff, n_entries * sizeof(float4)));
         r->tff_n = n_entries;
     }
-    VR_HIP(r, hipMemcpyAsync(r->tff, table.data(), n_entries * sizeof(float4),
-                             hipMemcpyHostToDevice, r->stream));
-    VR_HIP(r, hipStreamSynchronize(r->stream));
+    VR_HIP(r, hipMemcpy(r->tff, table.data(), n_entries * sizeof(float4), hipMemcpyHostToDevice));
+    r->skip_dirty = true;
     return VRHIP_OK;
 }
 
@@ -462,17 +684,16 @@ int vrhip_set_tff_prefix_sum(vrhip_renderer *r, const uint32_t *prefix, uint32_t
     if (!r) return VRHIP_ERR_INVALID;
     VR_REQUIRE(r, prefix && n > 0, VRHIP_ERR_INVALID, "Empty prefix sum.");
     if (set_device(r)) return VRHIP_ERR_HIP;
+    VR_HIP(r, hipStreamSynchronize(r->stream));
     if (r->prefix_n != n) {
-        VR_HIP(r, hipStreamSynchronize(r->stream));
         if (r->prefix) VR_HIP(r, hipFree(r->prefix));
         r->prefix = nullptr;
         r->prefix_n = 0;
         VR_HIP(r, hipMalloc((void **)&r->prefix, n * sizeof(uint32_t)));
         r->prefix_n = n;
     }
-    VR_HIP(r, hipMemcpyAsync(r->prefix, prefix, n * sizeof(uint32_t), hipMemcpyHostToDevice,
-                             r->stream));
-    VR_HIP(r, hipStreamSynchronize(r->stream));
+    VR_HIP(r, hipMemcpy(r->prefix, prefix, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    r->skip_dirty = true;
     return VRHIP_OK;
 }
 
@@ -489,13 +710,15 @@ int vrhip_build_bricks(vrhip_renderer *r)
         r->brick_tex[i] = (uint32_t)std::ceil((double)r->brick_res[i]);
         r->raycast.brickRes[i] = r->brick_res[i];   // :630-631
     }
-    VR_HIP(r, hipEventRecord(r->evb0, r->stream));
     for (VolumeSlot &s : r->vols) {
         if (!s.dev) return fail(r, VRHIP_ERR_NODATA,
                                 "Error loading timeseries data: size mismatch.");   // :227
         if (s.bricks) VR_HIP(r, hipFree(s.bricks));
         s.bricks = nullptr;
         VR_HIP(r, hipMalloc(&s.bricks, bricks_bytes(r)));
+    }
+    VR_HIP(r, hipEventRecord(r->evb0, r->stream));
+    for (VolumeSlot &s : r->vols) {
         VolView v = make_vol_view(r, s.dev);
         VR_HIP(r, vr_launch_build_bricks(v, r->format, r->brick_tex, s.bricks, r->stream));
     }
@@ -503,6 +726,7 @@ int vrhip_build_bricks(vrhip_renderer *r)
     VR_HIP(r, hipStreamSynchronize(r->stream));   // reference: _queueCL.finish() (:670)
     r->bricks_valid = true;
     r->bricks_timed = true;
+    r->skip_dirty = true;
     return VRHIP_OK;
 }
 
@@ -582,12 +806,10 @@ int vrhip_render_frame(vrhip_renderer *r, uint32_t width, uint32_t height, float
 {
     if (!r) return VRHIP_ERR_INVALID;
     if (set_device(r)) return VRHIP_ERR_HIP;
-    int rc = check_renderable(r, width, height);
-    if (rc) return rc;
-    rc = ensure_fb(r, width, height);
+    int rc = prepare_render(r, width, height, 0, 0, nullptr, 0);
     if (rc) return rc;
     RaycastLaunch a;
-    fill_launch(r, width, height, &a);
+    fill_launch(r, width, height, width, &a);
     if (out_rgba && out_is_device) a.frame.out = (float4 *)out_rgba;
     rc = launch_timed(r, a);
     if (rc) return rc;
@@ -605,41 +827,14 @@ int vrhip_render_tiles(vrhip_renderer *r, uint32_t width, uint32_t height, uint3
 {
     if (!r) return VRHIP_ERR_INVALID;
     if (set_device(r)) return VRHIP_ERR_HIP;
-    int rc = check_renderable(r, width, height);
-    if (rc) return rc;
-    VR_REQUIRE(r, tile_w && tile_h && tile_w % 16 == 0 && tile_h % 16 == 0, VRHIP_ERR_INVALID,
-               "Tile size must be a positive multiple of 16.");
     VR_REQUIRE(r, out_tiles_dev, VRHIP_ERR_INVALID, "vrhip_render_tiles: NULL output");
     if (n_tiles == 0) return VRHIP_OK;
     VR_REQUIRE(r, tile_ids, VRHIP_ERR_INVALID, "vrhip_render_tiles: NULL tile list");
-    const uint32_t tiles_x = (width + tile_w - 1) / tile_w, tiles_y = (height + tile_h - 1) / tile_h;
-    for (uint32_t i = 0; i < n_tiles; ++i)
-        VR_REQUIRE(r, tile_ids[i] < tiles_x * tiles_y, VRHIP_ERR_INVALID, "Tile id out of range.");
-    rc = ensure_fb(r, width, height);
+    int rc = prepare_render(r, width, height, tile_w, tile_h, tile_ids, n_tiles);
     if (rc) return rc;
-    // upload the tile list unless it is the one already resident
-    if (r->tile_ids_host.size() != n_tiles ||
-        std::memcmp(r->tile_ids_host.data(), tile_ids, n_tiles * sizeof(uint32_t)) != 0) {
-        VR_HIP(r, hipStreamSynchronize(r->stream));
-        if (r->tile_ids_host.size() < n_tiles || !r->tile_ids_dev) {
-            if (r->tile_ids_dev) VR_HIP(r, hipFree(r->tile_ids_dev));
-            r->tile_ids_dev = nullptr;
-            VR_HIP(r, hipMalloc((void **)&r->tile_ids_dev, n_tiles * sizeof(uint32_t)));
-        }
-        r->tile_ids_host.assign(tile_ids, tile_ids + n_tiles);
-        VR_HIP(r, hipMemcpyAsync(r->tile_ids_dev, r->tile_ids_host.data(),
-                                 n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice, r->stream));
-    }
     RaycastLaunch a;
-    fill_launch(r, width, height, &a);
-    a.frame.tile_ids = r->tile_ids_dev;
-    a.frame.tile_w = tile_w;
-    a.frame.tile_h = tile_h;
-    a.frame.tiles_x = tiles_x;
-    a.frame.bpt_x = tile_w / 16;
-    a.frame.bpt = (tile_w / 16) * (tile_h / 16);
+    fill_launch(r, width, height, tile_w, &a);
     a.frame.out = (float4 *)out_tiles_dev;
-    a.n_blocks = n_tiles * a.frame.bpt;
     return launch_timed(r, a);
 }
 
@@ -675,74 +870,6 @@ int vrhip_get_stats(const vrhip_renderer *r, vrhip_stats *out)
     return VRHIP_OK;
 }
 
-static int count_touched_impl(vrhip_renderer *r, uint32_t width, uint32_t height,
-                              uint32_t tile_w, uint32_t tile_h, const uint32_t *tile_ids,
-                              uint32_t n_tiles, uint64_t *microbricks_touched,
-                              uint8_t *bitmap_host, size_t bitmap_bytes)
-{
-    if (!r) return VRHIP_ERR_INVALID;
-    if (set_device(r)) return VRHIP_ERR_HIP;
-    int rc = check_renderable(r, width, height);
-    if (rc) return rc;
-    rc = ensure_fb(r, width, height);
-    if (rc) return rc;
-    uint32_t *ids_dev = nullptr;
-    if (tile_ids) {
-        VR_REQUIRE(r, n_tiles && tile_w && tile_h && tile_w % 16 == 0 && tile_h % 16 == 0,
-                   VRHIP_ERR_INVALID, "Tile size must be a positive multiple of 16.");
-        const uint32_t nt = ((width + tile_w - 1) / tile_w) * ((height + tile_h - 1) / tile_h);
-        for (uint32_t i = 0; i < n_tiles; ++i)
-            VR_REQUIRE(r, tile_ids[i] < nt, VRHIP_ERR_INVALID, "Tile id out of range.");
-        VR_HIP(r, hipMalloc((void **)&ids_dev, n_tiles * sizeof(uint32_t)));
-        VR_HIP(r, hipMemcpy(ids_dev, tile_ids, n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice));
-    }
-    const size_t mb = (size_t)((r->res[0] + 3) / 4) * ((r->res[1] + 3) / 4) * ((r->res[2] + 3) / 4);
-    const size_t words = (mb + 31) / 32;
-    VR_REQUIRE(r, !bitmap_host || bitmap_bytes == (mb + 7) / 8, VRHIP_ERR_INVALID,
-               "vrhip_count_touched: bitmap size mismatch");
-    uint32_t *bits = nullptr;
-    VR_HIP(r, hipMalloc((void **)&bits, words * sizeof(uint32_t)));
-    hipError_t e = hipMemsetAsync(bits, 0, words * sizeof(uint32_t), r->stream);
-    RaycastLaunch a;
-    fill_launch(r, width, height, &a);
-    a.instr = 2;
-    a.touched = bits;
-    // the instrumented pass must not disturb the accumulate buffer: render into a scratch
-    float4 *scratch = nullptr;
-    if (e == hipSuccess) e = hipMalloc((void **)&scratch, (size_t)width * height * sizeof(float4));
-    if (e == hipSuccess && r->render.iteration != 0)
-        e = hipMemcpyAsync(scratch, r->fb, (size_t)width * height * sizeof(float4),
-                           hipMemcpyDeviceToDevice, r->stream);
-    a.frame.fb = scratch;
-    if (ids_dev) {
-        a.frame.tile_ids = ids_dev;
-        a.frame.tile_w = tile_w;
-        a.frame.tile_h = tile_h;
-        a.frame.tiles_x = (width + tile_w - 1) / tile_w;
-        a.frame.bpt_x = tile_w / 16;
-        a.frame.bpt = (tile_w / 16) * (tile_h / 16);
-        a.n_blocks = n_tiles * a.frame.bpt;
-    }
-    if (e == hipSuccess) e = hipMemsetAsync(r->stats_dev, 0, sizeof(DevStats), r->stream);
-    if (e == hipSuccess) e = vr_launch_raycast(a, r->stream);
-    std::vector<uint32_t> host(words);
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(host.data(), bits, words * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                           r->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
-    (void)hipFree(bits);
-    if (scratch) (void)hipFree(scratch);
-    if (ids_dev) (void)hipFree(ids_dev);
-    if (e != hipSuccess)
-        return fail(r, VRHIP_ERR_HIP,
-                    std::string("ERROR: vrhip_count_touched (") + hipGetErrorString(e) + ")");
-    uint64_t cnt = 0;
-    for (size_t i = 0; i < words; ++i) cnt += (uint64_t)__builtin_popcount(host[i]);
-    if (microbricks_touched) *microbricks_touched = cnt;
-    if (bitmap_host) std::memcpy(bitmap_host, host.data(), bitmap_bytes);
-    return VRHIP_OK;
-}
-
 int vrhip_count_touched(vrhip_renderer *r, uint32_t width, uint32_t height,
                         uint64_t *microbricks_touched, uint8_t *bitmap_host, size_t bitmap_bytes)
 {
@@ -754,7 +881,8 @@ int vrhip_count_touched_tiles(vrhip_renderer *r, uint32_t width, uint32_t height
                               uint32_t tile_w, uint32_t tile_h, const uint32_t *tile_ids,
                               uint32_t n_tiles, uint64_t *microbricks_touched)
 {
-    if (r && !tile_ids) return fail(r, VRHIP_ERR_INVALID, "vrhip_count_touched_tiles: NULL tile list");
+    if (r && (!tile_ids || !n_tiles))
+        return fail(r, VRHIP_ERR_INVALID, "vrhip_count_touched_tiles: empty tile list");
     return count_touched_impl(r, width, height, tile_w, tile_h, tile_ids, n_tiles,
                               microbricks_touched, nullptr, 0);
 }

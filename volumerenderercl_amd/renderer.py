@@ -105,8 +105,10 @@ class VolumeRenderCL:
         except Exception:
             pass
 
-    def set_stream(self, stream_ptr):
-        self._check(self._lib.vrhip_set_stream(self._h, C.c_void_p(stream_ptr)))
+    def set_stream(self, stream_ptr, use_own=False):
+        """Launch on the given hipStream_t handle (0 = legacy default stream)."""
+        self._check(self._lib.vrhip_set_stream(self._h, C.c_void_p(stream_ptr),
+                                               1 if use_own else 0))
 
     def getCurrentDeviceName(self):
         buf = C.create_string_buffer(256)
