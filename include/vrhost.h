@@ -1,0 +1,43 @@
+/*
+ * vrhost.h -- C access to the host-side volume loader (libvrhost.so), the counterpart of the
+ * reference's DatRawReader (/root/reference/src/io/datrawreader.h:38-184).  Pure host code:
+ * no GPU needed.
+ */
+#ifndef VRHOST_H
+#define VRHOST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vrdr vrdr;
+
+typedef struct vrdr_info_t {
+    uint32_t res[4];            /* x, y, z, time steps (Properties::volume_res)       */
+    double thickness[3];        /* Properties::slice_thickness                        */
+    int32_t format;             /* DatRawReader::data_format: 0 UCHAR 1 USHORT 2 FLOAT 3 DOUBLE */
+    int32_t endianness;         /* 0 LITTLE, 1 BIG                                    */
+    float min_value, max_value; /* Properties::min_value / max_value                  */
+    uint64_t n_timesteps;
+    uint64_t bytes_per_timestep;
+    char channel_order[16];
+} vrdr_info_t;
+
+/* DatRawReader::read_files with dat_file_name = dat_file (raw_file: optional explicit .raw
+ * name, i.e. Properties::raw_file_names = {raw_file}).  Returns 0, 1 (std::invalid_argument)
+ * or 2 (std::runtime_error); vrdr_error() gives the exception text. */
+int vrdr_load(const char *dat_file, const char *raw_file, vrdr **out);
+const char *vrdr_error(void);
+void vrdr_free(vrdr *h);
+int vrdr_info(vrdr *h, vrdr_info_t *info);
+/* DatRawReader::data()[t] -- normalised voxels as they go to the GPU */
+const void *vrdr_data(vrdr *h, uint64_t t);
+/* DatRawReader::getHistogram(t) */
+int vrdr_histogram(vrdr *h, uint64_t t, double out[256]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,194 @@
+// vrhip_render -- headless host: loads a .dat/.raw volume (or a synthetic field), sets camera
+// and transfer function the way the reference's Qt widget does
+// (/root/reference/src/qt/volumerenderwidget.cpp:916-938 TF table, :1079-1098 view matrix),
+// renders through VolumeRenderCL and writes the float RGBA framebuffer to disk.  Replaces the
+// Qt/OpenGL front end dropped by the north star.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "volumerendercl.h"
+
+namespace {
+
+struct Stop { double pos; int c[4]; };
+
+// updateTransferFunction (volumerenderwidget.cpp:916-938), linear easing: 1024 entries sampled
+// at time qRound(i/1024*8192) of 8192; QColor channels interpolate as int(f + (t-f)*p); c - 3.
+std::vector<unsigned char> tff_from_stops(std::vector<Stop> stops, int n = 1024)
+{
+    std::sort(stops.begin(), stops.end(), [](const Stop &a, const Stop &b) { return a.pos < b.pos; });
+    if (stops.front().pos > 0.0) { Stop s = stops.front(); s.pos = 0.0; stops.insert(stops.begin(), s); }
+    if (stops.back().pos < 1.0) { Stop s = stops.back(); s.pos = 1.0; stops.push_back(s); }
+    std::vector<unsigned char> out(size_t(n) * 4, 0);
+    for (int i = 0; i < n; ++i) {
+        const double time = std::floor(double(i) / n * 8192.0 + 0.5);
+        const double p = time / 8192.0;
+        size_t k = 0;
+        while (k + 2 < stops.size() && p >= stops[k + 1].pos) ++k;
+        const Stop &a = stops[k], &b = stops[k + 1];
+        const double lp = b.pos == a.pos ? 0.0 : (p - a.pos) / (b.pos - a.pos);
+        for (int c = 0; c < 4; ++c) {
+            int v = int(a.c[c] + (b.c[c] - a.c[c]) * lp);
+            v = std::min(255, std::max(0, v));
+            out[size_t(i) * 4 + c] = static_cast<unsigned char>(std::max(0, v - 3));
+        }
+    }
+    return out;
+}
+
+// raw TF text file: 4096 whitespace-separated integers (mainwindow.cpp:680-719)
+std::vector<unsigned char> tff_from_raw_file(const std::string &path)
+{
+    std::ifstream in(path);
+    if (!in) throw std::runtime_error("Could not open transfer function file " + path);
+    std::vector<unsigned char> out;
+    double v;
+    while (in >> v) out.push_back(static_cast<unsigned char>(std::min(255.0, std::max(0.0, v))));
+    if (out.empty() || out.size() % 4) throw std::runtime_error("Invalid transfer function file " + path);
+    return out;
+}
+
+// updateViewMatrix (volumerenderwidget.cpp:1079-1098): M = R(q) T(t) S(t.z), row-major
+std::array<float, 16> view_matrix(const double q[4], const double t[3])
+{
+    double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    double w = q[0] / n, x = q[1] / n, y = q[2] / n, z = q[3] / n;
+    double R[3][3] = {{1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)},
+                      {2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)},
+                      {2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)}};
+    std::array<float, 16> m{};
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) m[r * 4 + c] = float(R[r][c] * t[2]);
+        m[r * 4 + 3] = float(R[r][0] * t[0] + R[r][1] * t[1] + R[r][2] * t[2]);
+    }
+    m[15] = 1.f;
+    return m;
+}
+
+void write_ppm(const std::string &path, const std::vector<float> &rgba, size_t w, size_t h)
+{
+    std::ofstream f(path, std::ios::binary);
+    f << "P6\n" << w << " " << h << "\n255\n";
+    std::vector<unsigned char> row(w * 3);
+    for (size_t y = 0; y < h; ++y) {
+        for (size_t x = 0; x < w; ++x)
+            for (int c = 0; c < 3; ++c) {
+                float v = rgba[(y * w + x) * 4 + c];
+                row[x * 3 + c] = static_cast<unsigned char>(std::lround(std::min(1.f, std::max(0.f, v)) * 255.f));
+            }
+        f.write(reinterpret_cast<const char *>(row.data()), std::streamsize(row.size()));
+    }
+}
+
+[[noreturn]] void usage()
+{
+    std::cerr <<
+        "usage: vrhip_render (--dat FILE.dat | --synth sphere|shells N UCHAR|USHORT|FLOAT)\n"
+        "         [--size W H] [--rotate AX AY AZ DEG] [--translate X Y Z] [--view M0..M15]\n"
+        "         [--tf default|FILE] [--illum N] [--no-ess] [--ortho] [--nearest] [--rate R]\n"
+        "         [--bg R G B] [--gradient-bg] [--seed S] [--frames N] [--device D] --out PREFIX\n"
+        "writes PREFIX.rgba.f32 (W*H*4 float32, row 0 = top), PREFIX.ppm and prints one JSON line\n";
+    std::exit(2);
+}
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+    std::string dat, synth_kind, synth_fmt = "UCHAR", tf = "default", out;
+    unsigned synth_n = 0;
+    size_t W = 1024, H = 1024;
+    double q[4] = {1, 0, 0, 0}, tr[3] = {0, 0, 2};
+    bool have_view = false, ess = true, ortho = false, linear = true, gradient_bg = false, pin = false;
+    std::array<float, 16> view{};
+    unsigned illum = 1, seed = 0;
+    int frames = 1, device = 0;
+    double rate = 1.5;
+    std::array<float, 4> bg = {{1, 1, 1, 1}};
+
+    auto need = [&](int i, int n) { if (i + n >= argc) usage(); };
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        if (a == "--dat") { need(i, 1); dat = argv[++i]; }
+        else if (a == "--synth") { need(i, 3); synth_kind = argv[++i]; synth_n = unsigned(std::atoi(argv[++i])); synth_fmt = argv[++i]; }
+        else if (a == "--size") { need(i, 2); W = size_t(std::atol(argv[++i])); H = size_t(std::atol(argv[++i])); }
+        else if (a == "--rotate") {
+            need(i, 4);
+            double ax = std::atof(argv[++i]), ay = std::atof(argv[++i]), az = std::atof(argv[++i]);
+            double half = std::atof(argv[++i]) * M_PI / 360.0, l = std::sqrt(ax * ax + ay * ay + az * az);
+            q[0] = std::cos(half); q[1] = ax / l * std::sin(half); q[2] = ay / l * std::sin(half); q[3] = az / l * std::sin(half);
+        }
+        else if (a == "--translate") { need(i, 3); for (int k = 0; k < 3; ++k) tr[k] = std::atof(argv[++i]); }
+        else if (a == "--view") { need(i, 16); for (int k = 0; k < 16; ++k) view[size_t(k)] = float(std::atof(argv[++i])); have_view = true; }
+        else if (a == "--tf") { need(i, 1); tf = argv[++i]; }
+        else if (a == "--illum") { need(i, 1); illum = unsigned(std::atoi(argv[++i])); }
+        else if (a == "--no-ess") ess = false;
+        else if (a == "--ortho") ortho = true;
+        else if (a == "--nearest") linear = false;
+        else if (a == "--gradient-bg") gradient_bg = true;
+        else if (a == "--rate") { need(i, 1); rate = std::atof(argv[++i]); }
+        else if (a == "--bg") { need(i, 3); for (int k = 0; k < 3; ++k) bg[size_t(k)] = float(std::atof(argv[++i])); }
+        else if (a == "--seed") { need(i, 1); seed = unsigned(std::strtoul(argv[++i], nullptr, 10)); pin = true; }
+        else if (a == "--frames") { need(i, 1); frames = std::atoi(argv[++i]); }
+        else if (a == "--device") { need(i, 1); device = std::atoi(argv[++i]); }
+        else if (a == "--out") { need(i, 1); out = argv[++i]; }
+        else usage();
+    }
+    if ((dat.empty() && synth_kind.empty()) || out.empty()) usage();
+
+    try {
+        VolumeRenderCL vr;
+        vr.initialize(false, false, VENDOR_ANY, std::to_string(device));
+        if (!dat.empty()) {
+            DatRawReader::Properties p;
+            p.dat_file_name = dat;
+            vr.loadVolumeData(p);
+        } else {
+            DatRawReader::data_format f = synth_fmt == "USHORT" ? DatRawReader::USHORT
+                                          : synth_fmt == "FLOAT" ? DatRawReader::FLOAT : DatRawReader::UCHAR;
+            vr.loadSyntheticVolume(synth_kind, synth_n, f);
+        }
+        std::vector<unsigned char> table =
+            tf == "default" ? tff_from_stops({{0.0, {0, 0, 0, 0}}, {0.1, {125, 125, 125, 0}}, {1.0, {0, 0, 0, 255}}})
+                            : tff_from_raw_file(tf);
+        vr.setTransferFunction(table);
+        vr.setIllumination(illum);
+        vr.setObjEss(ess);
+        vr.setCamOrtho(ortho);
+        vr.setLinearInterpolation(linear);
+        vr.setUseGradient(gradient_bg);
+        vr.setBackground(bg);
+        vr.updateSamplingRate(rate);
+        if (pin) vr.setSeed(seed);
+        vr.updateOutputImg(W, H, 0);
+        vr.updateView(have_view ? view : view_matrix(q, tr));
+
+        std::vector<float> frame;
+        double kernel_s = 0.0;
+        for (int f = 0; f < frames; ++f) {
+            vr.runRaycastNoGL(W, H, frame);   // frames accumulate (running mean), like the reference
+            kernel_s += vr.getLastExecTime();
+        }
+        std::ofstream raw(out + ".rgba.f32", std::ios::binary);
+        raw.write(reinterpret_cast<const char *>(frame.data()), std::streamsize(frame.size() * sizeof(float)));
+        write_ppm(out + ".ppm", frame, W, H);
+        auto res = vr.getResolution();
+        std::printf("{\"device\": \"%s\", \"volume\": [%u, %u, %u], \"width\": %zu, \"height\": %zu, "
+                    "\"frames\": %d, \"kernel_ms_per_frame\": %.4f, \"out\": \"%s.rgba.f32\"}\n",
+                    vr.getCurrentDeviceName().c_str(), res[0], res[1], res[2], W, H, frames,
+                    kernel_s / frames * 1e3, out.c_str());
+    } catch (const std::exception &e) {
+        std::cerr << e.what() << std::endl;
+        return 1;
+    }
+    return 0;
+}

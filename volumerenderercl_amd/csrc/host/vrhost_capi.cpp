@@ -1,0 +1,76 @@
+// vrhost_capi.cpp -- plain-C access to the host-side DatRawReader (libvrhost.so), used by the
+// Python package (volumerenderercl_amd/datraw.py) and its tests.  Declared in include/vrhost.h.
+#include "vrhost.h"
+
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "datrawreader.h"
+
+struct vrdr {
+    DatRawReader reader;
+};
+
+static thread_local std::string g_error;
+
+extern "C" {
+
+int vrdr_load(const char *dat_file, const char *raw_file, vrdr **out)
+{
+    if (!out) return 1;
+    *out = nullptr;
+    vrdr *h = new vrdr();
+    try {
+        DatRawReader::Properties p;
+        if (dat_file) p.dat_file_name = dat_file;
+        if (raw_file && *raw_file) p.raw_file_names.push_back(raw_file);
+        h->reader.read_files(p);
+    } catch (const std::invalid_argument &e) {
+        g_error = e.what();
+        delete h;
+        return 1;   // std::invalid_argument
+    } catch (const std::exception &e) {
+        g_error = e.what();
+        delete h;
+        return 2;   // std::runtime_error
+    }
+    *out = h;
+    return 0;
+}
+
+const char *vrdr_error(void) { return g_error.c_str(); }
+
+void vrdr_free(vrdr *h) { delete h; }
+
+int vrdr_info(vrdr *h, vrdr_info_t *info)
+{
+    if (!h || !info || !h->reader.has_data()) return 1;
+    const DatRawReader::Properties &p = h->reader.properties();
+    for (int i = 0; i < 4; ++i) info->res[i] = p.volume_res[i];
+    for (int i = 0; i < 3; ++i) info->thickness[i] = p.slice_thickness[i];
+    info->format = int(p.format);
+    info->endianness = int(p.endianness);
+    info->min_value = p.min_value;
+    info->max_value = p.max_value;
+    info->n_timesteps = h->reader.data().size();
+    info->bytes_per_timestep = h->reader.data().front().size();
+    std::memset(info->channel_order, 0, sizeof info->channel_order);
+    std::strncpy(info->channel_order, p.image_channel_order.c_str(), sizeof info->channel_order - 1);
+    return 0;
+}
+
+const void *vrdr_data(vrdr *h, uint64_t t)
+{
+    if (!h || !h->reader.has_data() || t >= h->reader.data().size()) return nullptr;
+    return h->reader.data()[t].data();
+}
+
+int vrdr_histogram(vrdr *h, uint64_t t, double out[256])
+{
+    if (!h || !h->reader.has_data() || t >= h->reader.data().size()) return 1;
+    const std::array<double, 256> &hist = h->reader.getHistogram(t);
+    std::memcpy(out, hist.data(), sizeof(double) * 256);
+    return 0;
+}
+}
