@@ -56,6 +56,8 @@ def main():
         acc += out[i]
         print("  %-34s %6.2f %%" % (PHASES[i], 100.0 * out[i] / total))
     print("  %-34s %6.2f %%" % ("(unattributed)", 100.0 * (total - acc) / total))
+    print("  DDA loop iterations/frame %.0f -> cycles per DDA iteration %.0f" % (
+        out[9] / frames, out[2] / max(out[9], 1)))
     rounds, tiles = out[10] / frames, out[11] / frames
     print("  rounds/frame %.0f  tiles/frame %.0f  cycles/round %.0f  cycles/tile %.0f" % (
         rounds, tiles, total / frames / max(rounds, 1), total / frames / max(tiles, 1)))

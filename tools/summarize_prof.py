@@ -24,7 +24,7 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recurs
             short(row.get("Name", "")), row.get("Calls"), row.get("TotalDurationNs"),
             row.get("AverageNs"), row.get("Percentage")))
 
-for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
+for d in sorted(glob.glob(os.path.join(out, "p*"))):
     if not os.path.isdir(d):
         continue
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):

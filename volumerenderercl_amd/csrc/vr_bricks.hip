@@ -1,13 +1,17 @@
-// vr_bricks.hip -- min/max brick grid for object-order empty-space skipping, and the
-// on-GPU synthetic volume generator.
+// vr_bricks.hip -- everything that streams the whole volume: the min/max brick grid for
+// object-order empty-space skipping, the dense <-> micro-brick re-tiling used by upload /
+// download, and the on-GPU synthetic volume generator.
 //
 // vr_build_bricks replaces the reference's `generateBricks` kernel
 // (/root/reference/src/kernel/volumeraycast.cl:932-961): per brick, min and max of the
 // voxel values over [lo, min(lo + vpc, res - 1)) on each axis -- the last voxel plane is
 // never included.  The reference launches one work-item per brick,
 // each walking its voxels with strided reads; here the volume is streamed once, fully
-// coalesced: one workgroup per (brick-row y, brick-row z) pair sweeps whole x-rows with
-// 16-byte loads, accumulates in registers and merges per brick through LDS atomics.
+// coalesced: one workgroup per (brick-row y, brick-row z) pair sweeps the micro-bricks of
+// its x-row (64 contiguous voxels per lane and load group), accumulates in registers and
+// merges per ESS brick through LDS atomics.
+#include <algorithm>
+
 #include "vr_internal.h"
 
 namespace {
@@ -38,12 +42,10 @@ template <> struct Key<float> {
     static __device__ float top() { return 1.0f; }
 };
 
-// VEC voxels per load (16 bytes) on the fast path, 1 on the generic path.
-template <typename VT, int VEC>
-__global__ __launch_bounds__(kThreads) void vr_build_bricks_kernel(
-    const VT *__restrict__ vol, int w, int h, int d, unsigned long long row,
-    unsigned long long slice, int tex_x, int tex_y, int tex_z, int vpc_x, int vpc_y, int vpc_z,
-    VT *__restrict__ out)
+template <typename VT>
+__global__ __launch_bounds__(kThreads) void vr_build_bricks_kernel(VolView vol, int tex_x, int tex_y,
+                                                                   int vpc_x, int vpc_y, int vpc_z,
+                                                                   VT *__restrict__ out)
 {
     extern __shared__ uint32_t s_keys[];   // [tex_x] min keys, then [tex_x] max keys
     uint32_t *s_min = s_keys, *s_max = s_keys + tex_x;
@@ -54,43 +56,53 @@ __global__ __launch_bounds__(kThreads) void vr_build_bricks_kernel(
     }
     __syncthreads();
 
-    const int ylo = vpc_y * cy, yhi = min(ylo + vpc_y, h - 1);
+    const int w = vol.w, h = vol.h, d = vol.d;
+    const int ylo = vpc_y * cy, yhi = min(ylo + vpc_y, h - 1);   // [lo, hi): last plane excluded
     const int zlo = vpc_z * cz, zhi = min(zlo + vpc_z, d - 1);
-    for (int x0 = threadIdx.x * VEC; x0 < w; x0 += kThreads * VEC) {
-        const int cx = x0 / vpc_x;   // fast path: vpc_x % VEC == 0, so the chunk is in one brick
-        uint32_t kmin = 0xffffffffu, kmax = 0u;
-        if (VEC > 1) {
-            const int xhi = min(vpc_x * cx + vpc_x, w - 1);   // exclusive
-            for (int z = zlo; z < zhi; ++z) {
-                const VT *p = vol + (unsigned long long)z * slice + (unsigned long long)x0;
-#pragma unroll 4
-                for (int y = ylo; y < yhi; ++y) {
-                    uint4 q = *reinterpret_cast<const uint4 *>(p + (unsigned long long)y * row);
-                    VT v[VEC];
-                    __builtin_memcpy(v, &q, 16);
+    const VT *base = (const VT *)vol.data;
+    if (yhi > ylo && zhi > zlo) {
+        const int my0 = ylo >> 2, my1 = (yhi - 1) >> 2, mz0 = zlo >> 2, mz1 = (zhi - 1) >> 2;
+        constexpr int N16 = 64 * (int)sizeof(VT) / 16;   // 16-byte loads per micro-brick
+        for (int mx = threadIdx.x; mx < (int)vol.nbx; mx += kThreads) {
+            uint32_t kmin[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            uint32_t kmax[4] = {0u, 0u, 0u, 0u};
+            for (int mz = mz0; mz <= mz1; ++mz)
+                for (int my = my0; my <= my1; ++my) {
+                    const uint4 *p = reinterpret_cast<const uint4 *>(
+                        base + (unsigned long long)mz * vol.zstride +
+                        (unsigned long long)my * vol.ystride + (unsigned long long)mx * 64ull);
+                    uint4 q[N16];
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) {
-                        uint32_t k = Key<VT>::enc(v[i]);
-                        bool in = x0 + i < xhi;
-                        kmin = in ? min(kmin, k) : kmin;
-                        kmax = in ? max(kmax, k) : kmax;
+                    for (int i = 0; i < N16; ++i) q[i] = p[i];
+                    VT v[64];
+                    __builtin_memcpy(v, q, sizeof v);
+#pragma unroll
+                    for (int dz = 0; dz < 4; ++dz) {
+                        const int z = 4 * mz + dz;
+                        if (z < zlo || z >= zhi) continue;   // block-uniform
+#pragma unroll
+                        for (int dy = 0; dy < 4; ++dy) {
+                            const int y = 4 * my + dy;
+                            if (y < ylo || y >= yhi) continue;   // block-uniform
+#pragma unroll
+                            for (int dx = 0; dx < 4; ++dx) {
+                                uint32_t k = Key<VT>::enc(v[dz * 16 + dy * 4 + dx]);
+                                kmin[dx] = min(kmin[dx], k);
+                                kmax[dx] = max(kmax[dx], k);
+                            }
+                        }
                     }
                 }
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) {
+                const int x = 4 * mx + dx;
+                const int cx = x / vpc_x;
+                const int xhi = min(vpc_x * cx + vpc_x, w - 1);
+                if (x < xhi && cx < tex_x && kmin[dx] <= kmax[dx]) {
+                    atomicMin(&s_min[cx], kmin[dx]);
+                    atomicMax(&s_max[cx], kmax[dx]);
+                }
             }
-        } else {
-            const int xhi = min(vpc_x * cx + vpc_x, w - 1);
-            if (x0 < xhi)
-                for (int z = zlo; z < zhi; ++z)
-                    for (int y = ylo; y < yhi; ++y) {
-                        uint32_t k = Key<VT>::enc(vol[(unsigned long long)z * slice +
-                                                      (unsigned long long)y * row + x0]);
-                        kmin = min(kmin, k);
-                        kmax = max(kmax, k);
-                    }
-        }
-        if (cx < tex_x && kmin <= kmax) {
-            atomicMin(&s_min[cx], kmin);
-            atomicMax(&s_max[cx], kmax);
         }
     }
     __syncthreads();
@@ -108,50 +120,86 @@ hipError_t build_typed(const VolView &vol, const uint32_t tex[3], void *out, hip
     int vpc[3];
     const int dim[3] = {vol.w, vol.h, vol.d};
     for (int i = 0; i < 3; ++i) vpc[i] = (int)ceilf((float)dim[i] / (float)tex[i]);
-    constexpr int VEC = 16 / (int)sizeof(VT);
-    const bool fast = ((size_t)vol.row * sizeof(VT)) % 16 == 0 &&
-                      (vol.row - (unsigned long long)vol.w) * sizeof(VT) >= 16 && vpc[0] % VEC == 0 &&
-                      ((uintptr_t)vol.data % 16) == 0;
     dim3 grid(tex[1] * tex[2]), block(kThreads);
     size_t lds = 2 * (size_t)tex[0] * sizeof(uint32_t);
-    if (fast)
-        hipLaunchKernelGGL((vr_build_bricks_kernel<VT, VEC>), grid, block, lds, stream,
-                           (const VT *)vol.data, vol.w, vol.h, vol.d, vol.row, vol.slice,
-                           (int)tex[0], (int)tex[1], (int)tex[2], vpc[0], vpc[1], vpc[2], (VT *)out);
-    else
-        hipLaunchKernelGGL((vr_build_bricks_kernel<VT, 1>), grid, block, lds, stream,
-                           (const VT *)vol.data, vol.w, vol.h, vol.d, vol.row, vol.slice,
-                           (int)tex[0], (int)tex[1], (int)tex[2], vpc[0], vpc[1], vpc[2], (VT *)out);
+    hipLaunchKernelGGL(vr_build_bricks_kernel<VT>, grid, block, lds, stream, vol, (int)tex[0],
+                       (int)tex[1], vpc[0], vpc[1], vpc[2], (VT *)out);
     return hipGetLastError();
 }
 
-// SURVEY 8(d) synthetic fields: p = 2(i+0.5)/N - 1; sphere d = max(0, 1-|p|/0.9);
-// shells = d*(0.5+0.5cos(24 pi |p|)) with values < 0.35 zeroed.
+// One thread per micro-brick of the slab [z0, z0 + nz): gathers its 16 rows of 4 voxels from
+// the dense array (each wave-load covers 64 lanes x 4 voxels of one row: coalesced) and writes
+// the 64 voxels contiguously -- or the inverse.  Voxels outside the volume are written as 0 and
+// never read back (texel indices are clamped to the edge).
 template <typename VT>
-__global__ __launch_bounds__(kThreads) void vr_synth_kernel(VT *dst, int w, int h, int d,
-                                                             unsigned long long row,
-                                                             unsigned long long slice, int kind)
+__global__ __launch_bounds__(kThreads) void vr_retile_kernel(VolView vol, VT *dense, int z0, int nz,
+                                                             bool to_bricks)
 {
-    const size_t n = (size_t)w * h * d;
+    const int mz0 = z0 >> 2, mz_n = ((z0 + nz - 1) >> 2) - mz0 + 1;
+    const size_t n = (size_t)vol.nbx * vol.nby * (size_t)mz_n;
+    VT *bricks = (VT *)const_cast<void *>(vol.data);
     for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n;
          i += (size_t)gridDim.x * kThreads) {
-        int x = (int)(i % (size_t)w);
-        size_t r = i / (size_t)w;
-        int y = (int)(r % (size_t)h), z = (int)(r / (size_t)h);
-        double px = 2.0 * (x + 0.5) / w - 1.0;
-        double py = 2.0 * (y + 0.5) / h - 1.0;
-        double pz = 2.0 * (z + 0.5) / d - 1.0;
-        double rr = sqrt(px * px + py * py + pz * pz);
-        double dv = 1.0 - rr / 0.9;
-        if (dv < 0.0) dv = 0.0;
-        if (kind == 1) {
-            dv = dv * (0.5 + 0.5 * cos(24.0 * 3.14159265358979323846 * rr));
-            if (dv < 0.35) dv = 0.0;
+        const int mx = (int)(i % vol.nbx);
+        const size_t r = i / vol.nbx;
+        const int my = (int)(r % vol.nby), mz = mz0 + (int)(r / vol.nby);
+        VT *b = bricks + (unsigned long long)mz * vol.zstride + (unsigned long long)my * vol.ystride +
+                (unsigned long long)mx * 64ull;
+#pragma unroll
+        for (int dz = 0; dz < 4; ++dz)
+#pragma unroll
+            for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 4; ++dx) {
+                    const int x = 4 * mx + dx, y = 4 * my + dy, z = 4 * mz + dz;
+                    const bool in = x < vol.w && y < vol.h && z >= z0 && z < z0 + nz;
+                    const size_t di = ((size_t)(z - z0) * vol.h + y) * vol.w + x;
+                    if (to_bricks) {
+                        if (in) b[dz * 16 + dy * 4 + dx] = dense[di];
+                        else if (z >= vol.d || y >= vol.h || x >= vol.w) b[dz * 16 + dy * 4 + dx] = (VT)0;
+                    } else if (in) {
+                        dense[di] = b[dz * 16 + dy * 4 + dx];
+                    }
+                }
+    }
+}
+
+// SURVEY 8(d) synthetic fields: p = 2(i+0.5)/N - 1; sphere d = max(0, 1-|p|/0.9);
+// shells = d*(0.5+0.5cos(24 pi |p|)) with values < 0.35 zeroed.  One thread per micro-brick.
+template <typename VT>
+__global__ __launch_bounds__(kThreads) void vr_synth_kernel(VolView vol, int kind)
+{
+    const size_t n = (size_t)vol.nbx * vol.nby * vol.nbz;
+    VT *bricks = (VT *)const_cast<void *>(vol.data);
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * kThreads) {
+        const int mx = (int)(i % vol.nbx);
+        const size_t r = i / vol.nbx;
+        const int my = (int)(r % vol.nby), mz = (int)(r / vol.nby);
+        VT v[64];
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            const int x = 4 * mx + (j & 3), y = 4 * my + ((j >> 2) & 3), z = 4 * mz + (j >> 4);
+            double px = 2.0 * (x + 0.5) / vol.w - 1.0;
+            double py = 2.0 * (y + 0.5) / vol.h - 1.0;
+            double pz = 2.0 * (z + 0.5) / vol.d - 1.0;
+            double rr = sqrt(px * px + py * py + pz * pz);
+            double dv = 1.0 - rr / 0.9;
+            if (dv < 0.0) dv = 0.0;
+            if (kind == 1) {
+                dv = dv * (0.5 + 0.5 * cos(24.0 * 3.14159265358979323846 * rr));
+                if (dv < 0.35) dv = 0.0;
+            }
+            if (x >= vol.w || y >= vol.h || z >= vol.d) dv = 0.0;
+            if (sizeof(VT) == 1) v[j] = (VT)llround(255.0 * dv);
+            else if (sizeof(VT) == 2) v[j] = (VT)llround(65535.0 * dv);
+            else v[j] = (VT)dv;
         }
-        const size_t o = (size_t)z * slice + (size_t)y * row + (size_t)x;
-        if (sizeof(VT) == 1) dst[o] = (VT)llround(255.0 * dv);
-        else if (sizeof(VT) == 2) dst[o] = (VT)llround(65535.0 * dv);
-        else dst[o] = (VT)dv;
+        uint4 q[64 * sizeof(VT) / 16];
+        __builtin_memcpy(q, v, sizeof v);
+        uint4 *dst = reinterpret_cast<uint4 *>(bricks + i * 64ull);
+#pragma unroll
+        for (size_t k = 0; k < 64 * sizeof(VT) / 16; ++k) dst[k] = q[k];
     }
 }
 
@@ -168,22 +216,35 @@ hipError_t vr_launch_build_bricks(const VolView &vol, int format, const uint32_t
     }
 }
 
-hipError_t vr_launch_synth(int kind, void *dst, const uint32_t res[3], unsigned long long row,
-                           unsigned long long slice, int format, hipStream_t stream)
+hipError_t vr_launch_synth(int kind, const VolView &vol, int format, hipStream_t stream)
 {
-    dim3 grid(256 * 32), block(kThreads);
+    dim3 grid(256 * 16), block(kThreads);
+    switch (format) {
+    case VRHIP_UCHAR: hipLaunchKernelGGL(vr_synth_kernel<uint8_t>, grid, block, 0, stream, vol, kind); break;
+    case VRHIP_USHORT: hipLaunchKernelGGL(vr_synth_kernel<uint16_t>, grid, block, 0, stream, vol, kind); break;
+    case VRHIP_FLOAT: hipLaunchKernelGGL(vr_synth_kernel<float>, grid, block, 0, stream, vol, kind); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t vr_launch_retile(const VolView &vol, int format, const void *dense, int z0, int nz,
+                            bool to_bricks, hipStream_t stream)
+{
+    if (nz <= 0) return hipSuccess;
+    const size_t n = (size_t)vol.nbx * vol.nby * (size_t)(((z0 + nz - 1) >> 2) - (z0 >> 2) + 1);
+    unsigned blocks = (unsigned)std::min<size_t>((n + kThreads - 1) / kThreads, 256 * 32);
+    dim3 grid(blocks), block(kThreads);
+    void *dn = const_cast<void *>(dense);
     switch (format) {
     case VRHIP_UCHAR:
-        hipLaunchKernelGGL(vr_synth_kernel<uint8_t>, grid, block, 0, stream, (uint8_t *)dst,
-                           (int)res[0], (int)res[1], (int)res[2], row, slice, kind);
+        hipLaunchKernelGGL(vr_retile_kernel<uint8_t>, grid, block, 0, stream, vol, (uint8_t *)dn, z0, nz, to_bricks);
         break;
     case VRHIP_USHORT:
-        hipLaunchKernelGGL(vr_synth_kernel<uint16_t>, grid, block, 0, stream, (uint16_t *)dst,
-                           (int)res[0], (int)res[1], (int)res[2], row, slice, kind);
+        hipLaunchKernelGGL(vr_retile_kernel<uint16_t>, grid, block, 0, stream, vol, (uint16_t *)dn, z0, nz, to_bricks);
         break;
     case VRHIP_FLOAT:
-        hipLaunchKernelGGL(vr_synth_kernel<float>, grid, block, 0, stream, (float *)dst,
-                           (int)res[0], (int)res[1], (int)res[2], row, slice, kind);
+        hipLaunchKernelGGL(vr_retile_kernel<float>, grid, block, 0, stream, vol, (float *)dn, z0, nz, to_bricks);
         break;
     default: return hipErrorInvalidValue;
     }

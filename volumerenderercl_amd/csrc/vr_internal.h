@@ -5,16 +5,26 @@
 
 #include "../../include/vrhip.h"
 
-// Scalar field in HBM. Layout (DESIGN.md "Data layout"): dense, x fastest, then y, z.
+// Scalar field in HBM (DESIGN.md "Data layout"): 4x4x4-voxel MICRO-BRICKS of 64 contiguous
+// voxels (x fastest inside a brick) -- one 64-byte line for UCHAR -- stored x-fastest over the
+// brick grid.  Every line a ray bundle pulls in is a compact 3-D neighbourhood, whatever the
+// view direction.  Element index of voxel (x, y, z):
+//   (((z>>2)*nby + (y>>2))*nbx + (x>>2))*64 + (z&3)*16 + (y&3)*4 + (x&3)
 struct VolView {
     const void *data;
     int w, h, d;
     float fw, fh, fd;
     float inv_max;              // UNORM scale: 1/255, 1/65535, 1
-    unsigned long long row;     // voxels per y step
-    unsigned long long slice;   // voxels per z step
-    int mbx, mby;               // micro-brick (4^3 voxels) grid, for the traffic bitmap
+    uint32_t nbx, nby, nbz;     // micro-brick grid = ceil(res / 4)
+    uint32_t ystride;           // elements per brick row:   nbx * 64
+    unsigned long long zstride; // elements per brick slice: nbx * nby * 64
 };
+
+__host__ __device__ inline unsigned long long vr_voxel_index(const VolView &v, int x, int y, int z)
+{
+    return (unsigned long long)(z >> 2) * v.zstride + (unsigned long long)(y >> 2) * v.ystride +
+           (unsigned long long)(((x >> 2) << 6) + ((z & 3) << 4) + ((y & 3) << 2) + (x & 3));
+}
 
 // min/max brick grid (generateBricks): (min,max) pairs in the volume's type, x fastest.
 struct BrickView {
@@ -31,12 +41,11 @@ struct TfView {
 
 // ESS decision per brick, precomputed from (bricks, TF, prefix sum): bit = 1 when the
 // reference's test `TF(max).a < 1e-6 && prefix[min] == prefix[max]` (volumeraycast.cl:
-// 777-787) holds.  x-fastest bit index; `oob_skip` is the decision for the (0,0) value
+// 777-787) holds.  x-fastest bit index; word n_words holds the decision for the (0,0) value
 // defined for out-of-range cells.
 struct SkipView {
     const uint32_t *bits;
     uint32_t n_words;
-    uint32_t oob_skip;
     uint32_t in_lds;       // bitmap is staged in LDS by every workgroup
 };
 
@@ -83,10 +92,12 @@ hipError_t vr_launch_raycast(const RaycastLaunch &a, hipStream_t stream);
 
 // skip bitmap from bricks + TF + prefix
 hipError_t vr_launch_skipmap(const BrickView &bricks, int format, float inv_max, const TfView &tf,
-                             uint32_t *bits, uint32_t n_words, uint32_t *oob_skip_dev,
-                             hipStream_t stream);
+                             uint32_t *bits, uint32_t n_words, hipStream_t stream);
 
 hipError_t vr_launch_build_bricks(const VolView &vol, int format, const uint32_t tex[3],
                                   void *bricks_out, hipStream_t stream);
-hipError_t vr_launch_synth(int kind, void *dst, const uint32_t res[3], unsigned long long row,
-                           unsigned long long slice, int format, hipStream_t stream);
+// synthetic field written straight into the micro-brick layout
+hipError_t vr_launch_synth(int kind, const VolView &vol, int format, hipStream_t stream);
+// dense x-fastest slices [z0, z0+nz) (device memory, `dense` points at slice z0) <-> bricks
+hipError_t vr_launch_retile(const VolView &vol, int format, const void *dense, int z0, int nz,
+                            bool to_bricks, hipStream_t stream);

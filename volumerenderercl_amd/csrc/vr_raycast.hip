@@ -28,7 +28,10 @@
 namespace {
 
 constexpr int kBlockDim = 256;       // 4 waves
-constexpr int kMaxBrickSteps = 4;    // DDA steps per round while other lanes wait to sample
+#ifndef VR_MAXBRICK
+#define VR_MAXBRICK 4
+#endif
+constexpr int kMaxBrickSteps = VR_MAXBRICK;   // DDA steps per round while other lanes wait to sample
 #ifndef VR_BATCH
 #define VR_BATCH 4
 #endif
@@ -66,15 +69,26 @@ struct Vol {
     int w1, h1, d1;   // res - 1
     float fw, fh, fd;
     float inv_max;
-    unsigned long long row, slice;
-    int mbx, mby;
+    uint32_t nbx, nby, ystride;     // micro-brick layout (vr_internal.h)
+    unsigned long long zstride;
     uint32_t *touched;
+
+    // per-axis parts of the element index of voxel (x, y, z) in the 4x4x4 micro-brick layout
+    VR_DEV uint32_t xoff(int x) const { return ((uint32_t)(x >> 2) << 6) + (uint32_t)(x & 3); }
+    VR_DEV uint32_t yoff(int y) const
+    {
+        return __umul24((uint32_t)(y >> 2), ystride) + ((uint32_t)(y & 3) << 2);
+    }
+    VR_DEV unsigned long long zoff(int z) const
+    {
+        return (unsigned long long)(uint32_t)(z >> 2) * zstride + (unsigned long long)((z & 3) << 4);
+    }
 
     VR_DEV void touch(int x, int y, int z) const
     {
         if (INSTR == 2) {
-            unsigned long long b = ((unsigned long long)(z >> 2) * (unsigned long long)mby +
-                                    (unsigned long long)(y >> 2)) * (unsigned long long)mbx +
+            unsigned long long b = ((unsigned long long)(z >> 2) * (unsigned long long)nby +
+                                    (unsigned long long)(y >> 2)) * (unsigned long long)nbx +
                                    (unsigned long long)(x >> 2);
             uint32_t bit = 1u << (uint32_t)(b & 31);
             uint32_t *wp = touched + (b >> 5);
@@ -82,10 +96,10 @@ struct Vol {
                 atomicOr(wp, bit);
         }
     }
-    VR_DEV float raw(int x, int y, unsigned long long zoff, int z) const
+    VR_DEV float raw(uint32_t xo, uint32_t yo, unsigned long long zo, int x, int y, int z) const
     {
         touch(x, y, z);
-        return (float)p[zoff + (unsigned long long)y * row + (unsigned long long)x];
+        return (float)p[zo + (unsigned long long)(yo + xo)];
     }
 
     // read_imagef(vol, linearSmp, pos).x -- normalised, CLAMP_TO_EDGE, LINEAR
@@ -99,12 +113,12 @@ struct Vol {
         int x0 = iclamp(ix, 0, w1), x1 = iclamp(ix + 1, 0, w1);
         int y0 = iclamp(iy, 0, h1), y1 = iclamp(iy + 1, 0, h1);
         int z0 = iclamp(iz, 0, d1), z1 = iclamp(iz + 1, 0, d1);
-        unsigned long long zo0 = (unsigned long long)z0 * slice;
-        unsigned long long zo1 = (unsigned long long)z1 * slice;
-        float v000 = raw(x0, y0, zo0, z0), v100 = raw(x1, y0, zo0, z0);
-        float v010 = raw(x0, y1, zo0, z0), v110 = raw(x1, y1, zo0, z0);
-        float v001 = raw(x0, y0, zo1, z1), v101 = raw(x1, y0, zo1, z1);
-        float v011 = raw(x0, y1, zo1, z1), v111 = raw(x1, y1, zo1, z1);
+        const uint32_t xo0 = xoff(x0), xo1 = xoff(x1), yo0 = yoff(y0), yo1 = yoff(y1);
+        const unsigned long long zo0 = zoff(z0), zo1 = zoff(z1);
+        float v000 = raw(xo0, yo0, zo0, x0, y0, z0), v100 = raw(xo1, yo0, zo0, x1, y0, z0);
+        float v010 = raw(xo0, yo1, zo0, x0, y1, z0), v110 = raw(xo1, yo1, zo0, x1, y1, z0);
+        float v001 = raw(xo0, yo0, zo1, x0, y0, z1), v101 = raw(xo1, yo0, zo1, x1, y0, z1);
+        float v011 = raw(xo0, yo1, zo1, x0, y1, z1), v111 = raw(xo1, yo1, zo1, x1, y1, z1);
         float c00 = lerpf(v000, v100, a);
         float c10 = lerpf(v010, v110, a);
         float c01 = lerpf(v001, v101, a);
@@ -126,15 +140,18 @@ struct Vol {
         float a = ub - fx, b = vb - fy, c = sb - fz;
         int ix = (int)fx, iy = (int)fy, iz = (int)fz;
         int X[4], Y[4], Z[4];
+        uint32_t xo[4], yo[4];
         unsigned long long zo[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             X[k] = iclamp(ix - 1 + k, 0, w1);
             Y[k] = iclamp(iy - 1 + k, 0, h1);
             Z[k] = iclamp(iz - 1 + k, 0, d1);
-            zo[k] = (unsigned long long)Z[k] * slice;
+            xo[k] = xoff(X[k]);
+            yo[k] = yoff(Y[k]);
+            zo[k] = zoff(Z[k]);
         }
-#define VR_L(xi, yi, zi) raw(X[xi], Y[yi], zo[zi], Z[zi])
+#define VR_L(xi, yi, zi) raw(xo[xi], yo[yi], zo[zi], X[xi], Y[yi], Z[zi])
 #define VR_R(yi, zi) lerpf(VR_L(1, yi, zi), VR_L(2, yi, zi), a)   /* texels (x0, x1)   */
 #define VR_M(yi, zi) lerpf(VR_L(0, yi, zi), VR_L(1, yi, zi), a)   /* texels (x0-1, x0) */
 #define VR_P(yi, zi) lerpf(VR_L(2, yi, zi), VR_L(3, yi, zi), a)   /* texels (x1, x1+1) */
@@ -165,8 +182,8 @@ struct Vol {
         if (!(fx >= 0.0f && fx <= (float)w1 && fy >= 0.0f && fy <= (float)h1 && fz >= 0.0f &&
               fz <= (float)d1))
             return 0.0f;
-        int z = (int)fz;
-        return raw((int)fx, (int)fy, (unsigned long long)z * slice, z) * inv_max;
+        int x = (int)fx, y = (int)fy, z = (int)fz;
+        return raw(xoff(x), yoff(y), zoff(z), x, y, z) * inv_max;
     }
 };
 
@@ -232,7 +249,7 @@ __global__ __launch_bounds__(kBlockDim) void vr_skipmap_kernel(BrickView b, floa
         if (w < n_words) bits[w] = (uint32_t)m;
         if (w + 1 < n_words) bits[w + 1] = (uint32_t)(m >> 32);
     }
-    if (i == 0) bits[n_words] = skip_test(tf, 0.0f, 0.0f) ? 1u : 0u;
+    if (i == 0) bits[n_words] = skip_test(tf, 0.0f, 0.0f) ? 0xffffffffu : 0u;   // every bit
 }
 
 // ------------------------------------------------------------------ ray set-up
@@ -339,8 +356,8 @@ __global__ __launch_bounds__(kBlockDim) void vr_raycast_kernel(
     vol.w1 = vv.w - 1; vol.h1 = vv.h - 1; vol.d1 = vv.d - 1;
     vol.fw = vv.fw; vol.fh = vv.fh; vol.fd = vv.fd;
     vol.inv_max = vv.inv_max;
-    vol.row = vv.row; vol.slice = vv.slice;
-    vol.mbx = vv.mbx; vol.mby = vv.mby;
+    vol.nbx = vv.nbx; vol.nby = vv.nby;
+    vol.ystride = vv.ystride; vol.zstride = vv.zstride;
     vol.touched = touched;
     const f3 voxLen = mk3(1.f / vol.fw, 1.f / vol.fh, 1.f / vol.fd);
     const float refInterval = 1.f / rc.samplingRate;
@@ -380,6 +397,7 @@ __global__ __launch_bounds__(kBlockDim) void vr_raycast_kernel(
         float t = 0.f, t_exit = tfar, stepSize = 0.f, offset = 0.f;
         int stepv[3] = {0, 0, 0}, cell[3] = {0, 0, 0}, exitc[3] = {0, 0, 0};
         float tv[3] = {0, 0, 0}, deltaT[3] = {0, 0, 0};
+        uint32_t cidx = 0, skw = 0;   // linear index of the current cell and its bitmap word
         // per-ray invariants of illumination()/specularBlinnPhong() (:280-303)
         const f3 toLight = neg3(rayDir);
         const f3 lgt = normalize3(toLight);
@@ -415,6 +433,10 @@ __global__ __launch_bounds__(kBlockDim) void vr_raycast_kernel(
                     exitc[i] = stepv[i] * bres[i];
                     if (exitc[i] < 0) exitc[i] = -1;
                 }
+                // bitmap word of the start cell (always inside the grid after the clamp)
+                cidx = __umul24(__umul24((uint32_t)cell[2], (uint32_t)bh) + (uint32_t)cell[1],
+                                (uint32_t)bw) + (uint32_t)cell[0];
+                skw = (SKIP_LDS ? s_skip : skip.bits)[cidx >> 5];
             }
         }
 
@@ -427,40 +449,42 @@ __global__ __launch_bounds__(kBlockDim) void vr_raycast_kernel(
                     const bool inB = state == S_BRICK;
                     if (!__ballot(inB)) break;
                     if (it >= kMaxBrickSteps && __ballot(state == S_SAMPLE)) break;
-                    if (inB) {
-                        if (!(t < tfar)) {   // outer loop condition (:763)
-                            state = S_DONE;
-                        } else {
-                            bool skp;
-                            const int cx = cell[0], cy = cell[1], cz = cell[2];
-                            const uint32_t *sb = SKIP_LDS ? s_skip : skip.bits;
-                            if (cx < 0 || cy < 0 || cz < 0 || cx >= bw || cy >= bh || cz >= bd) {
-                                skp = sb[skip.n_words] != 0u;
-                            } else {
-                                uint32_t idx = ((uint32_t)cz * (uint32_t)bh + (uint32_t)cy) *
-                                                   (uint32_t)bw + (uint32_t)cx;
-                                skp = (sb[idx >> 5] >> (idx & 31u)) & 1u;
-                            }
-                            if (INSTR) c_bricks++;
-                            float inc0 = (tv[0] <= tv[1]) && (tv[0] <= tv[2]) ? 1.f : 0.f;
-                            float inc1 = (tv[1] <= tv[0]) && (tv[1] <= tv[2]) ? 1.f : 0.f;
-                            float inc2 = (tv[2] <= tv[0]) && (tv[2] <= tv[1]) ? 1.f : 0.f;
-                            cell[0] += (int)inc0 * stepv[0];
-                            cell[1] += (int)inc1 * stepv[1];
-                            cell[2] += (int)inc2 * stepv[2];
-                            t_exit = ((tv[0] * inc0) + (tv[1] * inc1)) + (tv[2] * inc2);
-                            t_exit = vclamp(t_exit, t + stepSize, t + brickDia);
-                            tv[0] += inc0 * deltaT[0];
-                            tv[1] += inc1 * deltaT[1];
-                            tv[2] += inc2 * deltaT[2];
-                            if (skp) {
-                                if (INSTR) c_skipped++;
-                                t = t_exit;   // :784-785 `continue`
-                            } else {
-                                state = S_SAMPLE;
-                            }
-                        }
+                    VR_COUNT(9);
+                    // One DDA step (:763-787) as BRANCH-FREE predicated code: a lone wave pays
+                    // an instruction-buffer refill per taken branch, and this loop used to be
+                    // mostly branches.  Every lane computes the step; `go` (lane is in S_BRICK
+                    // and passes the outer loop condition t < tfar) gates what is committed.
+                    const bool go = inB && (t < tfar);
+                    // decision for the current cell: its bitmap word was fetched one step
+                    // ahead (skw), so the LDS latency overlaps the step arithmetic
+                    const bool skp = (skw >> (cidx & 31u)) & 1u;
+                    const bool m0 = (tv[0] <= tv[1]) && (tv[0] <= tv[2]);
+                    const bool m1 = (tv[1] <= tv[0]) && (tv[1] <= tv[2]);
+                    const bool m2 = (tv[2] <= tv[0]) && (tv[2] <= tv[1]);
+                    const float inc0 = m0 ? 1.f : 0.f, inc1 = m1 ? 1.f : 0.f, inc2 = m2 ? 1.f : 0.f;
+                    float te = ((tv[0] * inc0) + (tv[1] * inc1)) + (tv[2] * inc2);
+                    te = vclamp(te, t + stepSize, t + brickDia);
+                    cell[0] += (go && m0) ? stepv[0] : 0;
+                    cell[1] += (go && m1) ? stepv[1] : 0;
+                    cell[2] += (go && m2) ? stepv[2] : 0;
+                    tv[0] = go ? tv[0] + inc0 * deltaT[0] : tv[0];
+                    tv[1] = go ? tv[1] + inc1 * deltaT[1] : tv[1];
+                    tv[2] = go ? tv[2] + inc2 * deltaT[2] : tv[2];
+                    t_exit = go ? te : t_exit;
+                    // fetch the word of the cell just entered (out-of-range cells read the
+                    // trailing word, which holds the (0,0) decision in every bit)
+                    {
+                        const uint32_t *sb = SKIP_LDS ? s_skip : skip.bits;
+                        const bool oob = (uint32_t)cell[0] >= (uint32_t)bw ||
+                                         (uint32_t)cell[1] >= (uint32_t)bh ||
+                                         (uint32_t)cell[2] >= (uint32_t)bd;
+                        cidx = __umul24(__umul24((uint32_t)cell[2], (uint32_t)bh) +
+                                            (uint32_t)cell[1], (uint32_t)bw) + (uint32_t)cell[0];
+                        skw = sb[oob ? skip.n_words : (cidx >> 5)];
                     }
+                    if (INSTR) { c_bricks += go ? 1 : 0; c_skipped += (go && skp) ? 1 : 0; }
+                    t = (go && skp) ? te : t;   // :784-785 `continue`
+                    state = inB ? (go ? (skp ? S_BRICK : S_SAMPLE) : S_DONE) : state;
                 }
             }
             VR_STAMP(2);
@@ -686,7 +710,7 @@ hipError_t vr_launch_raycast(const RaycastLaunch &a, hipStream_t stream)
 }
 
 hipError_t vr_launch_skipmap(const BrickView &bricks, int format, float inv_max, const TfView &tf,
-                             uint32_t *bits, uint32_t n_words, uint32_t *, hipStream_t stream)
+                             uint32_t *bits, uint32_t n_words, hipStream_t stream)
 {
     const size_t n = (size_t)bricks.bw * bricks.bh * bricks.bd;
     dim3 grid((unsigned)((n + kBlockDim - 1) / kBlockDim)), block(kBlockDim);

@@ -36,10 +36,9 @@ struct vrhip_renderer {
 
     uint32_t res[3] = {0, 0, 0};
     int format = -1;
-    // HBM layout of a time step: dense x-fastest rows with padded, non-power-of-two row and
-    // slice pitches (elements) so that neighbouring rows / slices spread over the memory
-    // channels (DESIGN.md "Data layout")
-    unsigned long long row_pitch = 0, slice_pitch = 0;
+    // HBM layout of a time step: 4x4x4-voxel micro-bricks (vr_internal.h, DESIGN.md "Data
+    // layout"); nb = ceil(res / 4)
+    uint32_t nb[3] = {0, 0, 0};
     std::vector<VolumeSlot> vols;
     uint32_t timestep = 0;
 
@@ -129,35 +128,48 @@ size_t volume_bytes(const vrhip_renderer *r)   // dense (host-side) size
 
 size_t volume_alloc_bytes(const vrhip_renderer *r)
 {
-    return (size_t)r->slice_pitch * r->res[2] * fmt_bytes(r->format);
+    return (size_t)r->nb[0] * r->nb[1] * r->nb[2] * 64 * fmt_bytes(r->format);
 }
 
-void set_pitches(vrhip_renderer *r)
+void set_layout(vrhip_renderer *r)
 {
-    const size_t bpv = fmt_bytes(r->format);
-    size_t pad = 64;   // bytes per row; VRHIP_PITCH_PAD=0 gives the dense power-of-two layout
-    if (const char *e = getenv("VRHIP_PITCH_PAD")) pad = (size_t)atoi(e);
-    size_t row_b = (((size_t)r->res[0] * bpv + 63) / 64) * 64 + (pad / 16) * 16;
-    if (pad == 0) row_b = (size_t)r->res[0] * bpv;
-    r->row_pitch = row_b / bpv;
-    r->slice_pitch = r->row_pitch * ((size_t)r->res[1] + (pad ? 1 : 0));
+    for (int i = 0; i < 3; ++i) r->nb[i] = (r->res[i] + 3) / 4;
 }
 
-// dense host/device array <-> pitched device volume
-hipError_t copy_volume(const vrhip_renderer *r, void *pitched_dev, void *dense, bool to_device,
-                       hipMemcpyKind kind, hipStream_t stream)
+VolView make_vol_view(const vrhip_renderer *r, const void *data);
+
+// Dense x-fastest array (host memory, or device memory when dense_is_device) <-> micro-bricks,
+// slab by slab (multiples of 4 slices) through a bounded device staging buffer.
+hipError_t copy_volume(const vrhip_renderer *r, void *bricks_dev, void *dense, bool to_bricks,
+                       bool dense_is_device, hipStream_t stream)
 {
     const size_t bpv = fmt_bytes(r->format);
-    hipMemcpy3DParms p;
-    std::memset(&p, 0, sizeof p);
-    hipPitchedPtr dev = make_hipPitchedPtr(pitched_dev, r->row_pitch * bpv, r->res[0] * bpv,
-                                           r->slice_pitch / r->row_pitch);
-    hipPitchedPtr den = make_hipPitchedPtr(dense, r->res[0] * bpv, r->res[0] * bpv, r->res[1]);
-    p.srcPtr = to_device ? den : dev;
-    p.dstPtr = to_device ? dev : den;
-    p.extent = make_hipExtent(r->res[0] * bpv, r->res[1], r->res[2]);
-    p.kind = kind;
-    return hipMemcpy3DAsync(&p, stream);
+    const size_t slice_b = (size_t)r->res[0] * r->res[1] * bpv;
+    const VolView v = make_vol_view(r, bricks_dev);
+    if (dense_is_device) {
+        hipError_t e = vr_launch_retile(v, r->format, dense, 0, (int)r->res[2], to_bricks, stream);
+        return e != hipSuccess ? e : hipStreamSynchronize(stream);
+    }
+    int slab = (int)std::max<size_t>(4, ((size_t)256 << 20) / std::max<size_t>(slice_b, 1) / 4 * 4);
+    slab = std::min<int>(slab, (int)((r->res[2] + 3) / 4 * 4));
+    void *stage = nullptr;
+    hipError_t e = hipMalloc(&stage, (size_t)slab * slice_b);
+    if (e != hipSuccess) return e;
+    for (int z0 = 0; z0 < (int)r->res[2] && e == hipSuccess; z0 += slab) {
+        const int nz = std::min<int>(slab, (int)r->res[2] - z0);
+        char *h = (char *)dense + (size_t)z0 * slice_b;
+        if (to_bricks) {
+            e = hipMemcpyAsync(stage, h, (size_t)nz * slice_b, hipMemcpyHostToDevice, stream);
+            if (e == hipSuccess) e = vr_launch_retile(v, r->format, stage, z0, nz, true, stream);
+        } else {
+            e = vr_launch_retile(v, r->format, stage, z0, nz, false, stream);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(h, stage, (size_t)nz * slice_b, hipMemcpyDeviceToHost, stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);   // staging buffer is reused
+    }
+    (void)hipFree(stage);
+    return e;
 }
 
 size_t bricks_bytes(const vrhip_renderer *r)
@@ -191,10 +203,11 @@ VolView make_vol_view(const vrhip_renderer *r, const void *data)
     v.w = (int)r->res[0]; v.h = (int)r->res[1]; v.d = (int)r->res[2];
     v.fw = (float)v.w; v.fh = (float)v.h; v.fd = (float)v.d;
     v.inv_max = inv_max_of(r->format);
-    v.row = r->row_pitch;
-    v.slice = r->slice_pitch;
-    v.mbx = (v.w + 3) / 4;
-    v.mby = (v.h + 3) / 4;
+    v.nbx = r->nb[0];
+    v.nby = r->nb[1];
+    v.nbz = r->nb[2];
+    v.ystride = r->nb[0] * 64u;
+    v.zstride = (unsigned long long)r->nb[0] * r->nb[1] * 64ull;
     return v;
 }
 
@@ -243,7 +256,7 @@ int prepare_slot(vrhip_renderer *r, const uint32_t res[3], int format, uint32_t 
         if (rc) return rc;
         std::memcpy(r->res, res, sizeof r->res);
         r->format = format;
-        set_pitches(r);
+        set_layout(r);
     }
     if (r->vols.size() <= timestep) r->vols.resize(timestep + 1);
     VolumeSlot &s = r->vols[timestep];
@@ -306,7 +319,7 @@ int ensure_skipmap(vrhip_renderer *r)
     r->skip_words = words;
     VR_HIP(r, vr_launch_skipmap(make_brick_view(r, r->vols[r->timestep].bricks), r->format,
                                 inv_max_of(r->format), make_tf_view(r), r->skip_bits, words,
-                                nullptr, r->stream));
+                                r->stream));
     r->skip_dirty = false;
     return VRHIP_OK;
 }
@@ -376,6 +389,7 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
     a->skip.bits = r->skip_bits;
     a->skip.n_words = r->skip_words;
     a->skip.in_lds = ((size_t)r->skip_words + 1) * sizeof(uint32_t) <= kSkipLdsMaxBytes ? 1u : 0u;
+    if (getenv("VRHIP_SKIP_GLOBAL")) a->skip.in_lds = 0;   // experiments: bitmap from L2/HBM
     a->frame.W = width;
     a->frame.H = height;
     // padded NDRange of the reference (volumerendercl.cpp:513-514): a full extra group
@@ -564,9 +578,7 @@ int vrhip_upload_volume(vrhip_renderer *r, const void *host_voxels, const uint32
     VolumeSlot *s;
     int rc = prepare_slot(r, res, format, timestep, &s);
     if (rc) return rc;
-    VR_HIP(r, copy_volume(r, s->dev, const_cast<void *>(host_voxels), true, hipMemcpyHostToDevice,
-                          r->stream));
-    VR_HIP(r, hipStreamSynchronize(r->stream));
+    VR_HIP(r, copy_volume(r, s->dev, const_cast<void *>(host_voxels), true, false, r->stream));
     return VRHIP_OK;
 }
 
@@ -579,9 +591,7 @@ int vrhip_upload_volume_device(vrhip_renderer *r, const void *dev_voxels, const 
     VolumeSlot *s;
     int rc = prepare_slot(r, res, format, timestep, &s);
     if (rc) return rc;
-    VR_HIP(r, copy_volume(r, s->dev, const_cast<void *>(dev_voxels), true,
-                          hipMemcpyDeviceToDevice, r->stream));
-    VR_HIP(r, hipStreamSynchronize(r->stream));
+    VR_HIP(r, copy_volume(r, s->dev, const_cast<void *>(dev_voxels), true, true, r->stream));
     return VRHIP_OK;
 }
 
@@ -594,7 +604,7 @@ int vrhip_synth_volume(vrhip_renderer *r, int kind, const uint32_t res[3], int f
     VolumeSlot *s;
     int rc = prepare_slot(r, res, format, timestep, &s);
     if (rc) return rc;
-    VR_HIP(r, vr_launch_synth(kind, s->dev, res, r->row_pitch, r->slice_pitch, format, r->stream));
+    VR_HIP(r, vr_launch_synth(kind, make_vol_view(r, s->dev), format, r->stream));
     VR_HIP(r, hipStreamSynchronize(r->stream));
     return VRHIP_OK;
 }
@@ -607,9 +617,7 @@ int vrhip_download_volume(vrhip_renderer *r, uint32_t timestep, void *host_dst, 
     VR_REQUIRE(r, host_dst && bytes == volume_bytes(r), VRHIP_ERR_INVALID,
                "vrhip_download_volume: size mismatch");
     if (set_device(r)) return VRHIP_ERR_HIP;
-    VR_HIP(r, copy_volume(r, r->vols[timestep].dev, host_dst, false, hipMemcpyDeviceToHost,
-                          r->stream));
-    VR_HIP(r, hipStreamSynchronize(r->stream));
+    VR_HIP(r, copy_volume(r, r->vols[timestep].dev, host_dst, false, false, r->stream));
     return VRHIP_OK;
 }
 
