@@ -3,7 +3,8 @@
 
 Runs the diagnostic build of libvrhip (compiled with -DVR_STAMPS, selected through
 VRHIP_LIB_PATH) on a bench workload and prints the per-phase share of summed wave time.
-Stamps drain the memory queues, so read the SHARES, not the frame time."""
+Stamps drain the memory queues, so read the SHARES, not the frame time.  Covers phase 1 only
+(run with VRHIP_ROUND_BUDGET=0 to see the single-phase march)."""
 import ctypes as C
 import os
 import sys
@@ -16,9 +17,10 @@ os.environ.setdefault("VRHIP_LIB_PATH",
 import bench  # noqa: E402
 from volumerenderercl_amd import VolumeRenderCL, frontend  # noqa: E402
 
-PHASES = ["queue pop + tile load", "ray set-up", "DDA (brick steps)", "positions + density fetch",
-          "TF lookup", "gradient + shading", "powr + composite + transitions", "frame write",
-          "LDS staging (block start)", "-", "rounds (count)", "tiles (count)", "wave lifetime"]
+PHASES = ["queue pop + tile load", "ray set-up", "DDA (brick steps)",
+          "batch evaluation (fetch, TF, shading, powr)", "-", "-",
+          "composite + transitions", "suspend / frame write", "LDS staging (block start)", "-",
+          "rounds (count)", "tiles (count)", "wave lifetime"]
 
 
 def main():
@@ -54,7 +56,8 @@ def main():
     acc = 0.0
     for i in range(9):
         acc += out[i]
-        print("  %-34s %6.2f %%" % (PHASES[i], 100.0 * out[i] / total))
+        if PHASES[i] != "-":
+            print("  %-44s %6.2f %%" % (PHASES[i], 100.0 * out[i] / total))
     print("  %-34s %6.2f %%" % ("(unattributed)", 100.0 * (total - acc) / total))
     print("  DDA loop iterations/frame %.0f -> cycles per DDA iteration %.0f" % (
         out[9] / frames, out[2] / max(out[9], 1)))

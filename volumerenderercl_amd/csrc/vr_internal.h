@@ -55,6 +55,18 @@ struct WaveTile {
     uint32_t out_base;     // index of its first pixel in FrameView::out
 };
 
+// Dynamic state of a suspended ray (two-phase march): everything else is recomputed from the
+// pixel.  64 bytes.
+struct ContRec {
+    uint32_t pix;          // gx | gy << 16
+    uint32_t out_index;    // pixel index in FrameView::out
+    int32_t state;
+    float t, t_exit, alpha, r0, r1, r2;
+    int32_t cx, cy, cz;
+    float tv0, tv1, tv2;
+    uint32_t pad;
+};
+
 struct FrameView {
     uint32_t W, H;         // frame size in pixels
     uint32_t gsx, gsy;     // padded launch size the reference derives the camera from
@@ -64,6 +76,12 @@ struct FrameView {
     uint32_t *queue_head;  // zeroed before each launch
     float4 *fb;            // W*H frame / accumulate buffer (always written)
     float4 *out;           // optional second destination (device), frame or tile layout
+    // Two-phase march: rays still alive after `round_budget` sample rounds of phase 1 (0 =
+    // unlimited) are appended to `cont` and resumed by the split kernel, 16 lanes per ray.
+    ContRec *cont;
+    uint32_t *cont_count;  // zeroed before each launch
+    uint32_t *cont_head;   // zeroed before each launch
+    uint32_t round_budget;
 };
 
 struct DevStats {

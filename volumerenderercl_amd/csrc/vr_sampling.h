@@ -1,0 +1,316 @@
+// vr_sampling.h -- device-side building blocks of the ray-cast kernels (single-TU header,
+// included by vr_raycast.hip only): volume / transfer-function / prefix reads restated from
+// the OpenCL 1.2 image rules, the ESS skip bitmap kernel, ray set-up
+// (/root/reference/src/kernel/volumeraycast.cl:605-683) and the diagnostic phase stamps.
+#pragma once
+#include <cstdio>
+#include <cstdlib>
+
+#include "vr_device_math.h"
+#include "vr_internal.h"
+
+namespace {
+
+constexpr int kBlockDim = 256;       // 4 waves
+#ifndef VR_MAXBRICK
+#define VR_MAXBRICK 4
+#endif
+constexpr int kMaxBrickSteps = VR_MAXBRICK;   // DDA steps per round while other lanes wait to sample
+#ifndef VR_BATCH
+#define VR_BATCH 4
+#endif
+constexpr int kBatch = VR_BATCH;     // consecutive samples of a ray evaluated per round
+
+enum : int { S_DONE = 0, S_BRICK = 1, S_SAMPLE = 2 };
+
+// Diagnostic build only (-DVR_STAMPS, tools/stamps.sh): per-phase shader-clock totals summed
+// over all waves.  Every stamp drains the memory queues, so only the SHARES are meaningful;
+// the stamp values leave the kernel through g_stamps alone and feed no output.
+#ifdef VR_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define VR_STAMP_DECL unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = vr_stamp(), st_first = st_last
+#define VR_STAMP(i) do { unsigned long long n_ = vr_stamp(); st_acc[i] += n_ - st_last; st_last = n_; } while (0)
+#define VR_COUNT(i) st_acc[i] += 1
+#define VR_STAMP_FLUSH do { if ((threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_stamps[i_], st_acc[i_]); atomicAdd(&g_stamps[12], vr_stamp() - st_first); } } while (0)
+__device__ __forceinline__ unsigned long long vr_stamp()
+{
+    unsigned long long t;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#else
+#define VR_STAMP_DECL
+#define VR_STAMP(i)
+#define VR_COUNT(i)
+#define VR_STAMP_FLUSH
+#endif
+
+// ------------------------------------------------------------------ volume reads
+
+template <typename VT, int INSTR>
+struct Vol {
+    const VT *p;
+    int w1, h1, d1;   // res - 1
+    float fw, fh, fd;
+    float inv_max;
+    uint32_t nbx, nby, ystride;     // micro-brick layout (vr_internal.h)
+    unsigned long long zstride;
+    uint32_t *touched;
+
+    // per-axis parts of the element index of voxel (x, y, z) in the 4x4x4 micro-brick layout
+    VR_DEV uint32_t xoff(int x) const { return ((uint32_t)(x >> 2) << 6) + (uint32_t)(x & 3); }
+    VR_DEV uint32_t yoff(int y) const
+    {
+        return __umul24((uint32_t)(y >> 2), ystride) + ((uint32_t)(y & 3) << 2);
+    }
+    VR_DEV unsigned long long zoff(int z) const
+    {
+        return (unsigned long long)(uint32_t)(z >> 2) * zstride + (unsigned long long)((z & 3) << 4);
+    }
+
+    VR_DEV void touch(int x, int y, int z) const
+    {
+        if (INSTR == 2) {
+            unsigned long long b = ((unsigned long long)(z >> 2) * (unsigned long long)nby +
+                                    (unsigned long long)(y >> 2)) * (unsigned long long)nbx +
+                                   (unsigned long long)(x >> 2);
+            uint32_t bit = 1u << (uint32_t)(b & 31);
+            uint32_t *wp = touched + (b >> 5);
+            if (!(__hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit))
+                atomicOr(wp, bit);
+        }
+    }
+    VR_DEV float raw(uint32_t xo, uint32_t yo, unsigned long long zo, int x, int y, int z) const
+    {
+        touch(x, y, z);
+        return (float)p[zo + (unsigned long long)(yo + xo)];
+    }
+
+    // read_imagef(vol, linearSmp, pos).x -- normalised, CLAMP_TO_EDGE, LINEAR
+    VR_DEV float linear(float px, float py, float pz) const
+    {
+        float u = px * fw, v = py * fh, s = pz * fd;
+        float ub = u - 0.5f, vb = v - 0.5f, sb = s - 0.5f;
+        float fx = floorf(ub), fy = floorf(vb), fz = floorf(sb);
+        float a = ub - fx, b = vb - fy, c = sb - fz;
+        int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+        int x0 = iclamp(ix, 0, w1), x1 = iclamp(ix + 1, 0, w1);
+        int y0 = iclamp(iy, 0, h1), y1 = iclamp(iy + 1, 0, h1);
+        int z0 = iclamp(iz, 0, d1), z1 = iclamp(iz + 1, 0, d1);
+        const uint32_t xo0 = xoff(x0), xo1 = xoff(x1), yo0 = yoff(y0), yo1 = yoff(y1);
+        const unsigned long long zo0 = zoff(z0), zo1 = zoff(z1);
+        float v000 = raw(xo0, yo0, zo0, x0, y0, z0), v100 = raw(xo1, yo0, zo0, x1, y0, z0);
+        float v010 = raw(xo0, yo1, zo0, x0, y1, z0), v110 = raw(xo1, yo1, zo0, x1, y1, z0);
+        float v001 = raw(xo0, yo0, zo1, x0, y0, z1), v101 = raw(xo1, yo0, zo1, x1, y0, z1);
+        float v011 = raw(xo0, yo1, zo1, x0, y1, z1), v111 = raw(xo1, yo1, zo1, x1, y1, z1);
+        float c00 = lerpf(v000, v100, a);
+        float c10 = lerpf(v010, v110, a);
+        float c01 = lerpf(v001, v101, a);
+        float c11 = lerpf(v011, v111, a);
+        float c0 = lerpf(c00, c10, b);
+        float c1 = lerpf(c01, c11, b);
+        return lerpf(c0, c1, c) * inv_max;
+    }
+
+    // -gradientCentralDiff(vol, pos).xyz (volumeraycast.cl:159-178, :814).  The six taps sit
+    // exactly one texel from the centre sample (offset = 1/volRes, :162): they are evaluated
+    // in texel space -- the centre's filter weights with indices shifted by -+1 and clamped to
+    // the edge -- so the 4x4x4 neighbourhood is loaded once: 32 voxel loads and one set of
+    // coordinate arithmetic instead of 6 x (8 loads + coordinates).  DESIGN.md "Numerics".
+    VR_DEV f3 neg_gradient(float px, float py, float pz) const
+    {
+        float ub = px * fw - 0.5f, vb = py * fh - 0.5f, sb = pz * fd - 0.5f;
+        float fx = floorf(ub), fy = floorf(vb), fz = floorf(sb);
+        float a = ub - fx, b = vb - fy, c = sb - fz;
+        int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+        int X[4], Y[4], Z[4];
+        uint32_t xo[4], yo[4];
+        unsigned long long zo[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            X[k] = iclamp(ix - 1 + k, 0, w1);
+            Y[k] = iclamp(iy - 1 + k, 0, h1);
+            Z[k] = iclamp(iz - 1 + k, 0, d1);
+            xo[k] = xoff(X[k]);
+            yo[k] = yoff(Y[k]);
+            zo[k] = zoff(Z[k]);
+        }
+#define VR_L(xi, yi, zi) raw(xo[xi], yo[yi], zo[zi], X[xi], Y[yi], Z[zi])
+#define VR_R(yi, zi) lerpf(VR_L(1, yi, zi), VR_L(2, yi, zi), a)   /* texels (x0, x1)   */
+#define VR_M(yi, zi) lerpf(VR_L(0, yi, zi), VR_L(1, yi, zi), a)   /* texels (x0-1, x0) */
+#define VR_P(yi, zi) lerpf(VR_L(2, yi, zi), VR_L(3, yi, zi), a)   /* texels (x1, x1+1) */
+        const float r01 = VR_R(0, 1), r11 = VR_R(1, 1), r21 = VR_R(2, 1), r31 = VR_R(3, 1);
+        const float r02 = VR_R(0, 2), r12 = VR_R(1, 2), r22 = VR_R(2, 2), r32 = VR_R(3, 2);
+        const float r10 = VR_R(1, 0), r20 = VR_R(2, 0), r13 = VR_R(1, 3), r23 = VR_R(2, 3);
+        f3 s1, s2;
+        s1.x = lerpf(lerpf(VR_M(1, 1), VR_M(2, 1), b), lerpf(VR_M(1, 2), VR_M(2, 2), b), c) * inv_max;
+        s2.x = lerpf(lerpf(VR_P(1, 1), VR_P(2, 1), b), lerpf(VR_P(1, 2), VR_P(2, 2), b), c) * inv_max;
+        s1.y = lerpf(lerpf(r01, r11, b), lerpf(r02, r12, b), c) * inv_max;
+        s2.y = lerpf(lerpf(r21, r31, b), lerpf(r22, r32, b), c) * inv_max;
+        s1.z = lerpf(lerpf(r10, r20, b), lerpf(r11, r21, b), c) * inv_max;
+        s2.z = lerpf(lerpf(r12, r22, b), lerpf(r13, r23, b), c) * inv_max;
+#undef VR_L
+#undef VR_R
+#undef VR_M
+#undef VR_P
+        f3 g = sub3(s2, s1);
+        f3 n = normalize3(g);
+        if (dot3(g, g) == 0.0f) n = mk3(0.57735f, 0.57735f, 0.57735f);
+        return neg3(n);
+    }
+
+    // read_imagef(vol, nearestSmp, pos).x -- normalised, CLAMP (border 0), NEAREST
+    VR_DEV float nearest(float px, float py, float pz) const
+    {
+        float fx = floorf(px * fw), fy = floorf(py * fh), fz = floorf(pz * fd);
+        if (!(fx >= 0.0f && fx <= (float)w1 && fy >= 0.0f && fy <= (float)h1 && fz >= 0.0f &&
+              fz <= (float)d1))
+            return 0.0f;
+        int x = (int)fx, y = (int)fy, z = (int)fz;
+        return raw(xoff(x), yoff(y), zoff(z), x, y, z) * inv_max;
+    }
+};
+
+// read_imagef(tffData, linearSmp, x) on the float4 table
+VR_DEV float4 tff_linear(const float4 *tff, int n, float x)
+{
+    float ub = x * (float)n - 0.5f;
+    float fl = floorf(ub);
+    float a = ub - fl;
+    int i = (int)fl;
+    int i0 = iclamp(i, 0, n - 1), i1 = iclamp(i + 1, 0, n - 1);
+    float4 t0 = tff[i0], t1 = tff[i1];
+    float4 r;
+    r.x = lerpf(t0.x, t1.x, a);
+    r.y = lerpf(t0.y, t1.y, a);
+    r.z = lerpf(t0.z, t1.z, a);
+    r.w = lerpf(t0.w, t1.w, a);
+    return r;
+}
+VR_DEV float tff_linear_alpha(const float4 *tff, int n, float x)
+{
+    float ub = x * (float)n - 0.5f;
+    float fl = floorf(ub);
+    float a = ub - fl;
+    int i = (int)fl;
+    int i0 = iclamp(i, 0, n - 1), i1 = iclamp(i + 1, 0, n - 1);
+    return lerpf(tff[i0].w, tff[i1].w, a);
+}
+
+// read_imageui(tffPrefix, nearestSmp, x).x -- border 0 outside [0, n-1]
+VR_DEV uint32_t prefix_nearest(const uint32_t *prefix, uint32_t n, float x)
+{
+    float fi = floorf(x * (float)n);
+    if (!(fi >= 0.0f && fi <= (float)(n - 1))) return 0u;
+    return prefix[(int)fi];
+}
+
+// The reference's per-brick skip test (volumeraycast.cl:777-787) on one (min,max) pair.
+VR_DEV bool skip_test(const TfView &tf, float mn, float mx)
+{
+    float alphaMax = tff_linear_alpha(tf.tff, (int)tf.tff_n, mx);
+    if (!(alphaMax < 1e-6f)) return false;
+    return prefix_nearest(tf.prefix, tf.prefix_n, mn) == prefix_nearest(tf.prefix, tf.prefix_n, mx);
+}
+
+// One bit per brick + one trailing word for out-of-range cells, which the reference reads
+// with undefined result and SURVEY A.6 defines as (min,max) = (0,0).
+template <typename VT>
+__global__ __launch_bounds__(kBlockDim) void vr_skipmap_kernel(BrickView b, float inv_max,
+                                                               TfView tf, uint32_t *bits,
+                                                               uint32_t n_words)
+{
+    const size_t n = (size_t)b.bw * b.bh * b.bd;
+    const size_t i = (size_t)blockIdx.x * kBlockDim + threadIdx.x;
+    bool s = false;
+    if (i < n) {
+        const VT *p = (const VT *)b.data;
+        s = skip_test(tf, (float)p[2 * i] * inv_max, (float)p[2 * i + 1] * inv_max);
+    }
+    unsigned long long m = __ballot(s);
+    if ((threadIdx.x & 63) == 0) {
+        size_t w = (i >> 6) * 2;
+        if (w < n_words) bits[w] = (uint32_t)m;
+        if (w + 1 < n_words) bits[w + 1] = (uint32_t)(m >> 32);
+    }
+    if (i == 0) bits[n_words] = skip_test(tf, 0.0f, 0.0f) ? 0xffffffffu : 0u;   // every bit
+}
+
+// ------------------------------------------------------------------ ray set-up
+
+struct Ray {
+    f3 cam, dir;
+    float env[4];
+    float rnd;
+    float tnear, tfar;
+    bool hit;
+};
+
+// volumeraycast.cl:605-683: RNG jitter, padded-grid NDC, view transform, background, bbox
+VR_DEV Ray make_ray(uint32_t gx, uint32_t gy, const FrameView &fr, const vrhip_camera_params &cam,
+                    const vrhip_rendering_params &rp)
+{
+    Ray r;
+    const float *V = cam.viewMat;
+    const f3 ms = mk3(rp.modelScale[0], rp.modelScale[1], rp.modelScale[2]);
+    r.rnd = (float)parallel_rng3(gx, gy, rp.seed) / 4294967296.0f;
+
+    float gsx = (float)fr.gsx, gsy = (float)fr.gsy;
+    float aspect = gsy / gsx;
+    aspect = vmin(aspect, gsx / gsy);
+    int maxImg = (int)(fr.gsx > fr.gsy ? fr.gsx : fr.gsy);
+    float icx = ((float)(int)gx / (float)maxImg) * 2.f;
+    float icy = ((float)(int)gy / (float)maxImg) * 2.f;
+    if (fr.gsx > fr.gsy) { icx -= 1.0f; icy -= aspect; }
+    else { icx -= aspect; icy -= 1.0f; }
+    icy *= -1.f;
+    float psx = 2.f / gsx, psy = 2.f / gsy;
+    float rnd2 = (float)parallel_rng3(gy, gx, 2u * rp.seed) / 4294967296.0f;
+    icx += rnd2 * psx;
+    icy += (-r.rnd) * psy;
+
+    f3 npp = mk3(icx, icy, -1.0f);
+    f3 rayDir = mk3(dot3(mk3(V[0], V[1], V[2]), npp), dot3(mk3(V[4], V[5], V[6]), npp),
+                    dot3(mk3(V[8], V[9], V[10]), npp));
+    f3 camPos = mul3(mk3(V[3], V[7], V[11]), ms);
+    if (cam.ortho) {
+        camPos = mk3(V[3], V[7], V[11]);
+        f3 vpx = mk3(V[0], V[4], V[8]);
+        f3 vpy = mk3(V[1], V[5], V[9]);
+        f3 vpz = mk3(V[2], V[6], V[10]);
+        rayDir = neg3(vpz);
+        npp = add3(add3(camPos, scale3(vpx, icx)), scale3(vpy, icy));
+        npp = scale3(npp, len3(camPos));
+        camPos = mul3(npp, ms);
+    }
+    rayDir = normalize3(mul3(rayDir, ms));
+    r.cam = camPos;
+    r.dir = rayDir;
+
+    float bgf = rp.useGradient ? (0.7f + 0.5f * rayDir.y) : 1.f;
+    for (int i = 0; i < 4; ++i) r.env[i] = rp.backgroundColor[i] * bgf;
+
+    // intersectBBox, volumeraycast.cl:122-142
+    float o[3] = {camPos.x, camPos.y, camPos.z}, d[3] = {rayDir.x, rayDir.y, rayDir.z};
+    float tmin[3], tmax[3];
+    for (int i = 0; i < 3; ++i) {
+        float inv = 1.0f / d[i];
+        float tbot = inv * (cam.bbox_bl[i] - o[i]);
+        float ttop = inv * (cam.bbox_tr[i] - o[i]);
+        tmin[i] = vmin(ttop, tbot);
+        tmax[i] = vmax(ttop, tbot);
+    }
+    r.tnear = vmax(vmax(tmin[0], tmin[1]), vmax(tmin[0], tmin[2]));
+    r.tfar = vmin(vmin(tmax[0], tmax[1]), vmin(tmax[0], tmax[2]));
+    r.hit = (r.tfar > r.tnear) && !(r.tfar < 0);
+    return r;
+}
+
+VR_DEV unsigned long long wave_sum(unsigned long long v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+
+} // namespace

@@ -71,7 +71,10 @@ struct vrhip_renderer {
     // work queue of 8x8 wave tiles (centre first) for the current frame/tile set
     WaveTile *queue_dev = nullptr;
     uint32_t queue_n = 0, queue_cap = 0;
-    uint32_t *queue_head = nullptr;
+    uint32_t *queue_head = nullptr;   // 4 control words: queue head, cont count, cont head, pad
+    ContRec *cont = nullptr;          // suspended rays of the two-phase march
+    size_t cont_cap = 0;
+    uint32_t round_budget = 16;       // phase-1 sample rounds per patch (0 = single phase)
     std::vector<uint32_t> queue_key;   // W, H, tile_w, tile_h, tile ids...
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evb0 = nullptr, evb1 = nullptr;
@@ -375,6 +378,15 @@ int ensure_queue(vrhip_renderer *r, uint32_t W, uint32_t H, uint32_t tile_w, uin
                             hipMemcpyHostToDevice));
     r->queue_n = (uint32_t)q.size();
     r->queue_key.swap(key);
+    // continuation buffer of the two-phase march: worst case every ray is suspended
+    const size_t need = q.size() * 64;
+    if (need > r->cont_cap) {
+        if (r->cont) VR_HIP(r, hipFree(r->cont));
+        r->cont = nullptr;
+        r->cont_cap = 0;
+        VR_HIP(r, hipMalloc((void **)&r->cont, need * sizeof(ContRec)));
+        r->cont_cap = need;
+    }
     return VRHIP_OK;
 }
 
@@ -400,6 +412,10 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
     a->frame.n_wave_tiles = r->queue_n;
     a->frame.out_stride = out_stride;
     a->frame.queue_head = r->queue_head;
+    a->frame.cont = r->cont;
+    a->frame.cont_count = r->queue_head + 1;
+    a->frame.cont_head = r->queue_head + 2;
+    a->frame.round_budget = r->cont ? r->round_budget : 0;
     a->frame.fb = r->fb;
     a->cam = r->cam;
     a->render = r->render;
@@ -415,7 +431,7 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
 int launch_timed(vrhip_renderer *r, const RaycastLaunch &a)
 {
     if (a.instr) VR_HIP(r, hipMemsetAsync(r->stats_dev, 0, sizeof(DevStats), r->stream));
-    VR_HIP(r, hipMemsetAsync(r->queue_head, 0, sizeof(uint32_t), r->stream));
+    VR_HIP(r, hipMemsetAsync(r->queue_head, 0, 4 * sizeof(uint32_t), r->stream));
     VR_HIP(r, hipEventRecord(r->ev0, r->stream));
     VR_HIP(r, vr_launch_raycast(a, r->stream));
     VR_HIP(r, hipEventRecord(r->ev1, r->stream));
@@ -469,7 +485,8 @@ int count_touched_impl(vrhip_renderer *r, uint32_t width, uint32_t height, uint3
                            hipMemcpyDeviceToDevice, r->stream);
     a.frame.fb = scratch;
     if (e == hipSuccess) e = hipMemsetAsync(r->stats_dev, 0, sizeof(DevStats), r->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(r->queue_head, 0, sizeof(uint32_t), r->stream);
+    a.frame.round_budget = 0;   // the traffic pass runs single-phase (no speculative touches)
+    if (e == hipSuccess) e = hipMemsetAsync(r->queue_head, 0, 4 * sizeof(uint32_t), r->stream);
     if (e == hipSuccess) e = vr_launch_raycast(a, r->stream);
     std::vector<uint32_t> host(words);
     if (e == hipSuccess)
@@ -515,12 +532,13 @@ int vrhip_create(int device_id, vrhip_renderer **out)
         (e = hipEventCreate(&r->evb0)) != hipSuccess ||
         (e = hipEventCreate(&r->evb1)) != hipSuccess ||
         (e = hipMalloc((void **)&r->stats_dev, sizeof(DevStats))) != hipSuccess ||
-        (e = hipMalloc((void **)&r->queue_head, sizeof(uint32_t))) != hipSuccess) {
+        (e = hipMalloc((void **)&r->queue_head, 4 * sizeof(uint32_t))) != hipSuccess) {
         std::string msg = std::string("ERROR: vrhip_create (") + hipGetErrorString(e) + ")";
         delete r;
         return fail(nullptr, VRHIP_ERR_HIP, msg);
     }
     r->stream = r->own_stream;
+    if (const char *b = getenv("VRHIP_ROUND_BUDGET")) r->round_budget = (uint32_t)atoi(b);   // tuning
     r->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     r->devname = std::string(prop.name) + " (" + prop.gcnArchName + ")";
     *out = r;
@@ -539,6 +557,7 @@ void vrhip_destroy(vrhip_renderer *r)
     if (r->stats_dev) (void)hipFree(r->stats_dev);
     if (r->queue_dev) (void)hipFree(r->queue_dev);
     if (r->queue_head) (void)hipFree(r->queue_head);
+    if (r->cont) (void)hipFree(r->cont);
     if (r->skip_bits) (void)hipFree(r->skip_bits);
     if (r->ev0) (void)hipEventDestroy(r->ev0);
     if (r->ev1) (void)hipEventDestroy(r->ev1);
