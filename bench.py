@@ -58,9 +58,10 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(vr, vol_host, bricks_host, tff, fmt, W, H, target_s, use_ess=True):
-    """Oracle (CPU restatement, OpenMP over rows) timed on a bounded sample of the same
-    frame: evenly spaced 8-row stripes, grown until ~target_s of CPU work."""
+def cpu_baseline(vr, vol_host, bricks_host, tff, fmt, W, H, target_s, seeds, use_ess=True):
+    """Oracle (CPU restatement: scalar fp32 C, OpenMP over 8-pixel row chunks) timed on whole
+    frames of the same workload -- the timed frames' own jitter seeds, one after the other --
+    until ~target_s seconds of CPU work have been spent (bounded: at most len(seeds) frames)."""
     from oracle import vro
     cam, rp, rc, pt = vr.params()
     ocam = vro.CameraParams.from_buffer_copy(bytes(cam))
@@ -69,37 +70,44 @@ def cpu_baseline(vr, vol_host, bricks_host, tff, fmt, W, H, target_s, use_ess=Tr
     opt = vro.PathtraceParams.from_buffer_copy(bytes(pt))
     prefix = vro.prefix_sum(tff)
     cores = host_cpu_share()
-    SH = 8   # stripe height (rows); the oracle parallelises over 8-pixel row chunks
-    done_rows, samples, secs = 0, 0, 0.0
-    n_stripes = 4
-    rows_seen = set()
-    passes = 0
-    while True:
-        ys = [(int((k + 0.5) * H / n_stripes) // SH) * SH for k in range(n_stripes)]
-        ys = [y for y in ys if y not in rows_seen and y + SH <= H]
-        for y in ys:
-            t0 = time.perf_counter()
-            _, st, _ = vro.render_tile(vol_host, fmt, tff, ocam, orp, orc, opt, use_ess=use_ess,
-                                       W=W, H=H, tile=(0, y, W, SH), bricks=bricks_host,
-                                       prefix=prefix, threads=cores)
-            secs += time.perf_counter() - t0
-            samples += st["samples_taken"]
-            rows_seen.add(y)
-            done_rows += SH
-            if secs >= target_s:
-                break
-        passes += 1
-        if secs >= target_s or n_stripes * SH >= H:
+    frames, samples, secs = 0, 0, 0.0
+    for seed in seeds:
+        orp.seed = seed
+        orp.iteration = 0
+        t0 = time.perf_counter()
+        _, st, _ = vro.render_tile(vol_host, fmt, tff, ocam, orp, orc, opt, use_ess=use_ess,
+                                   W=W, H=H, bricks=bricks_host, prefix=prefix, threads=cores)
+        secs += time.perf_counter() - t0
+        samples += st["samples_taken"]
+        frames += 1
+        if secs >= target_s:
             break
-        n_stripes *= 2
     return {
         "value": samples / secs / 1e6 if secs > 0 else 0.0,
         "unit": "Msamples/s",
         "cores": int(cores),
         "kind": "port",
-        "sample": "%d of %d image rows (%d-row stripes, evenly spaced) of the same frame and "
-                  "seed, %.1f s of CPU work, %d samples taken" % (done_rows, H, SH, secs, samples),
+        "fps": frames / secs if secs > 0 else 0.0,
+        "sample": "%d whole frames of the same workload (mt19937 jitter seeds continuing the timed frames' sequence), "
+                  "%.1f s of CPU work, %d samples taken" % (frames, secs, samples),
     }
+
+
+def pmc_traffic(workload):
+    """HBM bytes per ray-cast pass from the committed rocprofv3 --pmc passes of this same
+    command (profiles/<round>/pmc_traffic.json, written by tools/pmc_traffic.py): FETCH_SIZE and
+    WRITE_SIZE collected in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for gfx950.  None when no profile of this workload is committed."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json")),
+                       reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if workload in d:
+            return d[workload]
+    return None
 
 
 def host_cpu_share():
@@ -185,6 +193,7 @@ def main():
     wall = time.perf_counter() - t0
     gpu_region_s = ev0.elapsed_time(ev1) * 1e-3
     last_kernel_s = vr.getLastExecTime()
+    last_phases = vr.getLastPhaseTimes()
     wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
@@ -221,26 +230,38 @@ def main():
         st1 = vr.getStats()
         # B_frame = b*64*|micro-bricks touched| + 2b*|bricks visited| + 16 B per pixel written
         alg_bytes = b * 64 * mb + 2 * b * st1["bricks_visited"] + 16 * n_pix
+        # The ray-cast pass is ONE logical kernel issued as two back-to-back launches (phase 1:
+        # budgeted march of every ray; phase 2: the suspended long rays, 4 lanes per ray).  Its
+        # duration = HIP events over the timed region on the launch stream / K (world == 1; with
+        # the gather in the region at world > 1 the vrhip events of the last pass are used).
         kernel_s = gpu_region_s / args.steps if world == 1 else last_kernel_s
         achieved = alg_bytes / kernel_s / 1e9
+        traffic = pmc_traffic(args.workload) if world == 1 else None
         roofline = {
-            "kernel": "vr_raycast_kernel<%s, ESS=%s>" % (fmt_name.lower(), ess),
+            "kernel": "ray-cast pass = vr_raycast_kernel + vr_raycast_split_kernel <%s, ESS=%s>, "
+                      "two back-to-back launches per frame" % (fmt_name.lower(), ess),
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,   # PMC HBM bytes: profiles/ (separate rocprofv3 --pmc pass)
+            "traffic": traffic["hbm_bytes_per_pass"] if traffic else None,
+            "traffic_detail": traffic,
             "algorithmic_bytes_per_launch": int(alg_bytes),
             "avg_launch_ms": kernel_s * 1e3,
-            "last_launch_ms_hip_events": last_kernel_s * 1e3,
+            "last_pass_ms_hip_events": {"phase1": last_phases[0] * 1e3, "phase2": last_phases[1] * 1e3,
+                                        "total": last_kernel_s * 1e3},
             "request_bytes_per_launch": int(b * 8 * (st1["samples_taken"] +
                                                     6 * st1["samples_shaded"])),
+            "note": "not HBM-bound: a latency/issue-bound march (DESIGN.md 'Kernels'); the "
+                    "streaming kernel of the path is vr_build_bricks (see bricks_build)",
         }
         if world == 1 and not args.no_cpu_baseline:
             vol_host = vr.downloadVolume()
             bricks_host = vr.downloadBricks()
-            cpu = cpu_baseline(vr, vol_host, bricks_host, tff, fmt, W, H, args.cpu_seconds, use_ess=ess)
+            cpu_seeds = seeds[args.warmup:] + [mt() for _ in range(2000)]   # bounded by cpu_seconds
+            cpu = cpu_baseline(vr, vol_host, bricks_host, tff, fmt, W, H, args.cpu_seconds,
+                               cpu_seeds, use_ess=ess)
             del vol_host
 
     if rank == 0:

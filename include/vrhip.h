@@ -150,6 +150,9 @@ int vrhip_render_tiles(vrhip_renderer *r, uint32_t width, uint32_t height, uint3
 /* getLastExecTime (volumerendercl.cpp:1053-1056): HIP-event time of the last ray-cast
  * kernel launch, seconds. */
 double vrhip_last_kernel_seconds(const vrhip_renderer *r);
+/* The ray-cast pass is two back-to-back launches (budgeted march of every ray, then the
+ * suspended long rays with 4 lanes per ray): HIP-event seconds of each. */
+int vrhip_last_phase_seconds(const vrhip_renderer *r, double *phase1, double *phase2);
 
 /* ---- measurement helpers ------------------------------------------- */
 /* When enabled, render calls run the instrumented kernel variant that accumulates

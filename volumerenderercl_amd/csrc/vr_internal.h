@@ -104,6 +104,7 @@ struct RaycastLaunch {
     DevStats *stats;
     uint32_t *touched;
     int num_cus;
+    hipEvent_t mid_event;  // optional: recorded between the phase-1 and phase-2 launches
 };
 
 hipError_t vr_launch_raycast(const RaycastLaunch &a, hipStream_t stream);

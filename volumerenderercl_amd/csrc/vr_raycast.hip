@@ -648,6 +648,7 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
     hipLaunchKernelGGL(k1, grid, block, lds, stream, a.vol, a.bricks, a.tf, a.skip, a.frame, a.cam,
                        a.render, a.raycast, a.stats, a.touched);
     hipError_t e = hipGetLastError();
+    if (e == hipSuccess && a.mid_event) e = hipEventRecord(a.mid_event, stream);
     if (e != hipSuccess || a.frame.round_budget == 0) return e;
     // phase 2: persistent grid; exits at once when nothing was suspended
     dim3 grid2(cus * (uint32_t)nb2);

@@ -77,7 +77,7 @@ struct vrhip_renderer {
     uint32_t round_budget = 16;       // phase-1 sample rounds per patch (0 = single phase)
     std::vector<uint32_t> queue_key;   // W, H, tile_w, tile_h, tile ids...
 
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, evb0 = nullptr, evb1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr, evb0 = nullptr, evb1 = nullptr;
     bool timed = false, bricks_timed = false;
 
     vrhip_renderer()
@@ -433,7 +433,9 @@ int launch_timed(vrhip_renderer *r, const RaycastLaunch &a)
     if (a.instr) VR_HIP(r, hipMemsetAsync(r->stats_dev, 0, sizeof(DevStats), r->stream));
     VR_HIP(r, hipMemsetAsync(r->queue_head, 0, 4 * sizeof(uint32_t), r->stream));
     VR_HIP(r, hipEventRecord(r->ev0, r->stream));
-    VR_HIP(r, vr_launch_raycast(a, r->stream));
+    RaycastLaunch b = a;
+    b.mid_event = r->evm;
+    VR_HIP(r, vr_launch_raycast(b, r->stream));
     VR_HIP(r, hipEventRecord(r->ev1, r->stream));
     r->timed = true;
     return VRHIP_OK;
@@ -529,6 +531,7 @@ int vrhip_create(int device_id, vrhip_renderer **out)
         (e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&r->own_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&r->ev0)) != hipSuccess || (e = hipEventCreate(&r->ev1)) != hipSuccess ||
+        (e = hipEventCreate(&r->evm)) != hipSuccess ||
         (e = hipEventCreate(&r->evb0)) != hipSuccess ||
         (e = hipEventCreate(&r->evb1)) != hipSuccess ||
         (e = hipMalloc((void **)&r->stats_dev, sizeof(DevStats))) != hipSuccess ||
@@ -561,6 +564,7 @@ void vrhip_destroy(vrhip_renderer *r)
     if (r->skip_bits) (void)hipFree(r->skip_bits);
     if (r->ev0) (void)hipEventDestroy(r->ev0);
     if (r->ev1) (void)hipEventDestroy(r->ev1);
+    if (r->evm) (void)hipEventDestroy(r->evm);
     if (r->evb0) (void)hipEventDestroy(r->evb0);
     if (r->evb1) (void)hipEventDestroy(r->evb1);
     if (r->own_stream) (void)hipStreamDestroy(r->own_stream);
@@ -872,6 +876,18 @@ double vrhip_last_kernel_seconds(const vrhip_renderer *r)
     if (hipEventSynchronize(r->ev1) != hipSuccess) return 0.0;
     if (hipEventElapsedTime(&ms, r->ev0, r->ev1) != hipSuccess) return 0.0;
     return (double)ms * 1e-3;
+}
+
+int vrhip_last_phase_seconds(const vrhip_renderer *r, double *phase1, double *phase2)
+{
+    if (!r || !r->timed) return VRHIP_ERR_NODATA;
+    float a = 0.f, b = 0.f;
+    if (hipEventSynchronize(r->ev1) != hipSuccess) return VRHIP_ERR_HIP;
+    if (hipEventElapsedTime(&a, r->ev0, r->evm) != hipSuccess) return VRHIP_ERR_HIP;
+    if (hipEventElapsedTime(&b, r->evm, r->ev1) != hipSuccess) return VRHIP_ERR_HIP;
+    if (phase1) *phase1 = (double)a * 1e-3;
+    if (phase2) *phase2 = (double)b * 1e-3;
+    return VRHIP_OK;
 }
 
 int vrhip_set_stats_enabled(vrhip_renderer *r, int enabled)

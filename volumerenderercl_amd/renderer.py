@@ -350,6 +350,12 @@ class VolumeRenderCL:
     def getLastExecTime(self):
         return float(self._lib.vrhip_last_kernel_seconds(self._h))
 
+    def getLastPhaseTimes(self):
+        """(phase-1 seconds, phase-2 seconds) of the last ray-cast pass."""
+        a, b = C.c_double(), C.c_double()
+        self._check(self._lib.vrhip_last_phase_seconds(self._h, C.byref(a), C.byref(b)))
+        return float(a.value), float(b.value)
+
     # ---- test / bench conveniences (not in the reference)
     def setSeed(self, seed):
         """Pin the per-frame jitter seed (None restores the mt19937 sequence)."""
