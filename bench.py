@@ -38,6 +38,10 @@ WORKLOADS = {
     "sphere256": ("sphere", 256, "UCHAR", 1, "default", True),
     "sphere256_plain": ("sphere", 256, "UCHAR", 0, "default", False),
     "sphere64": ("sphere", 64, "UCHAR", 1, "default", True),    # CI-sized
+    # BASELINE config 5: Woodcock-tracking path tracer (technique 1); a step = one sample per
+    # pixel of the progressive render (iteration k of the running mean), 64 steps = 64 spp
+    "pt1024f": ("shells", 1024, "FLOAT", 1, "default", True, 1),
+    "pt256f": ("shells", 256, "FLOAT", 1, "default", True, 1),
 }
 FMT = {"UCHAR": 0, "USHORT": 1, "FLOAT": 2}
 FMT_BYTES = {"UCHAR": 1, "USHORT": 2, "FLOAT": 4}
@@ -143,7 +147,8 @@ def main():
     from volumerenderercl_amd import VolumeRenderCL, frontend
     from volumerenderercl_amd import tiles as vtiles
 
-    kind, res, fmt_name, illum, tff_name, ess = WORKLOADS[args.workload]
+    kind, res, fmt_name, illum, tff_name, ess = WORKLOADS[args.workload][:6]
+    technique = WORKLOADS[args.workload][6] if len(WORKLOADS[args.workload]) > 6 else 0
     fmt, b = FMT[fmt_name], FMT_BYTES[fmt_name]
     W = H = args.viewport
     tff = {"default": frontend.tff_from_stops, "haze": frontend.haze_tff,
@@ -158,6 +163,7 @@ def main():
     bricks_s = vr.lastBricksSeconds()
     vr.setIllumination(illum)
     vr.setObjEss(ess)
+    vr.setTechnique(technique)
     view = frontend.view_matrix() if args.view == "default" else frontend.view_matrix(
         frontend.quat_from_axis_angle((1, 1, 0), 30.0))
     vr.updateView(view)
@@ -170,9 +176,9 @@ def main():
     frame = torch.empty((H, W, 4), dtype=torch.float32, device=dev) if rank == 0 else None
     driver = vtiles.TileDriver(vr, split, dev)
 
-    def render(seed):
+    def render(seed, k=0):
         vr.setSeed(seed)
-        vr.setIteration(0)
+        vr.setIteration(k if technique == 1 else 0)   # path tracer: progressive running mean
         return driver.render_frame(frame)
 
     for k in range(args.warmup):
@@ -185,7 +191,7 @@ def main():
     t0 = time.perf_counter()
     ev0.record(stream)
     for k in range(args.steps):
-        render(seeds[args.warmup + k])
+        render(seeds[args.warmup + k], k)
     ev1.record(stream)
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -205,7 +211,7 @@ def main():
     names = ["samples_taken", "samples_nominal", "samples_shaded", "bricks_visited",
              "bricks_skipped", "rays_hit"]
     for k in range(args.steps):
-        render(seeds[args.warmup + k])
+        render(seeds[args.warmup + k], k)
         st = vr.getStats()
         tot += np.array([st[n] for n in names], dtype=np.int64)
     vr.setStatsEnabled(False)
@@ -238,7 +244,9 @@ def main():
         achieved = alg_bytes / kernel_s / 1e9
         traffic = pmc_traffic(args.workload) if world == 1 else None
         roofline = {
-            "kernel": "ray-cast pass = vr_raycast_kernel + vr_raycast_split_kernel <%s, ESS=%s>, "
+            "kernel": ("vr_pathtrace_kernel <%s>, one launch per sample-per-pixel pass" % fmt_name.lower())
+                      if technique == 1 else
+                      "ray-cast pass = vr_raycast_kernel + vr_raycast_split_kernel <%s, ESS=%s>, "
                       "two back-to-back launches per frame" % (fmt_name.lower(), ess),
             "bound": "hbm",
             "achieved": achieved,
@@ -266,8 +274,10 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "Msamples/s (samples taken, rays x steps after ESS/ERT) at %dx%d viewport, "
-                      "%d^3 %s" % (W, H, res, fmt_name),
+            "metric": ("Msamples/s (tracking steps taken, Woodcock path tracer, 1 spp per step) at %dx%d "
+                       "viewport, %d^3 %s" if technique == 1 else
+                       "Msamples/s (samples taken, rays x steps after ESS/ERT) at %dx%d viewport, "
+                       "%d^3 %s") % (W, H, res, fmt_name),
             "value": work["samples_taken"] / wall / 1e6,
             "unit": "Msamples/s",
             "n_gpus": world,
@@ -285,7 +295,9 @@ def main():
                             "%dx%d), view %s, TF %s, illumType %d, object-order ESS %s, ERT 0.98, "
                             "samplingRate 1.5, per-frame mt19937 jitter seeds"
                             % (args.workload, res, fmt_name, kind, W, H, W + (8 - W % 8),
-                               H + (8 - H % 8), args.view, tff_name, illum, "on" if ess else "off"),
+                               H + (8 - H % 8), args.view, tff_name, illum, "on" if ess else "off")
+                            + (" -- technique 1 (path tracer, max_extinction 100): illumType/ESS/ERT/"
+                               "samplingRate unused" if technique == 1 else ""),
                 "parallelism": "tiles%dx%d/%d ranks, volume replicated, RCCL gather" % (
                     args.tile, args.tile, world) if world > 1 else "single GPU, full frame",
             },

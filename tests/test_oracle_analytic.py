@@ -79,3 +79,46 @@ def test_tile_equals_full_frame_crop():
     full, _, _ = vro.render_tile(vol, vro.UCHAR, tff, cam, rp, rc, W=70, H=50)
     part, _, _ = vro.render_tile(vol, vro.UCHAR, tff, cam, rp, rc, W=70, H=50, tile=(16, 8, 33, 21))
     np.testing.assert_array_equal(part, full[8:29, 16:49])
+
+
+def test_pathtrace_empty_volume_gives_background():
+    """technique 1: zero opacity everywhere -> no walk ever accepts an interaction -> every
+    pixel that hits the box keeps the background colour with alpha 1 (volumeraycast.cl:
+    463-503 with isInteraction == false, :689-704)."""
+    vol = np.zeros((24, 24, 24), np.float32)
+    cam, rp, rc = _params(res=(24, 24, 24))
+    rp.technique = 1
+    img, st, _ = vro.render_tile(vol, vro.FLOAT, frontend.tff_from_stops(), cam, rp, rc,
+                                 pt=vro.PathtraceParams(50.0), W=48, H=40)
+    assert np.all(img[..., :3] == 1.0)
+    hit = img[..., 3] == 1.0          # misses carry the background alpha (1 here as well)
+    assert hit.all() and st["rays_hit"] > 0
+    # every primary walk runs until it leaves the box or for 513 steps, and is the only walk
+    assert st["rays_hit"] <= st["samples_taken"] <= 513 * st["rays_hit"]
+
+
+def test_pathtrace_opaque_volume_closed_form():
+    """technique 1, opacity 1 everywhere, TF colour (1, 0, 0): the primary walk accepts its
+    first step inside the box; the TF-opacity gradient is 0 -> the fallback normal with
+    |(-n, 0)| = 1 > 0.5 -> Phong branch; the shadow walk accepts its first step -> w = 0.6.
+    So G == B == 0.6 * 0.15 * spec and R - G = 0.6 * (0.15 + 0.7 * max(0, n.l))."""
+    vol = np.full((24, 24, 24), 0.5, np.float32)
+    tff = np.zeros((256, 4), np.uint8)
+    tff[:, 0] = 255
+    tff[:, 3] = 255
+    cam, rp, rc = _params(res=(24, 24, 24))
+    rp.technique = 1
+    rp.backgroundColor[:] = [0.25, 0.5, 0.75, 1.0]
+    img, st, _ = vro.render_tile(vol, vro.FLOAT, tff, cam, rp, rc, pt=vro.PathtraceParams(100.0),
+                                 W=64, H=64)
+    bg = np.array([0.25, 0.5, 0.75], np.float32)
+    traced = np.any(img[..., :3] != bg, axis=-1)
+    assert traced.sum() > 0.3 * traced.size
+    r, g, b = (img[..., i][traced].astype(np.float64) for i in range(3))
+    np.testing.assert_array_equal(g, b)
+    d = r - g
+    # w is 0.6 when the shadow walk interacts (its first step stays inside the box) else 1
+    assert np.all((d >= 0.6 * 0.15 - 1e-6) & (d <= 0.85 + 1e-6))
+    assert np.all(g <= 0.15 + 1e-6)
+    # 1 primary + 1 shadow step for interior hits; grazing rays leave the box on the first step
+    assert st["samples_taken"] <= 2 * st["rays_hit"]

@@ -108,6 +108,13 @@ struct RaycastLaunch {
 };
 
 hipError_t vr_launch_raycast(const RaycastLaunch &a, hipStream_t stream);
+// technique 1 (Woodcock-tracking path tracer), one sample per pixel; vr_pathtrace.hip
+hipError_t vr_launch_pathtrace(const RaycastLaunch &a, hipStream_t stream);
+// the frame launch for a.render.technique
+inline hipError_t vr_launch_frame(const RaycastLaunch &a, hipStream_t stream)
+{
+    return a.render.technique == 1 ? vr_launch_pathtrace(a, stream) : vr_launch_raycast(a, stream);
+}
 
 // skip bitmap from bricks + TF + prefix
 hipError_t vr_launch_skipmap(const BrickView &bricks, int format, float inv_max, const TfView &tf,

@@ -1,0 +1,379 @@
+// vr_pathtrace.hip -- the Woodcock-tracking path-tracing mode of the reference kernel
+// (/root/reference/src/kernel/volumeraycast.cl:686-706 with trace_volume :463-503,
+// sample_interaction :407-437, get_dir_phase_function :453-460, gradientCentralDiffTff
+// :181-206) for gfx950.
+//
+// One sample per pixel and launch; the caller accumulates over `iteration` (running mean in
+// the fp32 frame buffer, as the ray caster does).  A pixel is up to three tracking walks --
+// primary, optional scatter, shadow -- each a chain of up to 513 steps with a PER-CALL CONSTANT
+// stride and acceptance threshold (`rand2 = ParallelRNG(rand)` is loop-invariant, :423-424;
+// SURVEY A.8), so a walk is a strided march whose length differs wildly between neighbouring
+// pixels (exponentially distributed stride, uniformly distributed threshold).
+//
+// Execution design: persistent workgroups, transfer function in LDS, and LANE-LEVEL work
+// refill: every lane runs a small state machine (fetch pixel -> primary walk -> shade ->
+// scatter walk -> shadow walk -> write) and draws its next pixel as soon as its current one is
+// written, instead of waiting for the longest walk of an 8x8 patch.  Pixels are handed out in
+// blocks of 64 from the same centre-first queue of 8x8 patches the ray caster uses, so a wave
+// still works on neighbouring pixels most of the time.  Each round evaluates kPtBatch
+// consecutive tracking steps of the lane's walk as independent straight-line code (addresses
+// are clamped, so steps past the end of the walk are harmless speculation) and then resolves
+// the walk's sequential exit conditions in order: the per-pixel operation sequence is the
+// reference's.
+#include "vr_sampling.h"
+
+namespace {
+
+#ifndef VR_PT_BATCH
+#define VR_PT_BATCH 4
+#endif
+constexpr int kPtBatch = VR_PT_BATCH;
+
+enum : int { P_FETCH = 0, P_PRIMARY = 1, P_SCATTER = 2, P_SHADOW = 3, P_WRITE = 4, P_ENDED = 8 };
+#ifndef VR_PT_STAGE_MIN
+#define VR_PT_STAGE_MIN 16
+#endif
+// lanes that must wait for the (divergent) refill / shading code before it is worth running
+constexpr int kStageMin = VR_PT_STAGE_MIN;
+
+VR_DEV bool in_volume(f3 p)   // volumeraycast.cl:93-96
+{
+    return vmax(fabsf(p.x), vmax(fabsf(p.y), fabsf(p.z))) < 1.f;
+}
+
+// get_dir_phase_function, volumeraycast.cl:453-460
+VR_DEV f3 dir_phase_function(uint32_t rnd)
+{
+    const uint32_t rand2 = parallel_rng(rnd);
+    const float phi = (float)(2.0 * (double)3.14159274101257f) * map_uint_float(rand2);
+    const float cos_theta = 1.0f - 2.0f * map_uint_float(parallel_rng(rand2));
+    const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+    float s, c;
+    vr_sincosf(phi, &s, &c);
+    return mk3(c * sin_theta, s * sin_theta, cos_theta);
+}
+
+// gradientCentralDiffTff (:181-206), un-negated: xyz = normalised difference of the
+// TF opacities one texel either side, w = its length.
+template <typename VT, int INSTR>
+VR_DEV float4 gradient_tff(const Vol<VT, INSTR> &vol, const float4 *s_tff, int tffn, f3 p)
+{
+    const f3 off = mk3(1.0f / vol.fw, 1.0f / vol.fh, 1.0f / vol.fd);
+    f3 s1, s2;
+    s1.x = tff_linear_alpha(s_tff, tffn, vol.linear(p.x + (-off.x), p.y + 0.0f, p.z + 0.0f));
+    s1.y = tff_linear_alpha(s_tff, tffn, vol.linear(p.x + 0.0f, p.y + (-off.y), p.z + 0.0f));
+    s1.z = tff_linear_alpha(s_tff, tffn, vol.linear(p.x + 0.0f, p.y + 0.0f, p.z + (-off.z)));
+    s2.x = tff_linear_alpha(s_tff, tffn, vol.linear(p.x + off.x, p.y + 0.0f, p.z + 0.0f));
+    s2.y = tff_linear_alpha(s_tff, tffn, vol.linear(p.x + 0.0f, p.y + off.y, p.z + 0.0f));
+    s2.z = tff_linear_alpha(s_tff, tffn, vol.linear(p.x + 0.0f, p.y + 0.0f, p.z + off.z));
+    const f3 g = sub3(s2, s1);
+    f3 n = normalize3(g);
+    if (dot3(g, g) == 0.0f) n = mk3(0.57735f, 0.57735f, 0.57735f);
+    return make_float4(n.x, n.y, n.z, len3(g));
+}
+
+// illumination (:294-303) with specularBlinnPhong (:280-291)
+VR_DEV f3 illumination(f3 color, f3 toLightDir, f3 n)
+{
+    const f3 l = normalize3(toLightDir);
+    const float ndl = vmax(0.f, dot3(n, l));
+    f3 h = add3(toLightDir, l);
+    float sp = 0.0f;
+    if (!(dot3(h, h) < 1.e-6f)) {
+        h = normalize3(h);
+        sp = vr_powr(vmax(dot3(n, h), 0.f), 40.f);
+    }
+    sp = sp * 0.15f;
+    return mk3(((color.x * 0.15f) + ((color.x * ndl) * 0.7f)) + sp,
+               ((color.y * 0.15f) + ((color.y * ndl) * 0.7f)) + sp,
+               ((color.z * 0.15f) + ((color.z * ndl) * 0.7f)) + sp);
+}
+
+struct PtPixel {   // the pixel a lane is working on
+    uint32_t gx, gy, out_index;
+    uint32_t rnd;           // ParallelRNG3(x, y, seed), :688
+    float dt, thr;          // stride (log(1-u)/max_extinction) and acceptance threshold of every walk
+    float env0, env1, env2, env3;
+    f3 dir;                 // primary ray direction
+    f3 hit_pos;             // position of the primary interaction
+    float c0, c1, c2;       // colour carried through trace_volume
+    // current walk
+    f3 org, wdir;
+    float t;
+    uint32_t cnt;
+    // how it ended
+    bool accepted;
+    f3 apos;
+    float adens;
+};
+
+template <typename VT, int INSTR>
+__global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
+    VolView vv, TfView tf, FrameView fr, vrhip_camera_params cam, vrhip_rendering_params rp,
+    vrhip_pathtrace_params pt, DevStats *stats, uint32_t *touched)
+{
+    extern __shared__ float4 s_mem[];
+    float4 *s_tff = s_mem;
+    for (uint32_t i = threadIdx.x; i < tf.tff_n; i += kBlockDim) s_tff[i] = tf.tff[i];
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const int tffn = (int)tf.tff_n;
+    unsigned long long c_taken = 0, c_hit = 0;
+    Vol<VT, INSTR> vol;
+    vol.p = (const VT *)vv.data;
+    vol.w1 = vv.w - 1; vol.h1 = vv.h - 1; vol.d1 = vv.d - 1;
+    vol.fw = vv.fw; vol.fh = vv.fh; vol.fd = vv.fd;
+    vol.inv_max = vv.inv_max;
+    vol.nbx = vv.nbx; vol.nby = vv.nby;
+    vol.ystride = vv.ystride; vol.zstride = vv.zstride;
+    vol.touched = touched;
+    // the traffic-instrumented variant must not touch speculative voxels: one step per round
+    constexpr int B = INSTR == 2 ? 1 : kPtBatch;
+
+    PtPixel px = {};
+    int state = P_FETCH;
+    uint32_t patch_taken = 64;         // pixels of the current patch already handed out (wave-uniform)
+    bool drained = false;              // queue exhausted (wave-uniform)
+    WaveTile wt = {0, 0, 0};
+
+    // Exit condition reached by every wave: the queue head only grows, every walk ends after at
+    // most 513 steps, and the refill / transition stages run unconditionally once no lane walks.
+    for (;;) {
+        const unsigned long long walk_m = __ballot(state >= P_PRIMARY && state <= P_SHADOW);
+
+        // ---- stage 1: hand out pixels to idle lanes -- when enough lanes are idle to pay for the
+        //      ray set-up code, or when nothing else is left to do
+        unsigned long long idle = __ballot(state == P_FETCH);
+        if (!drained && idle && ((int)__builtin_popcountll(idle) >= kStageMin || !walk_m)) {
+            while (idle && !drained) {
+                if (patch_taken >= 64) {
+                    uint32_t q = 0;
+                    if (lane == 0) q = atomicAdd(fr.queue_head, 1u);
+                    q = __builtin_amdgcn_readfirstlane(q);
+                    if (q >= fr.n_wave_tiles) { drained = true; break; }
+                    patch_taken = 0;
+                    wt = fr.queue[q];
+                }
+                // the i-th idle lane takes pixel patch_taken + i of the patch
+                const uint32_t rank = (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
+                const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
+                const uint32_t avail = 64u - patch_taken;
+                const uint32_t n_take = n_idle < avail ? n_idle : avail;
+                if (state == P_FETCH && rank < n_take) {
+                    const uint32_t pi = patch_taken + rank;
+                    const uint32_t lx = pi & 7u, ly = pi >> 3;
+                    px.gx = (uint32_t)wt.tx8 * 8u + lx;
+                    px.gy = (uint32_t)wt.ty8 * 8u + ly;
+                    px.out_index = wt.out_base + ly * fr.out_stride + lx;
+                    // pixels outside the frame (ragged right / bottom patches) are dropped
+                    if (px.gx < fr.W && px.gy < fr.H) {
+                        const Ray ray = make_ray(px.gx, px.gy, fr, cam, rp);
+                        px.env0 = ray.env[0]; px.env1 = ray.env[1];
+                        px.env2 = ray.env[2]; px.env3 = ray.env[3];
+                        if (!ray.hit) {   // :677-683
+                            const float4 o = make_float4(px.env0, px.env1, px.env2, px.env3);
+                            fr.fb[(size_t)px.gy * fr.W + px.gx] = o;
+                            if (fr.out) fr.out[px.out_index] = o;
+                        } else {
+                            if (INSTR) c_hit++;
+                            px.rnd = parallel_rng3(px.gx, px.gy, rp.seed);   // :688
+                            const uint32_t rand2 = parallel_rng(px.rnd);     // :423
+                            px.dt = vr_logf(1.f - map_uint_float(rand2)) / pt.max_extinction;
+                            px.thr = map_uint_float(px.rnd);
+                            px.dir = ray.dir;
+                            px.c0 = px.env0; px.c1 = px.env1; px.c2 = px.env2;
+                            px.org = add3(ray.cam, scale3(ray.dir, ray.tnear));   // :473
+                            px.wdir = ray.dir;
+                            px.t = 0.f;
+                            px.cnt = 0;
+                            state = P_PRIMARY;
+                        }
+                    }
+                }
+                patch_taken += n_take;
+                idle = __ballot(state == P_FETCH);
+            }
+        }
+
+        // ---- stage 2: kPtBatch consecutive tracking steps of every walking lane (:419-431)
+        const bool walking = state >= P_PRIMARY && state <= P_SHADOW;
+        if (__ballot(walking)) {
+            float tk[B], dens[B], al[B];
+            f3 pk[B];
+            bool ink[B];
+            float tc = px.t;
+#pragma unroll
+            for (int k = 0; k < B; ++k) {
+                tc = tc - px.dt;
+                tk[k] = tc;
+                pk[k] = add3(px.org, scale3(px.wdir, tc));
+                ink[k] = in_volume(pk[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < B; ++k) {
+                dens[k] = 0.f;
+                if (INSTR != 2 || (walking && ink[k]))
+                    dens[k] = vol.linear(pk[k].x * 0.5f + 0.5f, pk[k].y * 0.5f + 0.5f,
+                                         pk[k].z * 0.5f + 0.5f);
+            }
+#pragma unroll
+            for (int k = 0; k < B; ++k) al[k] = tff_linear_alpha(s_tff, tffn, dens[k]);
+            // the walk's exit conditions, in step order
+            bool run = walking;
+#pragma unroll
+            for (int k = 0; k < B; ++k) {
+                if (run) {
+                    ++px.cnt;
+                    px.t = tk[k];
+                    if (!ink[k]) { run = false; px.accepted = false; }               // :426-427
+                    else {
+                        if (INSTR) c_taken++;
+                        if (px.cnt > 512) { run = false; px.accepted = false; }      // :430-431
+                        else if (!(al[k] < px.thr)) {                                // :432
+                            run = false;
+                            px.accepted = true;
+                            px.apos = pk[k];
+                            px.adens = dens[k];
+                        }
+                    }
+                }
+            }
+            if (walking && !run) state |= P_ENDED;
+        }
+
+        // ---- stage 3: trace_volume's control flow (:463-503) for lanes whose walk ended -- again
+        //      only when enough lanes wait, or no lane walks any more
+        const unsigned long long pend = __ballot((state & P_ENDED) != 0);
+        const unsigned long long still = __ballot(state >= P_PRIMARY && state <= P_SHADOW);
+        if (pend && ((int)__builtin_popcountll(pend) >= kStageMin || !still) && (state & P_ENDED)) {
+            const int ended = state & ~P_ENDED;
+            bool start_shadow = false;
+            if (ended == P_PRIMARY) {
+                if (!px.accepted) {
+                    state = P_WRITE;   // no interaction: the background colour, w = 1
+                } else {
+                    const float4 col = tff_linear(s_tff, tffn, px.adens);
+                    px.c0 = col.x; px.c1 = col.y; px.c2 = col.z;
+                    px.hit_pos = px.apos;
+                    const f3 sp = mk3(px.apos.x * 0.5f + 0.5f, px.apos.y * 0.5f + 0.5f,
+                                      px.apos.z * 0.5f + 0.5f);
+                    const float4 gq = gradient_tff<VT, INSTR>(vol, s_tff, tffn, sp);
+                    const float g0 = -gq.x, g1 = -gq.y, g2 = -gq.z, g3 = -gq.w;
+                    const float glen = sqrtf((((g0 * g0) + (g1 * g1)) + (g2 * g2)) + (g3 * g3));
+                    if (glen > 0.5f) {   // :483-486 high gradient: Phong
+                        const f3 light = add3(neg3(px.dir), mk3(0.5f, 0.5f, 0.f));
+                        const f3 c = illumination(mk3(px.c0, px.c1, px.c2), light, mk3(g0, g1, g2));
+                        px.c0 = c.x; px.c1 = c.y; px.c2 = c.z;
+                        start_shadow = true;
+                    } else {             // :487-494 low gradient: second scatter ray
+                        px.org = px.apos;
+                        px.wdir = dir_phase_function(px.rnd);
+                        px.t = 0.f;
+                        px.cnt = 0;
+                        state = P_SCATTER;
+                    }
+                }
+            } else if (ended == P_SCATTER) {
+                float s0 = px.env0, s1 = px.env1, s2 = px.env2;
+                if (px.accepted) {
+                    const float4 col = tff_linear(s_tff, tffn, px.adens);
+                    s0 = col.x; s1 = col.y; s2 = col.z;
+                }
+                px.c0 = px.c0 + (s0 - px.c0) * 0.5f;   // mix(color, scatterColor, 0.5f), :493
+                px.c1 = px.c1 + (s1 - px.c1) * 0.5f;
+                px.c2 = px.c2 + (s2 - px.c2) * 0.5f;
+                start_shadow = true;
+            } else {   // P_SHADOW
+                const float w = px.accepted ? 0.6f : 1.f;   // :497-499
+                px.c0 = px.c0 * w; px.c1 = px.c1 * w; px.c2 = px.c2 * w;
+                state = P_WRITE;
+            }
+            if (start_shadow) {   // :496-497 shadow ray towards the light, from the interaction
+                px.org = px.hit_pos;
+                px.wdir = add3(neg3(px.dir), mk3(0.5f, 0.5f, 0.f));
+                px.t = 0.f;
+                px.cnt = 0;
+                state = P_SHADOW;
+            }
+            if (state == P_WRITE) {    // :689-704 accumulate + write
+                const size_t fi = (size_t)px.gy * fr.W + px.gx;
+                float r0 = px.c0, r1 = px.c1, r2 = px.c2;
+                if (rp.iteration != 0) {
+                    const float4 prev = fr.fb[fi];
+                    const float it1 = (float)(rp.iteration + 1u);
+                    r0 = prev.x + (r0 - prev.x) / it1;
+                    r1 = prev.y + (r1 - prev.y) / it1;
+                    r2 = prev.z + (r2 - prev.z) / it1;
+                }
+                const float4 o = make_float4(r0, r1, r2, 1.f);
+                fr.fb[fi] = o;
+                if (fr.out) fr.out[px.out_index] = o;
+                state = P_FETCH;
+            }
+        }
+        if (drained && !__ballot(state != P_FETCH)) break;
+    }
+
+    if (INSTR) {
+        unsigned long long s = wave_sum(c_taken);
+        if (lane == 0 && s) atomicAdd(&stats->v[0], s);
+        s = wave_sum(c_hit);
+        if (lane == 0 && s) atomicAdd(&stats->v[5], s);
+    }
+}
+
+template <typename VT, int INSTR>
+hipError_t launch_pt(const RaycastLaunch &a, hipStream_t stream)
+{
+    auto k = vr_pathtrace_kernel<VT, INSTR>;
+    const size_t lds = (size_t)a.tf.tff_n * sizeof(float4);
+    static int nb = 0;
+    static size_t cached_lds = ~(size_t)0;
+    if (cached_lds != lds) {
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void *)k,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, kBlockDim, lds) != hipSuccess || nb < 1)
+            nb = 1;
+        if (const char *e = getenv("VRHIP_BLOCKS_PER_CU")) {
+            int v = atoi(e);
+            if (v > 0) nb = v;
+        }
+        if (getenv("VRHIP_DEBUG"))
+            fprintf(stderr, "[vrhip] pathtrace: lds=%zu B, blocks/CU=%d, CUs=%d\n", lds, nb, a.num_cus);
+        cached_lds = lds;
+    }
+    const uint32_t cus = (uint32_t)(a.num_cus > 0 ? a.num_cus : 256);
+    const uint32_t want = (a.frame.n_wave_tiles + 3u) / 4u;
+    const uint32_t cap = cus * (uint32_t)nb;
+    dim3 grid(want < cap ? want : cap), block(kBlockDim);
+    if (grid.x == 0) return hipSuccess;
+    hipLaunchKernelGGL(k, grid, block, lds, stream, a.vol, a.tf, a.frame, a.cam, a.render,
+                       a.pathtrace, a.stats, a.touched);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && a.mid_event) e = hipEventRecord(a.mid_event, stream);
+    return e;
+}
+
+template <typename VT>
+hipError_t launch_pt_typed(const RaycastLaunch &a, hipStream_t stream)
+{
+    if (a.instr == 0) return launch_pt<VT, 0>(a, stream);
+    if (a.instr == 1) return launch_pt<VT, 1>(a, stream);
+    return launch_pt<VT, 2>(a, stream);
+}
+
+} // namespace
+
+hipError_t vr_launch_pathtrace(const RaycastLaunch &a, hipStream_t stream)
+{
+    switch (a.format) {
+    case VRHIP_UCHAR: return launch_pt_typed<uint8_t>(a, stream);
+    case VRHIP_USHORT: return launch_pt_typed<uint16_t>(a, stream);
+    case VRHIP_FLOAT: return launch_pt_typed<float>(a, stream);
+    default: return hipErrorInvalidValue;
+    }
+}

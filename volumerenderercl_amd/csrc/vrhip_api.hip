@@ -296,13 +296,15 @@ int check_renderable(vrhip_renderer *r, uint32_t width, uint32_t height)
         VR_REQUIRE(r, r->prefix && r->prefix_n, VRHIP_ERR_NODATA,
                    "No transfer function prefix sum set.");
     }
-    VR_REQUIRE(r, r->render.illumType <= 1, VRHIP_ERR_UNSUPPORTED,
+    VR_REQUIRE(r, r->render.technique <= 1, VRHIP_ERR_INVALID, "Unknown rendering technique.");
+    // the path-tracing branch of the kernel returns before illumType is looked at (:686-706)
+    VR_REQUIRE(r, r->render.illumType <= 1 || r->render.technique == 1, VRHIP_ERR_UNSUPPORTED,
                "illumType 2-5 are outside the hot path (SURVEY 8f2).");
+    VR_REQUIRE(r, r->render.technique == 0 || r->pathtrace.max_extinction > 0.f, VRHIP_ERR_INVALID,
+               "max_extinction must be positive.");
     VR_REQUIRE(r, !r->render.imgEss && !r->render.showEss && !r->raycast.useAO,
                VRHIP_ERR_UNSUPPORTED,
                "image-order ESS / showEss / ambient occlusion are outside the hot path (SURVEY 8f).");
-    VR_REQUIRE(r, r->render.technique == 0, VRHIP_ERR_UNSUPPORTED,
-               "path tracing technique not available in this build.");
     return VRHIP_OK;
 }
 
@@ -435,7 +437,7 @@ int launch_timed(vrhip_renderer *r, const RaycastLaunch &a)
     VR_HIP(r, hipEventRecord(r->ev0, r->stream));
     RaycastLaunch b = a;
     b.mid_event = r->evm;
-    VR_HIP(r, vr_launch_raycast(b, r->stream));
+    VR_HIP(r, vr_launch_frame(b, r->stream));
     VR_HIP(r, hipEventRecord(r->ev1, r->stream));
     r->timed = true;
     return VRHIP_OK;
@@ -455,8 +457,10 @@ int prepare_render(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t 
     }
     rc = ensure_fb(r, width, height);
     if (rc) return rc;
-    rc = ensure_skipmap(r);
-    if (rc) return rc;
+    if (r->render.technique == 0) {
+        rc = ensure_skipmap(r);
+        if (rc) return rc;
+    }
     return ensure_queue(r, width, height, tile_w, tile_h, tile_ids, n_tiles);
 }
 
@@ -489,7 +493,7 @@ int count_touched_impl(vrhip_renderer *r, uint32_t width, uint32_t height, uint3
     if (e == hipSuccess) e = hipMemsetAsync(r->stats_dev, 0, sizeof(DevStats), r->stream);
     a.frame.round_budget = 0;   // the traffic pass runs single-phase (no speculative touches)
     if (e == hipSuccess) e = hipMemsetAsync(r->queue_head, 0, 4 * sizeof(uint32_t), r->stream);
-    if (e == hipSuccess) e = vr_launch_raycast(a, r->stream);
+    if (e == hipSuccess) e = vr_launch_frame(a, r->stream);
     std::vector<uint32_t> host(words);
     if (e == hipSuccess)
         e = hipMemcpyAsync(host.data(), bits, words * sizeof(uint32_t), hipMemcpyDeviceToHost,
