@@ -44,7 +44,7 @@ def _setup(vr, vol, fmt, tff, view, **kw):
     vr.setIteration(0)
 
 
-def _compare(vr, vol, fmt, tff, W, H, ess=True):
+def _compare(vr, vol, fmt, tff, W, H, ess=True, pathtrace=False):
     vr.setStatsEnabled(True)
     got = vr.runRaycastNoGL(W, H)
     gstats = vr.getStats()
@@ -54,6 +54,11 @@ def _compare(vr, vol, fmt, tff, W, H, ess=True):
     assert np.isfinite(got).all()
     assert diff.max() <= TOL, "max abs diff %.3g at %s" % (
         diff.max(), np.unravel_index(diff.argmax(), diff.shape))
+    if pathtrace:
+        # technique 1 reuses the two brick counters for its majorant-grid culling (steps whose
+        # bound was consulted / whose voxel fetch was skipped); the oracle has no such grid
+        assert gstats["bricks_skipped"] <= gstats["bricks_visited"] <= gstats["samples_taken"]
+        gstats = dict(gstats, bricks_visited=0, bricks_skipped=0)
     assert gstats == rstats
     return got, ref, gstats
 
@@ -107,7 +112,7 @@ def test_pathtrace_frame_matches_oracle(vr, fmt, res, size, view, tff, smooth, k
     vol = common.noise_volume(res, fmt, seed=11, smooth=smooth)
     table = common.tffs()[tff]
     _setup(vr, vol, fmt, table, common.views()[view], technique=1, **kw)
-    got, ref, stats = _compare(vr, vol, fmt, table, size[0], size[1])
+    got, ref, stats = _compare(vr, vol, fmt, table, size[0], size[1], pathtrace=True)
     assert stats["rays_hit"] > 0 and stats["samples_taken"] > stats["rays_hit"]
     assert np.ptp(ref[..., :3]) > 0.05   # something was traced
 
@@ -130,6 +135,32 @@ def test_pathtrace_accumulates_like_oracle(vr):
         ref, _, _ = common.oracle_frame(vr, vol, FLOAT, table, W, H, in_accum=ref)
         np.testing.assert_array_equal(got, ref)
     vr.setIteration(0)
+
+
+def test_pathtrace_culling_is_exact(vr, monkeypatch):
+    """The majorant grid only skips fetches that cannot change the walk: the image with and
+    without it is identical, and it does skip a large share of the fetches."""
+    vol = common.noise_volume((96, 80, 72), FLOAT, seed=21, smooth=True)
+    table = common.tffs()["default"]
+    W, H = 128, 96
+    _setup(vr, vol, FLOAT, table, common.views()["rot30"], technique=1)
+    vr.setStatsEnabled(True)
+    got = vr.runRaycastNoGL(W, H)
+    st = vr.getStats()
+    vr.setStatsEnabled(False)
+    assert st["bricks_visited"] == st["samples_taken"] and st["bricks_skipped"] > 0
+    monkeypatch.setenv("VRHIP_PT_NO_CULL", "1")
+    r2 = VolumeRenderCL()
+    r2.initialize()
+    try:
+        _setup(r2, vol, FLOAT, table, common.views()["rot30"], technique=1)
+        r2.setStatsEnabled(True)
+        plain = r2.runRaycastNoGL(W, H)
+        st2 = r2.getStats()
+    finally:
+        r2.close()
+    np.testing.assert_array_equal(got, plain)
+    assert st2["samples_taken"] == st["samples_taken"] and st2["bricks_skipped"] == 0
 
 
 def test_pathtrace_tiles_equal_full_frame(vr):

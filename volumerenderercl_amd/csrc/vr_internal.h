@@ -84,6 +84,17 @@ struct FrameView {
     uint32_t round_budget;
 };
 
+// Path tracer only: conservative upper bound of the transfer function's opacity over every
+// value a trilinear fetch can return inside a cell of 2^shift voxels per axis (the cell's voxels
+// plus the one-voxel halo on the high side).  A tracking step whose cell bound is below the
+// walk's acceptance threshold cannot be accepted, so its 8 voxel loads are skipped; the walk's
+// step sequence and result are unchanged (vr_pathtrace.hip).
+struct PtView {
+    const float *bound;    // cx * cy * cz floats, x fastest; nullptr = no culling
+    int cx, cy, cz;
+    int shift;
+};
+
 struct DevStats {
     unsigned long long v[6]; // order of vrhip_stats
 };
@@ -98,6 +109,7 @@ struct RaycastLaunch {
     vrhip_rendering_params render;
     vrhip_raycast_params raycast;
     vrhip_pathtrace_params pathtrace;
+    PtView pt;
     int format;            // vrhip_format
     int use_ess;
     int instr;             // 0 none, 1 stats, 2 stats + touched bitmap
@@ -110,6 +122,13 @@ struct RaycastLaunch {
 hipError_t vr_launch_raycast(const RaycastLaunch &a, hipStream_t stream);
 // technique 1 (Woodcock-tracking path tracer), one sample per pixel; vr_pathtrace.hip
 hipError_t vr_launch_pathtrace(const RaycastLaunch &a, hipStream_t stream);
+// path-tracer majorant grid: per-cell (min,max) of the raw voxel values incl. halo, then the
+// opacity bound from (min,max) + transfer function
+hipError_t vr_launch_pt_minmax(const VolView &vol, int format, const PtView &grid, float2 *minmax,
+                               hipStream_t stream);
+hipError_t vr_launch_pt_bound(const float2 *minmax, const PtView &grid, float inv_max,
+                              const TfView &tf, float *sparse_scratch, float *bound,
+                              hipStream_t stream);
 // the frame launch for a.render.technique
 inline hipError_t vr_launch_frame(const RaycastLaunch &a, hipStream_t stream)
 {

@@ -112,6 +112,17 @@ struct Vol {
         return lerpf(c0, c1, c) * inv_max;
     }
 
+    // index of the majorant-grid cell holding the low corner texel (x0, y0, z0) of linear()'s
+    // footprint: the fetch uses voxels x0..x0+1 etc., all inside that cell's halo'd extent
+    VR_DEV uint32_t cell_index(float px, float py, float pz, const PtView &g) const
+    {
+        const int x0 = iclamp((int)floorf(px * fw - 0.5f), 0, w1);
+        const int y0 = iclamp((int)floorf(py * fh - 0.5f), 0, h1);
+        const int z0 = iclamp((int)floorf(pz * fd - 0.5f), 0, d1);
+        return ((uint32_t)(z0 >> g.shift) * (uint32_t)g.cy + (uint32_t)(y0 >> g.shift)) *
+                   (uint32_t)g.cx + (uint32_t)(x0 >> g.shift);
+    }
+
     // -gradientCentralDiff(vol, pos).xyz (volumeraycast.cl:159-178, :814).  The six taps sit
     // exactly one texel from the centre sample (offset = 1/volRes, :162): they are evaluated
     // in texel space -- the centre's filter weights with indices shifted by -+1 and clamped to

@@ -18,6 +18,8 @@ namespace {
 struct VolumeSlot {
     void *dev = nullptr;      // dense x-fastest voxels
     void *bricks = nullptr;   // (min,max) grid
+    float2 *pt_minmax = nullptr;   // path tracer: per-cell (min,max) incl. halo, built on demand
+    bool pt_minmax_valid = false;
 };
 
 std::string g_create_error;
@@ -55,6 +57,14 @@ struct vrhip_renderer {
     uint32_t *skip_bits = nullptr;
     uint32_t skip_words = 0, skip_cap = 0;
     bool skip_dirty = true;
+
+    // path tracer: majorant grid (opacity bound per cell) of the current timestep + TF
+    PtView pt_grid = {nullptr, 0, 0, 0, 3};
+    float *pt_bound = nullptr;
+    float *pt_sparse = nullptr;    // 13 x 4096 floats of scratch for the TF range-max table
+    size_t pt_bound_cap = 0;
+    bool pt_dirty = true;
+    bool pt_cull = true;           // VRHIP_PT_NO_CULL=1 disables (experiments)
 
     vrhip_camera_params cam;
     vrhip_rendering_params render;
@@ -266,6 +276,8 @@ int prepare_slot(vrhip_renderer *r, const uint32_t res[3], int format, uint32_t 
     if (!s.dev) VR_HIP(r, hipMalloc(&s.dev, volume_alloc_bytes(r)));
     r->bricks_valid = false;
     r->skip_dirty = true;
+    r->pt_dirty = true;
+    s.pt_minmax_valid = false;
     *slot = &s;
     return VRHIP_OK;
 }
@@ -326,6 +338,47 @@ int ensure_skipmap(vrhip_renderer *r)
                                 inv_max_of(r->format), make_tf_view(r), r->skip_bits, words,
                                 r->stream));
     r->skip_dirty = false;
+    return VRHIP_OK;
+}
+
+// Path tracer: (re)build the majorant grid when the volume, the timestep or the TF changed.
+// Cells of 2^shift voxels per axis, at most 128 per axis.
+int ensure_pt_grid(vrhip_renderer *r)
+{
+    if (!r->pt_cull) {
+        r->pt_grid.bound = nullptr;
+        return VRHIP_OK;
+    }
+    if (!r->pt_dirty && r->pt_grid.bound) return VRHIP_OK;
+    VolumeSlot &s = r->vols[r->timestep];
+    uint32_t mres = std::max(r->res[0], std::max(r->res[1], r->res[2]));
+    int shift = 3;
+    while (((mres + (1u << shift) - 1) >> shift) > 128u) ++shift;
+    PtView g;
+    g.shift = shift;
+    g.cx = (int)((r->res[0] + (1u << shift) - 1) >> shift);
+    g.cy = (int)((r->res[1] + (1u << shift) - 1) >> shift);
+    g.cz = (int)((r->res[2] + (1u << shift) - 1) >> shift);
+    const size_t n_cells = (size_t)g.cx * g.cy * g.cz;
+    if (n_cells > r->pt_bound_cap) {
+        VR_HIP(r, hipStreamSynchronize(r->stream));
+        if (r->pt_bound) VR_HIP(r, hipFree(r->pt_bound));
+        r->pt_bound = nullptr;
+        r->pt_bound_cap = 0;
+        VR_HIP(r, hipMalloc((void **)&r->pt_bound, n_cells * sizeof(float)));
+        r->pt_bound_cap = n_cells;
+    }
+    if (!r->pt_sparse) VR_HIP(r, hipMalloc((void **)&r->pt_sparse, 13 * 4096 * sizeof(float)));
+    g.bound = r->pt_bound;
+    if (!s.pt_minmax) VR_HIP(r, hipMalloc((void **)&s.pt_minmax, n_cells * sizeof(float2)));
+    if (!s.pt_minmax_valid) {
+        VR_HIP(r, vr_launch_pt_minmax(make_vol_view(r, s.dev), r->format, g, s.pt_minmax, r->stream));
+        s.pt_minmax_valid = true;
+    }
+    VR_HIP(r, vr_launch_pt_bound(s.pt_minmax, g, inv_max_of(r->format), make_tf_view(r),
+                                 r->pt_sparse, r->pt_bound, r->stream));
+    r->pt_grid = g;
+    r->pt_dirty = false;
     return VRHIP_OK;
 }
 
@@ -423,6 +476,7 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
     a->render = r->render;
     a->raycast = r->raycast;
     a->pathtrace = r->pathtrace;
+    a->pt = r->pt_grid;
     a->format = r->format;
     a->use_ess = r->use_ess ? 1 : 0;
     a->instr = r->stats_enabled ? 1 : 0;
@@ -457,10 +511,8 @@ int prepare_render(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t 
     }
     rc = ensure_fb(r, width, height);
     if (rc) return rc;
-    if (r->render.technique == 0) {
-        rc = ensure_skipmap(r);
-        if (rc) return rc;
-    }
+    rc = r->render.technique == 0 ? ensure_skipmap(r) : ensure_pt_grid(r);
+    if (rc) return rc;
     return ensure_queue(r, width, height, tile_w, tile_h, tile_ids, n_tiles);
 }
 
@@ -546,6 +598,7 @@ int vrhip_create(int device_id, vrhip_renderer **out)
     }
     r->stream = r->own_stream;
     if (const char *b = getenv("VRHIP_ROUND_BUDGET")) r->round_budget = (uint32_t)atoi(b);   // tuning
+    if (getenv("VRHIP_PT_NO_CULL")) r->pt_cull = false;   // experiments: path tracer without the majorant grid
     r->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     r->devname = std::string(prop.name) + " (" + prop.gcnArchName + ")";
     *out = r;
@@ -566,6 +619,8 @@ void vrhip_destroy(vrhip_renderer *r)
     if (r->queue_head) (void)hipFree(r->queue_head);
     if (r->cont) (void)hipFree(r->cont);
     if (r->skip_bits) (void)hipFree(r->skip_bits);
+    if (r->pt_bound) (void)hipFree(r->pt_bound);
+    if (r->pt_sparse) (void)hipFree(r->pt_sparse);
     if (r->ev0) (void)hipEventDestroy(r->ev0);
     if (r->ev1) (void)hipEventDestroy(r->ev1);
     if (r->evm) (void)hipEventDestroy(r->evm);
@@ -656,10 +711,12 @@ int vrhip_clear_volumes(vrhip_renderer *r)
     for (VolumeSlot &s : r->vols) {
         if (s.dev) (void)hipFree(s.dev);
         if (s.bricks) (void)hipFree(s.bricks);
+        if (s.pt_minmax) (void)hipFree(s.pt_minmax);
     }
     r->vols.clear();
     r->bricks_valid = false;
     r->skip_dirty = true;
+    r->pt_dirty = true;
     r->format = -1;
     r->res[0] = r->res[1] = r->res[2] = 0;
     r->timestep = 0;
@@ -671,7 +728,7 @@ int vrhip_set_timestep(vrhip_renderer *r, uint32_t timestep)
     if (!r) return VRHIP_ERR_INVALID;
     // volumerendercl.cpp:1169-1170: silently ignored when out of range
     if (!r->vols.empty() && timestep >= r->vols.size()) return VRHIP_OK;
-    if (r->timestep != timestep) r->skip_dirty = true;
+    if (r->timestep != timestep) r->skip_dirty = r->pt_dirty = true;
     r->timestep = timestep;
     return VRHIP_OK;
 }
@@ -711,6 +768,7 @@ int vrhip_set_transfer_function(vrhip_renderer *r, const uint8_t *rgba8, uint32_
     }
     VR_HIP(r, hipMemcpy(r->tff, table.data(), n_entries * sizeof(float4), hipMemcpyHostToDevice));
     r->skip_dirty = true;
+    r->pt_dirty = true;
     return VRHIP_OK;
 }
 
@@ -729,6 +787,7 @@ int vrhip_set_tff_prefix_sum(vrhip_renderer *r, const uint32_t *prefix, uint32_t
     }
     VR_HIP(r, hipMemcpy(r->prefix, prefix, n * sizeof(uint32_t), hipMemcpyHostToDevice));
     r->skip_dirty = true;
+    r->pt_dirty = true;
     return VRHIP_OK;
 }
 
@@ -762,6 +821,7 @@ int vrhip_build_bricks(vrhip_renderer *r)
     r->bricks_valid = true;
     r->bricks_timed = true;
     r->skip_dirty = true;
+    r->pt_dirty = true;
     return VRHIP_OK;
 }
 
