@@ -137,6 +137,36 @@ def test_pathtrace_accumulates_like_oracle(vr):
     vr.setIteration(0)
 
 
+def test_empty_skipping_is_exact(vr, monkeypatch):
+    """Ray caster: stepping over runs of samples in empty cells (opacity exactly 0) leaves the
+    image and every work counter unchanged."""
+    vol = common.noise_volume((96, 80, 72), UCHAR, seed=22, smooth=True)
+    vol[vol < 90] = 0          # large exactly-empty regions next to structure
+    table = common.tffs()["default"]
+    W, H = 128, 96
+    outs = []
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("VRHIP_NO_EMPTY_SKIP", env)
+        r2 = VolumeRenderCL()
+        r2.initialize()
+        try:
+            for ess in (True, False):
+                _setup(r2, vol, UCHAR, table, common.views()["rot30"], ess=ess)
+                r2.setStatsEnabled(True)
+                outs.append((r2.runRaycastNoGL(W, H), r2.getStats()))
+            if not env:
+                r2.setIteration(0)
+                ref, rstats, _ = common.oracle_frame(r2, vol, UCHAR, table, W, H, use_ess=False)
+        finally:
+            r2.close()
+    for i in range(2):
+        np.testing.assert_array_equal(outs[i][0], outs[i + 2][0])
+        assert outs[i][1] == outs[i + 2][1]
+    np.testing.assert_array_equal(outs[1][0], ref)
+    assert outs[1][1] == rstats
+
+
 def test_pathtrace_culling_is_exact(vr, monkeypatch):
     """The majorant grid only skips fetches that cannot change the walk: the image with and
     without it is identical, and it does skip a large share of the fetches."""

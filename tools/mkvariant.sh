@@ -10,7 +10,7 @@ OBJ=$SRC/_obj/var_$NAME
 mkdir -p "$OBJ" "$ROOT/volumerenderercl_amd/_variants"
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Wno-unused-function"
 pids=()
-for f in vr_raycast vr_pathtrace vr_bricks vrhip_api; do
+for f in vr_raycast vr_pathtrace vr_cells vr_bricks vrhip_api; do
   /opt/rocm/bin/hipcc $FLAGS "$@" -c "$SRC/$f.hip" -o "$OBJ/$f.o" &
   pids+=($!)
 done

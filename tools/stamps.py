@@ -3,8 +3,8 @@
 
 Runs the diagnostic build of libvrhip (compiled with -DVR_STAMPS, selected through
 VRHIP_LIB_PATH) on a bench workload and prints the per-phase share of summed wave time.
-Stamps drain the memory queues, so read the SHARES, not the frame time.  Covers phase 1 only
-(run with VRHIP_ROUND_BUDGET=0 to see the single-phase march)."""
+Stamps drain the memory queues, so read the SHARES, not the frame time.  Both phases are reported
+(VRHIP_ROUND_BUDGET=0 gives the single-phase march)."""
 import ctypes as C
 import os
 import sys
@@ -18,7 +18,7 @@ import bench  # noqa: E402
 from volumerenderercl_amd import VolumeRenderCL, frontend  # noqa: E402
 
 PHASES = ["queue pop + tile load", "ray set-up", "DDA (brick steps)",
-          "batch evaluation (fetch, TF, shading, powr)", "-", "-",
+          "batch evaluation (fetch, TF, shading, powr)", "empty-run lookahead + skip", "-",
           "composite + transitions", "suspend / frame write", "LDS staging (block start)", "-",
           "rounds (count)", "tiles (count)", "wave lifetime"]
 
@@ -26,7 +26,7 @@ PHASES = ["queue pop + tile load", "ray set-up", "DDA (brick steps)",
 def main():
     wl = sys.argv[1] if len(sys.argv) > 1 else "shells2048"
     frames = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-    kind, res, fmt_name, illum, tff_name, ess = bench.WORKLOADS[wl]
+    kind, res, fmt_name, illum, tff_name, ess = bench.WORKLOADS[wl][:6]
     vr = VolumeRenderCL()
     vr.initialize()
     vr.synthVolume(kind, (res, res, res), bench.FMT[fmt_name])
@@ -39,7 +39,7 @@ def main():
     mt = frontend.Mt19937()
     dbg = vr.lib.vrhip_debug_stamps
     dbg.argtypes = [C.POINTER(C.c_uint64), C.c_int]
-    out = (C.c_uint64 * 16)()
+    out = (C.c_uint64 * 32)()
     vr.setSeed(mt())
     vr.runRaycast(1024, 1024)
     dbg(out, 1)
@@ -50,20 +50,23 @@ def main():
         vr.runRaycast(1024, 1024)
         ms.append(vr.getLastExecTime() * 1e3)
     dbg(out, 0)
-    total = float(out[12])
-    print("%s: %d frames, kernel %.3f ms/frame (stamped build), summed wave lifetime %.3g cycles"
-          % (wl, frames, sum(ms) / len(ms), total))
-    acc = 0.0
-    for i in range(9):
-        acc += out[i]
-        if PHASES[i] != "-":
-            print("  %-44s %6.2f %%" % (PHASES[i], 100.0 * out[i] / total))
-    print("  %-34s %6.2f %%" % ("(unattributed)", 100.0 * (total - acc) / total))
-    print("  DDA loop iterations/frame %.0f -> cycles per DDA iteration %.0f" % (
-        out[9] / frames, out[2] / max(out[9], 1)))
-    rounds, tiles = out[10] / frames, out[11] / frames
-    print("  rounds/frame %.0f  tiles/frame %.0f  cycles/round %.0f  cycles/tile %.0f" % (
-        rounds, tiles, total / frames / max(rounds, 1), total / frames / max(tiles, 1)))
+    print("%s: %d frames, kernel %.3f ms/frame (stamped build)" % (wl, frames, sum(ms) / len(ms)))
+    for name, base in (("phase 1", 0), ("phase 2", 16)):
+        o = [int(out[base + i]) for i in range(16)]
+        total = float(o[12])
+        if total <= 0:
+            continue
+        print(" %s: summed wave lifetime %.3g cycles" % (name, total))
+        acc = 0.0
+        for i in range(9):
+            acc += o[i]
+            if PHASES[i] != "-" and o[i]:
+                print("  %-44s %6.2f %%" % (PHASES[i], 100.0 * o[i] / total))
+        print("  %-44s %6.2f %%" % ("(unattributed)", 100.0 * (total - acc) / total))
+        rounds, tiles = o[10] / frames, o[11] / frames
+        print("  DDA iterations/frame %.0f (%.0f cycles each)  rounds/frame %.0f (%.0f cycles each)  "
+              "tiles|groups/frame %.0f" % (o[9] / frames, o[2] / max(o[9], 1), rounds,
+                                           total / frames / max(rounds, 1), tiles))
     vr.close()
 
 

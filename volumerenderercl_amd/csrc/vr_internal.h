@@ -84,13 +84,20 @@ struct FrameView {
     uint32_t round_budget;
 };
 
-// Path tracer only: conservative upper bound of the transfer function's opacity over every
-// value a trilinear fetch can return inside a cell of 2^shift voxels per axis (the cell's voxels
-// plus the one-voxel halo on the high side).  A tracking step whose cell bound is below the
-// walk's acceptance threshold cannot be accepted, so its 8 voxel loads are skipped; the walk's
-// step sequence and result are unchanged (vr_pathtrace.hip).
-struct PtView {
-    const float *bound;    // cx * cy * cz floats, x fastest; nullptr = no culling
+// Cell grid: the volume cut into cells of 2^shift voxels per axis.  For every cell the renderer
+// keeps (min, max) of the voxels a trilinear fetch whose low-corner texel lies in the cell -- or
+// within one texel of it -- can read: voxels [(c << shift) - 1, ((c + 1) << shift) + 1] per axis.
+// Combined with the transfer function this gives, per cell (vr_cells.hip):
+//  * bound: an upper bound of the opacity any such fetch can map to.  Path tracer: a tracking
+//    step whose bound is below the walk's acceptance threshold cannot be accepted, so its voxel
+//    loads are skipped.
+//  * empty: 1 bit, set when that opacity is exactly 0.  Ray caster: such a sample composites to
+//    exactly nothing (volumeraycast.cl:864-879 with alpha == 0), so runs of them are stepped over
+//    with the reference's own t sequence and without touching the volume.
+// Neither changes any pixel: both only skip work whose result is known.
+struct CellView {
+    const float *bound;     // cx * cy * cz floats, x fastest; nullptr = feature off
+    const uint32_t *empty;  // 1 bit per cell, same order; nullptr = feature off
     int cx, cy, cz;
     int shift;
 };
@@ -109,7 +116,7 @@ struct RaycastLaunch {
     vrhip_rendering_params render;
     vrhip_raycast_params raycast;
     vrhip_pathtrace_params pathtrace;
-    PtView pt;
+    CellView cells;
     int format;            // vrhip_format
     int use_ess;
     int instr;             // 0 none, 1 stats, 2 stats + touched bitmap
@@ -122,13 +129,13 @@ struct RaycastLaunch {
 hipError_t vr_launch_raycast(const RaycastLaunch &a, hipStream_t stream);
 // technique 1 (Woodcock-tracking path tracer), one sample per pixel; vr_pathtrace.hip
 hipError_t vr_launch_pathtrace(const RaycastLaunch &a, hipStream_t stream);
-// path-tracer majorant grid: per-cell (min,max) of the raw voxel values incl. halo, then the
-// opacity bound from (min,max) + transfer function
-hipError_t vr_launch_pt_minmax(const VolView &vol, int format, const PtView &grid, float2 *minmax,
-                               hipStream_t stream);
-hipError_t vr_launch_pt_bound(const float2 *minmax, const PtView &grid, float inv_max,
-                              const TfView &tf, float *sparse_scratch, float *bound,
-                              hipStream_t stream);
+// cell grid (vr_cells.hip): per-cell (min,max) of the raw voxel values incl. halo; then opacity
+// bound + empty bit from (min,max) and the transfer function.  sparse_scratch: 13 * 4096 floats.
+hipError_t vr_launch_cell_minmax(const VolView &vol, int format, const CellView &grid,
+                                 float2 *minmax, hipStream_t stream);
+hipError_t vr_launch_cell_bounds(const float2 *minmax, const CellView &grid, float inv_max,
+                                 const TfView &tf, float *sparse_scratch, float *bound,
+                                 uint32_t *empty_bits, hipStream_t stream);
 // the frame launch for a.render.technique
 inline hipError_t vr_launch_frame(const RaycastLaunch &a, hipStream_t stream)
 {

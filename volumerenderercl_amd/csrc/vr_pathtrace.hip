@@ -109,7 +109,7 @@ struct PtPixel {   // the pixel a lane is working on
 
 template <typename VT, int INSTR>
 __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
-    VolView vv, TfView tf, PtView grid, FrameView fr, vrhip_camera_params cam,
+    VolView vv, TfView tf, CellView grid, FrameView fr, vrhip_camera_params cam,
     vrhip_rendering_params rp, vrhip_pathtrace_params pt, DevStats *stats, uint32_t *touched)
 {
     extern __shared__ float4 s_mem[];
@@ -341,94 +341,6 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
     }
 }
 
-// ------------------------------------------------------------------ majorant grid
-
-// (min, max) of the raw voxel values of every cell incl. its one-voxel halo on the high side:
-// voxels [c << s, (c + 1) << s] per axis, clamped to the volume.  One wave per cell.
-template <typename VT>
-__global__ __launch_bounds__(kBlockDim) void vr_pt_minmax_kernel(VolView vv, PtView grid,
-                                                                 float2 *out)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    const size_t n_cells = (size_t)grid.cx * grid.cy * grid.cz;
-    const size_t cell = (size_t)blockIdx.x * (kBlockDim / 64) + (threadIdx.x >> 6);
-    if (cell >= n_cells) return;
-    const int cxi = (int)(cell % (size_t)grid.cx);
-    const int cyi = (int)((cell / (size_t)grid.cx) % (size_t)grid.cy);
-    const int czi = (int)(cell / ((size_t)grid.cx * grid.cy));
-    const int n = (1 << grid.shift) + 1;
-    const int x0 = cxi << grid.shift, y0 = cyi << grid.shift, z0 = czi << grid.shift;
-    const VT *p = (const VT *)vv.data;
-    float mn = __builtin_inff(), mx = -__builtin_inff();
-    bool bad = false;
-    for (int dz = 0; dz < n; ++dz) {
-        const int z = min(z0 + dz, vv.d - 1);
-        for (int i = (int)lane; i < n * n; i += 64) {
-            const int dy = i / n, dx = i - dy * n;
-            const int x = min(x0 + dx, vv.w - 1), y = min(y0 + dy, vv.h - 1);
-            const float v = (float)p[vr_voxel_index(vv, x, y, z)];
-            bad = bad || !(v == v);
-            mn = v < mn ? v : mn;
-            mx = v > mx ? v : mx;
-        }
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        const float omn = __shfl_down(mn, off, 64), omx = __shfl_down(mx, off, 64);
-        mn = omn < mn ? omn : mn;
-        mx = omx > mx ? omx : mx;
-    }
-    const bool any_bad = __ballot(bad) != 0ull;
-    if (lane == 0) out[cell] = any_bad ? make_float2(1.f, 0.f) /* min > max: never cull */
-                                       : make_float2(mn, mx);
-}
-
-constexpr int kSparseLevels = 13;   // 2^12 = 4096 >= max transfer function entries
-
-// sparse table of the TF opacity for O(1) range maxima: T[j][i] = max(alpha[i .. i + 2^j - 1])
-__global__ __launch_bounds__(kBlockDim) void vr_pt_sparse_kernel(TfView tf, float *T)
-{
-    const int n = (int)tf.tff_n;
-    for (int i = threadIdx.x; i < n; i += kBlockDim) T[i] = tf.tff[i].w;
-    for (int j = 1; j < kSparseLevels; ++j) {
-        __syncthreads();
-        const float *prev = T + (size_t)(j - 1) * n;
-        float *cur = T + (size_t)j * n;
-        const int half = 1 << (j - 1);
-        for (int i = threadIdx.x; i < n; i += kBlockDim) {
-            const float a = prev[i], b = prev[min(i + half, n - 1)];
-            cur[i] = a < b ? b : a;
-        }
-    }
-}
-
-// Opacity bound of every cell.  A trilinear fetch returns a value within [min, max] of the
-// cell's voxels up to a few ulps; the TF lookup (tff_linear_alpha) interpolates two adjacent
-// entries, so its result is at most the larger of them up to an ulp.  One extra table entry on
-// either side and a relative margin of 1e-6 (8 ulps) cover both roundings.
-__global__ __launch_bounds__(kBlockDim) void vr_pt_bound_kernel(const float2 *minmax, size_t n_cells,
-                                                                float inv_max, int n,
-                                                                const float *T, float *bound)
-{
-    const size_t c = (size_t)blockIdx.x * kBlockDim + threadIdx.x;
-    if (c >= n_cells) return;
-    const float2 mm = minmax[c];
-    float b = 2.0f;   // above every threshold: never cull
-    if (mm.x <= mm.y) {
-        const float fn = (float)n;
-        float flo = floorf((mm.x * inv_max) * fn - 0.5f) - 1.0f;
-        float fhi = floorf((mm.y * inv_max) * fn - 0.5f) + 2.0f;
-        flo = vclamp(flo, 0.0f, fn - 1.0f);
-        fhi = vclamp(fhi, 0.0f, fn - 1.0f);
-        const int lo = (int)flo, hi = (int)fhi;
-        if (lo <= hi) {
-            const int k = 31 - __clz(hi - lo + 1);
-            const float a = T[(size_t)k * n + lo], d = T[(size_t)k * n + (hi - (1 << k) + 1)];
-            b = (a < d ? d : a) * 1.000001f;
-        }
-    }
-    bound[c] = b;
-}
-
 template <typename VT, int INSTR>
 hipError_t launch_pt(const RaycastLaunch &a, hipStream_t stream)
 {
@@ -457,7 +369,7 @@ hipError_t launch_pt(const RaycastLaunch &a, hipStream_t stream)
     const uint32_t cap = cus * (uint32_t)nb;
     dim3 grid(want < cap ? want : cap), block(kBlockDim);
     if (grid.x == 0) return hipSuccess;
-    hipLaunchKernelGGL(k, grid, block, lds, stream, a.vol, a.tf, a.pt, a.frame, a.cam, a.render,
+    hipLaunchKernelGGL(k, grid, block, lds, stream, a.vol, a.tf, a.cells, a.frame, a.cam, a.render,
                        a.pathtrace, a.stats, a.touched);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && a.mid_event) e = hipEventRecord(a.mid_event, stream);
@@ -482,40 +394,4 @@ hipError_t vr_launch_pathtrace(const RaycastLaunch &a, hipStream_t stream)
     case VRHIP_FLOAT: return launch_pt_typed<float>(a, stream);
     default: return hipErrorInvalidValue;
     }
-}
-
-hipError_t vr_launch_pt_minmax(const VolView &vol, int format, const PtView &grid, float2 *minmax,
-                               hipStream_t stream)
-{
-    const size_t n_cells = (size_t)grid.cx * grid.cy * grid.cz;
-    const size_t per_block = kBlockDim / 64;
-    dim3 g((unsigned)((n_cells + per_block - 1) / per_block)), block(kBlockDim);
-    switch (format) {
-    case VRHIP_UCHAR:
-        hipLaunchKernelGGL(vr_pt_minmax_kernel<uint8_t>, g, block, 0, stream, vol, grid, minmax);
-        break;
-    case VRHIP_USHORT:
-        hipLaunchKernelGGL(vr_pt_minmax_kernel<uint16_t>, g, block, 0, stream, vol, grid, minmax);
-        break;
-    case VRHIP_FLOAT:
-        hipLaunchKernelGGL(vr_pt_minmax_kernel<float>, g, block, 0, stream, vol, grid, minmax);
-        break;
-    default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
-
-// sparse_scratch: kSparseLevels * tf.tff_n floats
-hipError_t vr_launch_pt_bound(const float2 *minmax, const PtView &grid, float inv_max,
-                              const TfView &tf, float *sparse_scratch, float *bound,
-                              hipStream_t stream)
-{
-    hipLaunchKernelGGL(vr_pt_sparse_kernel, dim3(1), dim3(kBlockDim), 0, stream, tf, sparse_scratch);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    const size_t n_cells = (size_t)grid.cx * grid.cy * grid.cz;
-    dim3 g((unsigned)((n_cells + kBlockDim - 1) / kBlockDim)), block(kBlockDim);
-    hipLaunchKernelGGL(vr_pt_bound_kernel, g, block, 0, stream, minmax, n_cells, inv_max,
-                       (int)tf.tff_n, (const float *)sparse_scratch, bound);
-    return hipGetLastError();
 }

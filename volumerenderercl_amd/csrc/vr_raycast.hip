@@ -30,6 +30,13 @@ namespace {
 
 constexpr int kSplit = 4;            // lanes per ray in phase 2 (x kBatch samples per lane)
 
+// Occupancy experiments: -DVR_WAVES_PER_EU=N asks the compiler to fit N waves per SIMD
+#ifdef VR_WAVES_PER_EU
+#define VR_OCC __attribute__((amdgpu_waves_per_eu(VR_WAVES_PER_EU, VR_WAVES_PER_EU)))
+#else
+#define VR_OCC
+#endif
+
 struct RayCtx {   // per-ray invariants, recomputable from the pixel
     f3 cam, dir;
     float env0, env1, env2, env3;
@@ -49,7 +56,15 @@ struct RayDyn {   // marching state
     int c0, c1, c2;
     float tv0, tv1, tv2;
     uint32_t cidx, skw;   // linear index of the current brick cell and its bitmap word
+#ifdef VR_RAYLEN          // diagnostic build: samples taken by the ray, written to the alpha channel
+    uint32_t nsmp;
+#endif
 };
+#ifdef VR_RAYLEN
+#define VR_RAYLEN_INC(d) ((d).nsmp++)
+#else
+#define VR_RAYLEN_INC(d)
+#endif
 
 struct Grid {     // wave-uniform brick-grid constants
     int bw, bh, bd;
@@ -88,6 +103,9 @@ VR_DEV void setup_ray(uint32_t gx, uint32_t gy, bool inside, const FrameView &fr
     d.c0 = d.c1 = d.c2 = 0;
     d.tv0 = d.tv1 = d.tv2 = 0.f;
     d.cidx = 0; d.skw = 0;
+#ifdef VR_RAYLEN
+    d.nsmp = 0;
+#endif
     if (c.valid) {
         // volumeraycast.cl:709-733
         float stepSize = vmin(c.sampleDist,
@@ -179,17 +197,34 @@ VR_DEV void after_segment(const RayCtx &c, RayDyn &d)
     }
 }
 
+// LDS staging of the gathered sample evaluation (eval_batch): one slot per sample of a wave's
+// round (64 lanes x kBatch samples), for each of the 4 waves of a workgroup
+constexpr int kSlotFloats = 5;   // in: pos.xyz, opacity, owner|flags   out: ndl, spec, contour, op
+constexpr int kStageFloatsPerWave = 64 * kBatch * kSlotFloats;
+constexpr int kStageF4 = (kBlockDim / 64) * kStageFloatsPerWave / 4;   // float4 units, whole workgroup
+
 // Up to kBatch consecutive samples of one ray (inner loop, :790-864): for each, the colour
 // already multiplied by the sample's opacity and the opacity.  Neither depends on the running
 // alpha, so the batch is independent straight-line code (the loads of all its fetches are in
 // flight together) and only the cheap front-to-back compositing is sequential.  Samples past
 // ERT / t_exit are speculative: fetched from clamped (always valid) addresses, never composited.
+//
+// The kernel is bound by VALU issue, and the expensive part of a sample -- opacity correction
+// (powr), and for samples above the shading threshold the gradient (32 voxel loads), the
+// Blinn-Phong terms and a second powr -- only matters for samples whose opacity is not 0:
+// often a few per cent of them, scattered over lanes and batch slots.  Under per-slot divergent
+// branches that code would run up to kBatch times per round for a handful of lanes each.
+// Instead the wave GATHERS its non-zero samples into LDS slots, evaluates the expensive scalars
+// over the dense slot list (usually one pass over the active lanes; per-ray constants come from
+// the owner lane by ds_bpermute) and hands four scalars per sample back.  Every sample sees the
+// same fp32 operations as before, in another lane.
 template <typename VT, int INSTR>
-VR_DEV void eval_batch(const Vol<VT, INSTR> &vol, const float4 *s_tff, int tffn, const RayCtx &c,
-                       const vrhip_rendering_params &rp, const vrhip_raycast_params &rcp,
-                       float refInterval, const float (&tk)[kBatch], const bool (&vk)[kBatch],
-                       float (&p0)[kBatch], float (&p1)[kBatch], float (&p2)[kBatch],
-                       float (&op)[kBatch], bool (&shaded)[kBatch])
+VR_DEV void eval_batch(const Vol<VT, INSTR> &vol, const float4 *s_tff, int tffn, float *s_stage,
+                       const RayCtx &c, const vrhip_rendering_params &rp,
+                       const vrhip_raycast_params &rcp, float refInterval,
+                       const float (&tk)[kBatch], const bool (&vk)[kBatch], float (&p0)[kBatch],
+                       float (&p1)[kBatch], float (&p2)[kBatch], float (&op)[kBatch],
+                       bool (&shaded)[kBatch])
 {
     f3 pk[kBatch];
     float dens[kBatch];
@@ -211,50 +246,184 @@ VR_DEV void eval_batch(const Vol<VT, INSTR> &vol, const float4 *s_tff, int tffn,
     float4 tfc[kBatch];
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) tfc[k] = tff_linear(s_tff, tffn, dens[k]);
+
+    // ---- which samples need the expensive part, and their slots
+    const bool want_grad = rp.illumType == 1 || (rcp.contours && !rp.illumType);
+    const uint32_t lane = threadIdx.x & 63u;
+    bool lit[kBatch], need[kBatch];
+    uint32_t slot[kBatch];
+    uint32_t n_slots = 0;
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
-        f3 grad = mk3(0.f, 0.f, 0.f);
-        const bool lit = vk[k] && tfc[k].w > 0.1f;
-        shaded[k] = lit && rp.illumType == 1;
-        if (lit && (rp.illumType == 1 || (rcp.contours && !rp.illumType)))
-            grad = vol.neg_gradient(pk[k].x, pk[k].y, pk[k].z);
-        if (lit && rp.illumType == 1) {
-            // illumination (:294-303)
-            float ndl = vmax(0.f, dot3(grad, c.lgt));
-            float sp = c.hvalid ? vr_powr(vmax(dot3(grad, c.hv), 0.f), 40.f) : 0.0f;
-            sp = sp * 0.15f;
-            tfc[k].x = ((tfc[k].x * 0.15f) + ((tfc[k].x * ndl) * 0.7f)) + sp;
-            tfc[k].y = ((tfc[k].y * 0.15f) + ((tfc[k].y * ndl) * 0.7f)) + sp;
-            tfc[k].z = ((tfc[k].z * 0.15f) + ((tfc[k].z * ndl) * 0.7f)) + sp;
+        lit[k] = vk[k] && tfc[k].w > 0.1f;                    // :812, before the depth cue
+        shaded[k] = lit[k] && rp.illumType == 1;
+        if (rcp.aerial) {                                     // :858-862
+            float depthCue = 1.f - (tk[k] - c.tnear) / c.sampleDist;
+            tfc[k].w *= depthCue;
         }
-        if (lit && rcp.contours) {
-            float e = fabsf(dot3(c.dir, grad));
-            tfc[k].x *= e; tfc[k].y *= e; tfc[k].z *= e;
+        // opacity 0 gives op = 1 - powr(1, y) = 0 exactly: nothing of the sample survives
+        need[k] = vk[k] && tfc[k].w != 0.f;
+        const unsigned long long m = __ballot(need[k]);
+        slot[k] = n_slots + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        n_slots += (uint32_t)__builtin_popcountll(m);
+    }
+    float ndl[kBatch], spc[kBatch], cnt[kBatch];
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) { ndl[k] = 0.f; spc[k] = 0.f; cnt[k] = 0.f; op[k] = 0.f; }
+
+    if (n_slots) {   // wave-uniform
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+            if (need[k]) {
+                float *q = s_stage + kSlotFloats * slot[k];
+                q[0] = pk[k].x; q[1] = pk[k].y; q[2] = pk[k].z;
+                q[3] = tfc[k].w;
+                q[4] = __uint_as_float(lane | ((lit[k] && want_grad) ? 64u : 0u));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // only the lanes inside this (divergent) call can work: slots go to them by rank
+        const unsigned long long act = __ballot(true);
+        const uint32_t n_act = (uint32_t)__builtin_popcountll(act);
+        const uint32_t arank = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+        for (uint32_t base = 0; base < n_slots; base += n_act) {
+            const uint32_t sidx = base + arank;
+            const bool mine = sidx < n_slots;
+            float *q = s_stage + kSlotFloats * (mine ? sidx : 0u);
+            const float qx = q[0], qy = q[1], qz = q[2], qw = q[3];
+            const uint32_t tag = mine ? __float_as_uint(q[4]) : lane;
+            const int owner = (int)(tag & 63u);
+            const bool shade = mine && (tag & 64u);
+            // the owner's per-ray constants (every lane takes part in the exchange)
+            const f3 lgt = mk3(__shfl(c.lgt.x, owner, 64), __shfl(c.lgt.y, owner, 64),
+                               __shfl(c.lgt.z, owner, 64));
+            const f3 hv = mk3(__shfl(c.hv.x, owner, 64), __shfl(c.hv.y, owner, 64),
+                              __shfl(c.hv.z, owner, 64));
+            const int hvalid = __shfl(c.hvalid ? 1 : 0, owner, 64);
+            f3 dirv = mk3(0.f, 0.f, 0.f);
+            if (rcp.contours)
+                dirv = mk3(__shfl(c.dir.x, owner, 64), __shfl(c.dir.y, owner, 64),
+                           __shfl(c.dir.z, owner, 64));
+            float o_ndl = 0.f, o_sp = 0.f, o_cnt = 0.f, o_op = 0.f;
+            if (__ballot(shade)) {
+                if (shade) {
+                    const f3 g = vol.neg_gradient(qx, qy, qz);
+                    // illumination (:294-303) with specularBlinnPhong (:280-291)
+                    o_ndl = vmax(0.f, dot3(g, lgt));
+                    o_sp = hvalid ? vr_powr(vmax(dot3(g, hv), 0.f), 40.f) : 0.0f;
+                    o_sp = o_sp * 0.15f;
+                    o_cnt = fabsf(dot3(dirv, g));             // contours (:846-848)
+                }
+            }
+            if (mine) {
+                o_op = 1.f - vr_powr(1.f - qw, refInterval);  // opacity correction (:864)
+                q[0] = o_ndl; q[1] = o_sp; q[2] = o_cnt; q[3] = o_op;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+            if (need[k]) {
+                const float *q = s_stage + kSlotFloats * slot[k];
+                ndl[k] = q[0]; spc[k] = q[1]; cnt[k] = q[2]; op[k] = q[3];
+            }
+        }
+    }
+
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+        if (lit[k] && rp.illumType == 1) {
+            tfc[k].x = ((tfc[k].x * 0.15f) + ((tfc[k].x * ndl[k]) * 0.7f)) + spc[k];
+            tfc[k].y = ((tfc[k].y * 0.15f) + ((tfc[k].y * ndl[k]) * 0.7f)) + spc[k];
+            tfc[k].z = ((tfc[k].z * 0.15f) + ((tfc[k].z * ndl[k]) * 0.7f)) + spc[k];
+        }
+        if (lit[k] && rcp.contours) {
+            tfc[k].x *= cnt[k]; tfc[k].y *= cnt[k]; tfc[k].z *= cnt[k];
         }
         tfc[k].x = c.env0 - tfc[k].x;
         tfc[k].y = c.env1 - tfc[k].y;
         tfc[k].z = c.env2 - tfc[k].z;
-        if (rcp.aerial) {
-            float depthCue = 1.f - (tk[k] - c.tnear) / c.sampleDist;
-            tfc[k].w *= depthCue;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < kBatch; ++k) {
-        // opacity correction (:864).  alpha == 0 gives 1 - powr(1, y) == 0 exactly, so the
-        // whole wave skips the powr when no lane has a non-zero alpha.
-        op[k] = 0.f;
-        if (__ballot(vk[k] && tfc[k].w != 0.f)) op[k] = 1.f - vr_powr(1.f - tfc[k].w, refInterval);
         p0[k] = tfc[k].x * op[k];
         p1[k] = tfc[k].y * op[k];
         p2[k] = tfc[k].z * op[k];
     }
 }
 
+constexpr int kLook = 16;   // samples looked ahead per round for empty runs
+
+// Bit k set: sample k of the run t0, t0 + stepSize, ... lies in an EMPTY cell (CellView): its
+// fetch can only map to opacity 0, so compositing it changes nothing (:864-879 with alpha == 0).
+// The cell is found from a linearised texel position (u0 + k * du): the cell extents carry a
+// one-texel halo for exactly this purpose, so the lookahead costs a few instructions per sample
+// and no voxel access.
+template <typename VT, int INSTR>
+VR_DEV uint32_t empty_mask(const CellView &cv, const Vol<VT, INSTR> &vol, const RayCtx &c, float t0)
+{
+    const f3 p0 = add3(c.cam, scale3(c.dir, t0 - c.offset));
+    const float u0 = (p0.x * 0.5f + 0.5f) * vol.fw - 0.5f;
+    const float v0 = (p0.y * 0.5f + 0.5f) * vol.fh - 0.5f;
+    const float s0 = (p0.z * 0.5f + 0.5f) * vol.fd - 0.5f;
+    const float du = (c.dir.x * c.stepSize) * (0.5f * vol.fw);
+    const float dv = (c.dir.y * c.stepSize) * (0.5f * vol.fh);
+    const float ds = (c.dir.z * c.stepSize) * (0.5f * vol.fd);
+    uint32_t w[kLook], sh[kLook];
+#pragma unroll
+    for (int k = 0; k < kLook; ++k) {
+        const float fk = (float)k;
+        const int x = iclamp((int)floorf(__builtin_fmaf(fk, du, u0)), 0, vol.w1) >> cv.shift;
+        const int y = iclamp((int)floorf(__builtin_fmaf(fk, dv, v0)), 0, vol.h1) >> cv.shift;
+        const int z = iclamp((int)floorf(__builtin_fmaf(fk, ds, s0)), 0, vol.d1) >> cv.shift;
+        const uint32_t idx = ((uint32_t)z * (uint32_t)cv.cy + (uint32_t)y) * (uint32_t)cv.cx + (uint32_t)x;
+        w[k] = cv.empty[idx >> 5];
+        sh[k] = idx & 31u;
+    }
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < kLook; ++k) m |= ((w[k] >> sh[k]) & 1u) << k;
+    return m;
+}
+
+// Step over the leading empty samples of the run (the reference's own t sequence and loop
+// exits, :790 and :868-879; nothing else of the loop body has an effect for them).  Returns
+// true when all kLook samples were consumed and the run may continue.
+VR_DEV bool skip_empty_run(uint32_t mask, const RayCtx &c, RayDyn &d, bool count,
+                           unsigned long long &c_taken)
+{
+    bool run = d.state == S_SAMPLE;
+    float tk = d.t;
+#pragma unroll
+    for (int k = 0; k < kLook; ++k) {
+        if (run) {
+            if (!(tk < d.t_exit) || !((mask >> k) & 1u)) run = false;
+            else {
+                if (count) c_taken++;
+                VR_RAYLEN_INC(d);
+                if (tk >= c.tfar) { d.state = S_DONE; run = false; }
+                else { tk = tk + c.stepSize; d.t = tk; }
+            }
+        }
+    }
+    return run;
+}
+
+// The lookahead costs a few hundred instructions for the whole wave: it runs when at least half
+// of the sampling lanes expect their next sample to be empty (their last one was).
+VR_DEV bool lookahead_pays(bool sampling, bool guess_empty)
+{
+    const int n_s = __builtin_popcountll(__ballot(sampling));
+    const int n_g = __builtin_popcountll(__ballot(sampling && guess_empty));
+    return n_g > 0 && 2 * n_g >= n_s;
+}
+
 // One front-to-back compositing step (:865-879) with the sample's colour*opacity (q0..q2),
 // opacity qo and ray parameter ti.
 VR_DEV void composite(const RayCtx &c, RayDyn &d, float q0, float q1, float q2, float qo, float ti)
 {
+    VR_RAYLEN_INC(d);
     float oma = 1.f - d.alpha;
     d.r0 = d.r0 - q0 * oma;
     d.r1 = d.r1 - q1 * oma;
@@ -289,6 +458,9 @@ VR_DEV void write_pixel(const FrameView &fr, const vrhip_rendering_params &rp, c
         r2 = prev.z + (r2 - prev.z) / it1;
     }
     float4 o = make_float4(r0, r1, r2, c.valid ? d.alpha : c.env3);
+#ifdef VR_RAYLEN
+    o.w = c.valid ? (float)d.nsmp : 0.f;
+#endif
     fr.fb[fi] = o;
     if (fr.out) fr.out[out_index] = o;
 }
@@ -335,15 +507,17 @@ VR_DEV void flush_counters(DevStats *stats, uint32_t lane, const unsigned long l
 // ------------------------------------------------------------------ phase 1
 
 template <typename VT, bool ESS, int INSTR, bool SKIP_LDS>
-__global__ __launch_bounds__(kBlockDim) void vr_raycast_kernel(
-    VolView vv, BrickView bricks, TfView tf, SkipView skip, FrameView fr, vrhip_camera_params cam,
-    vrhip_rendering_params rp, vrhip_raycast_params rc, DevStats *stats, uint32_t *touched)
+__global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_kernel(
+    VolView vv, BrickView bricks, TfView tf, SkipView skip, CellView cells, FrameView fr,
+    vrhip_camera_params cam, vrhip_rendering_params rp, vrhip_raycast_params rc, DevStats *stats,
+    uint32_t *touched)
 {
-    // LDS: [tff_n float4][skip words + 1]
+    // LDS: [gradient staging, 4 waves][tff_n float4][skip words + 1]
     extern __shared__ float4 s_mem[];
     VR_STAMP_DECL;
-    float4 *s_tff = s_mem;
-    uint32_t *s_skip = reinterpret_cast<uint32_t *>(s_mem + tf.tff_n);
+    float *s_stage = reinterpret_cast<float *>(s_mem) + (threadIdx.x >> 6) * kStageFloatsPerWave;
+    float4 *s_tff = s_mem + kStageF4;
+    uint32_t *s_skip = reinterpret_cast<uint32_t *>(s_tff + tf.tff_n);
     for (uint32_t i = threadIdx.x; i < tf.tff_n; i += kBlockDim) s_tff[i] = tf.tff[i];
     if (ESS && SKIP_LDS)
         for (uint32_t i = threadIdx.x; i <= skip.n_words; i += kBlockDim) s_skip[i] = skip.bits[i];
@@ -360,6 +534,9 @@ __global__ __launch_bounds__(kBlockDim) void vr_raycast_kernel(
     const float refInterval = 1.f / rc.samplingRate;
     const Grid grid = make_grid(bricks, rc, skip.n_words, ESS);
     const uint32_t *sb = SKIP_LDS ? s_skip : skip.bits;
+    // empty-run skipping needs the linear sampler's footprint; the traffic-instrumented variant
+    // reproduces the reference's fetch set instead
+    const bool skip_empty = INSTR != 2 && cells.empty != nullptr && rp.useLinear != 0;
 
     // every wave pulls 8x8 patches until the queue is drained (exit condition reached by every
     // wave: the head only grows).  The next ticket is drawn while the current patch is marched,
@@ -387,6 +564,7 @@ __global__ __launch_bounds__(kBlockDim) void vr_raycast_kernel(
         // ---- flattened DDA / sample state machine, at most round_budget sample rounds
         uint32_t rounds_left = fr.round_budget ? fr.round_budget : 0xffffffffu;
         bool suspended = false;
+        bool guess_empty = true;   // this ray's next sample is expected to lie in an empty cell
         for (;;) {
             VR_COUNT(10);
             if (ESS) {
@@ -401,7 +579,18 @@ __global__ __launch_bounds__(kBlockDim) void vr_raycast_kernel(
             if (!__ballot(d.state != S_DONE)) break;
             if (rounds_left == 0) { suspended = true; break; }
             if (__ballot(d.state == S_SAMPLE)) --rounds_left;
-            if (d.state == S_SAMPLE) {
+            bool more_empty = false;
+            if (skip_empty && lookahead_pays(d.state == S_SAMPLE, guess_empty)) {
+                if (d.state == S_SAMPLE) {
+                    // ---- step over a run of up to kLook samples in empty cells
+                    const uint32_t em = empty_mask<VT, INSTR>(cells, vol, c, d.t);
+                    more_empty = skip_empty_run(em, c, d, INSTR != 0, c_taken);
+                    guess_empty = (em & 1u) != 0u;
+                    after_segment<ESS>(c, d);
+                }
+            }
+            VR_STAMP(4);
+            if (d.state == S_SAMPLE && !more_empty) {
                 // ---- up to kBatch consecutive samples of this ray per round
                 float tk[kBatch];
                 bool vk[kBatch], litk[kBatch];
@@ -415,7 +604,7 @@ __global__ __launch_bounds__(kBlockDim) void vr_raycast_kernel(
                     if (INSTR == 2) vk[k] = false;
                 }
                 float p0[kBatch], p1[kBatch], p2[kBatch], opk[kBatch];
-                eval_batch<VT, INSTR>(vol, s_tff, tffn, c, rp, rc, refInterval, tk, vk, p0, p1, p2,
+                eval_batch<VT, INSTR>(vol, s_tff, tffn, s_stage, c, rp, rc, refInterval, tk, vk, p0, p1, p2,
                                       opk, litk);
                 VR_STAMP(3);
                 // sequential front-to-back compositing (:865-879)
@@ -426,6 +615,7 @@ __global__ __launch_bounds__(kBlockDim) void vr_raycast_kernel(
                         composite(c, d, p0[k], p1[k], p2[k], opk[k], tk[k]);
                     }
                 }
+                if (vk[kBatch - 1]) guess_empty = opk[kBatch - 1] == 0.f;
                 after_segment<ESS>(c, d);
                 VR_STAMP(6);
             }
@@ -449,6 +639,9 @@ __global__ __launch_bounds__(kBlockDim) void vr_raycast_kernel(
                 r.cx = d.c0; r.cy = d.c1; r.cz = d.c2;
                 r.tv0 = d.tv0; r.tv1 = d.tv1; r.tv2 = d.tv2;
                 r.pad = 0;
+#ifdef VR_RAYLEN
+                r.pad = d.nsmp;
+#endif
                 const uint32_t rank = (uint32_t)__builtin_popcountll(cm & ((1ull << lane) - 1ull));
                 fr.cont[base + rank] = r;
             }
@@ -457,7 +650,7 @@ __global__ __launch_bounds__(kBlockDim) void vr_raycast_kernel(
             write_pixel(fr, rp, c, d, gx, gy, (size_t)wt.out_base + (size_t)ly * fr.out_stride + lx);
         VR_STAMP(7);
     }
-    VR_STAMP_FLUSH;
+    VR_STAMP_FLUSH_AT(0);
 
     if (INSTR) {
         const unsigned long long cc[6] = {c_taken, c_nominal, c_shaded, c_bricks, c_skipped, c_hit};
@@ -494,16 +687,19 @@ VR_DEV void composite_from(const RayCtx &c, RayDyn &d, const float (&p0)[kBatch]
 // in-quad DPP broadcasts -- the fp32 operation sequence per ray is exactly phase 1's (and the
 // reference's), the serial chain of a long ray is 4x shorter.
 template <typename VT, bool ESS, int INSTR, bool SKIP_LDS>
-__global__ __launch_bounds__(kBlockDim) void vr_raycast_split_kernel(
-    VolView vv, BrickView bricks, TfView tf, SkipView skip, FrameView fr, vrhip_camera_params cam,
-    vrhip_rendering_params rp, vrhip_raycast_params rc, DevStats *stats, uint32_t *touched)
+__global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
+    VolView vv, BrickView bricks, TfView tf, SkipView skip, CellView cells, FrameView fr,
+    vrhip_camera_params cam, vrhip_rendering_params rp, vrhip_raycast_params rc, DevStats *stats,
+    uint32_t *touched)
 {
     static_assert(kSplit == 4 && kBatch == 4, "phase 2 is written for 4 lanes x 4 samples");
     const uint32_t n_rays = *fr.cont_count;   // written by phase 1 (previous kernel on the stream)
     if (n_rays == 0) return;
     extern __shared__ float4 s_mem[];
-    float4 *s_tff = s_mem;
-    uint32_t *s_skip = reinterpret_cast<uint32_t *>(s_mem + tf.tff_n);
+    VR_STAMP_DECL;
+    float *s_stage = reinterpret_cast<float *>(s_mem) + (threadIdx.x >> 6) * kStageFloatsPerWave;
+    float4 *s_tff = s_mem + kStageF4;
+    uint32_t *s_skip = reinterpret_cast<uint32_t *>(s_tff + tf.tff_n);
     for (uint32_t i = threadIdx.x; i < tf.tff_n; i += kBlockDim) s_tff[i] = tf.tff[i];
     if (ESS && SKIP_LDS)
         for (uint32_t i = threadIdx.x; i <= skip.n_words; i += kBlockDim) s_skip[i] = skip.bits[i];
@@ -520,6 +716,7 @@ __global__ __launch_bounds__(kBlockDim) void vr_raycast_split_kernel(
     const float refInterval = 1.f / rc.samplingRate;
     const Grid grid = make_grid(bricks, rc, skip.n_words, ESS);
     const uint32_t *sb = SKIP_LDS ? s_skip : skip.bits;
+    const bool skip_empty = INSTR != 2 && cells.empty != nullptr && rp.useLinear != 0;
     const uint32_t n_groups = (n_rays + kRaysPerWave - 1u) / kRaysPerWave;
 
     uint32_t q_next = 0;
@@ -528,6 +725,7 @@ __global__ __launch_bounds__(kBlockDim) void vr_raycast_split_kernel(
         const uint32_t q = __builtin_amdgcn_readfirstlane(q_next);
         if (q >= n_groups) break;
         if (lane == 0) q_next = atomicAdd(fr.cont_head, 1u);
+        VR_COUNT(11);
         const uint32_t ri = q * kRaysPerWave + rsel;
         const bool have = ri < n_rays;
         const ContRec rec = fr.cont[have ? ri : 0];
@@ -541,21 +739,40 @@ __global__ __launch_bounds__(kBlockDim) void vr_raycast_split_kernel(
         d.r0 = rec.r0; d.r1 = rec.r1; d.r2 = rec.r2;
         d.c0 = rec.cx; d.c1 = rec.cy; d.c2 = rec.cz;
         d.tv0 = rec.tv0; d.tv1 = rec.tv1; d.tv2 = rec.tv2;
+#ifdef VR_RAYLEN
+        d.nsmp = rec.pad;
+#endif
         if (ESS) fetch_skip_word(sb, grid, d);
         unsigned long long dummy0 = 0, dummy1 = 0;
         const bool count = INSTR && slot == 0;
+        bool guess_empty = true;   // identical in the four lanes of a ray, like all of its state
+        VR_STAMP(1);
 
         for (;;) {
             if (ESS) {
                 for (int it = 0;; ++it) {
                     if (!__ballot(d.state == S_BRICK)) break;
                     if (it >= kMaxBrickSteps && __ballot(d.state == S_SAMPLE)) break;
+                    VR_COUNT(9);
                     if (count) dda_step<INSTR>(sb, grid, c, d, c_bricks, c_skipped);
                     else dda_step<0>(sb, grid, c, d, dummy0, dummy1);
                 }
             }
+            VR_STAMP(2);
             if (!__ballot(d.state != S_DONE)) break;
-            if (d.state == S_SAMPLE) {
+            VR_COUNT(10);
+            bool more_empty = false;
+            if (skip_empty && lookahead_pays(d.state == S_SAMPLE, guess_empty)) {
+                if (d.state == S_SAMPLE) {
+                    // the four lanes of a ray hold the same state and take the same decisions
+                    const uint32_t em = empty_mask<VT, INSTR>(cells, vol, c, d.t);
+                    more_empty = skip_empty_run(em, c, d, count, c_taken);
+                    guess_empty = (em & 1u) != 0u;
+                    after_segment<ESS>(c, d);
+                }
+            }
+            VR_STAMP(4);
+            if (d.state == S_SAMPLE && !more_empty) {
                 // parameters (t += stepSize, :879) and validity (:790, :868) of the ray's next 16
                 // samples; this lane keeps numbers 4*slot .. 4*slot+3
                 float tk[kBatch] = {0.f, 0.f, 0.f, 0.f};
@@ -575,8 +792,9 @@ __global__ __launch_bounds__(kBlockDim) void vr_raycast_split_kernel(
                 }
                 float p0[kBatch], p1[kBatch], p2[kBatch], opk[kBatch];
                 bool litk[kBatch];
-                eval_batch<VT, INSTR>(vol, s_tff, tffn, c, rp, rc, refInterval, tk, vk, p0, p1, p2,
+                eval_batch<VT, INSTR>(vol, s_tff, tffn, s_stage, c, rp, rc, refInterval, tk, vk, p0, p1, p2,
                                       opk, litk);
+                VR_STAMP(3);
                 int fl[kBatch];
 #pragma unroll
                 for (int k = 0; k < kBatch; ++k) fl[k] = (vk[k] ? 1 : 0) | (litk[k] ? 2 : 0);
@@ -584,11 +802,19 @@ __global__ __launch_bounds__(kBlockDim) void vr_raycast_split_kernel(
                 composite_from<1>(c, d, p0, p1, p2, opk, tk, fl, count, c_taken, c_shaded);
                 composite_from<2>(c, d, p0, p1, p2, opk, tk, fl, count, c_taken, c_shaded);
                 composite_from<3>(c, d, p0, p1, p2, opk, tk, fl, count, c_taken, c_shaded);
+                {   // the ray's 16th sample of this round: lane 3 of the quad, slot kBatch - 1
+                    const int f3v = quad_bcast<3>(fl[kBatch - 1]);
+                    const float o3 = quad_bcast<3>(opk[kBatch - 1]);
+                    if (f3v & 1) guess_empty = o3 == 0.f;
+                }
                 after_segment<ESS>(c, d);
+                VR_STAMP(6);
             }
         }
         if (have && slot == 0) write_pixel(fr, rp, c, d, gx, gy, (size_t)rec.out_index);
+        VR_STAMP(7);
     }
+    VR_STAMP_FLUSH_AT(16);
 
     if (INSTR) {
         const unsigned long long cc[6] = {c_taken, 0, c_shaded, c_bricks, c_skipped, 0};
@@ -630,7 +856,7 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
 {
     auto k1 = vr_raycast_kernel<VT, ESS, INSTR, SKIP_LDS>;
     auto k2 = vr_raycast_split_kernel<VT, ESS, INSTR, SKIP_LDS>;
-    size_t lds = (size_t)a.tf.tff_n * sizeof(float4);
+    size_t lds = (size_t)kStageF4 * sizeof(float4) + (size_t)a.tf.tff_n * sizeof(float4);
     if (ESS && SKIP_LDS) lds += ((size_t)a.skip.n_words + 1) * sizeof(uint32_t);
     static int nb1 = 0, nb2 = 0;
     static size_t cached_lds = ~(size_t)0;
@@ -645,14 +871,14 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
     uint32_t cap = cus * (uint32_t)nb1;
     dim3 grid(want < cap ? want : cap), block(kBlockDim);
     if (grid.x == 0) return hipSuccess;
-    hipLaunchKernelGGL(k1, grid, block, lds, stream, a.vol, a.bricks, a.tf, a.skip, a.frame, a.cam,
+    hipLaunchKernelGGL(k1, grid, block, lds, stream, a.vol, a.bricks, a.tf, a.skip, a.cells, a.frame, a.cam,
                        a.render, a.raycast, a.stats, a.touched);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && a.mid_event) e = hipEventRecord(a.mid_event, stream);
     if (e != hipSuccess || a.frame.round_budget == 0) return e;
     // phase 2: persistent grid; exits at once when nothing was suspended
     dim3 grid2(cus * (uint32_t)nb2);
-    hipLaunchKernelGGL(k2, grid2, block, lds, stream, a.vol, a.bricks, a.tf, a.skip, a.frame, a.cam,
+    hipLaunchKernelGGL(k2, grid2, block, lds, stream, a.vol, a.bricks, a.tf, a.skip, a.cells, a.frame, a.cam,
                        a.render, a.raycast, a.stats, a.touched);
     return hipGetLastError();
 }
@@ -680,13 +906,13 @@ hipError_t launch_typed(const RaycastLaunch &a, hipStream_t stream)
 
 #ifdef VR_STAMPS
 // diagnostic builds only: read (and optionally clear) the per-phase cycle totals
-extern "C" int vrhip_debug_stamps(unsigned long long out[16], int reset)
+extern "C" int vrhip_debug_stamps(unsigned long long out[32], int reset)
 {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), 16 * sizeof(unsigned long long)) != hipSuccess)
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), 32 * sizeof(unsigned long long)) != hipSuccess)
         return -1;
     if (reset) {
-        unsigned long long z[16] = {0};
+        unsigned long long z[32] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z) != hipSuccess) return -1;
     }
     return 0;

@@ -27,11 +27,11 @@ enum : int { S_DONE = 0, S_BRICK = 1, S_SAMPLE = 2 };
 // over all waves.  Every stamp drains the memory queues, so only the SHARES are meaningful;
 // the stamp values leave the kernel through g_stamps alone and feed no output.
 #ifdef VR_STAMPS
-__device__ unsigned long long g_stamps[16];
+__device__ unsigned long long g_stamps[32];   // [0,16) phase 1, [16,32) phase 2
 #define VR_STAMP_DECL unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = vr_stamp(), st_first = st_last
 #define VR_STAMP(i) do { unsigned long long n_ = vr_stamp(); st_acc[i] += n_ - st_last; st_last = n_; } while (0)
 #define VR_COUNT(i) st_acc[i] += 1
-#define VR_STAMP_FLUSH do { if ((threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_stamps[i_], st_acc[i_]); atomicAdd(&g_stamps[12], vr_stamp() - st_first); } } while (0)
+#define VR_STAMP_FLUSH_AT(b) do { if ((threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_stamps[(b) + i_], st_acc[i_]); atomicAdd(&g_stamps[(b) + 12], vr_stamp() - st_first); } } while (0)
 __device__ __forceinline__ unsigned long long vr_stamp()
 {
     unsigned long long t;
@@ -42,7 +42,7 @@ __device__ __forceinline__ unsigned long long vr_stamp()
 #define VR_STAMP_DECL
 #define VR_STAMP(i)
 #define VR_COUNT(i)
-#define VR_STAMP_FLUSH
+#define VR_STAMP_FLUSH_AT(b)
 #endif
 
 // ------------------------------------------------------------------ volume reads
@@ -114,7 +114,7 @@ struct Vol {
 
     // index of the majorant-grid cell holding the low corner texel (x0, y0, z0) of linear()'s
     // footprint: the fetch uses voxels x0..x0+1 etc., all inside that cell's halo'd extent
-    VR_DEV uint32_t cell_index(float px, float py, float pz, const PtView &g) const
+    VR_DEV uint32_t cell_index(float px, float py, float pz, const CellView &g) const
     {
         const int x0 = iclamp((int)floorf(px * fw - 0.5f), 0, w1);
         const int y0 = iclamp((int)floorf(py * fh - 0.5f), 0, h1);

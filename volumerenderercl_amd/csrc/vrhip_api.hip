@@ -58,13 +58,16 @@ struct vrhip_renderer {
     uint32_t skip_words = 0, skip_cap = 0;
     bool skip_dirty = true;
 
-    // path tracer: majorant grid (opacity bound per cell) of the current timestep + TF
-    PtView pt_grid = {nullptr, 0, 0, 0, 3};
-    float *pt_bound = nullptr;
-    float *pt_sparse = nullptr;    // 13 x 4096 floats of scratch for the TF range-max table
-    size_t pt_bound_cap = 0;
-    bool pt_dirty = true;
-    bool pt_cull = true;           // VRHIP_PT_NO_CULL=1 disables (experiments)
+    // cell grid of the current timestep + TF (CellView, vr_internal.h): opacity bound for the
+    // path tracer, empty bits for the ray caster
+    CellView cells = {nullptr, nullptr, 0, 0, 0, 3};
+    float *cell_bound = nullptr;
+    uint32_t *cell_empty = nullptr;
+    float *cell_sparse = nullptr;  // 13 x 4096 floats of scratch for the TF range-max table
+    size_t cell_cap = 0;
+    bool pt_dirty = true;          // cells out of date (volume, timestep or TF changed)
+    bool pt_cull = true;           // VRHIP_PT_NO_CULL=1 disables the path tracer's culling
+    bool skip_empty = true;        // VRHIP_NO_EMPTY_SKIP=1 disables the ray caster's empty runs
 
     vrhip_camera_params cam;
     vrhip_rendering_params render;
@@ -341,43 +344,43 @@ int ensure_skipmap(vrhip_renderer *r)
     return VRHIP_OK;
 }
 
-// Path tracer: (re)build the majorant grid when the volume, the timestep or the TF changed.
-// Cells of 2^shift voxels per axis, at most 128 per axis.
-int ensure_pt_grid(vrhip_renderer *r)
+// (Re)build the cell grid when the volume, the timestep or the TF changed.  Cells of 2^shift
+// voxels per axis, at most 256 per axis (shift 3 up to 2048^3: 2 MiB of empty bits).
+int ensure_cells(vrhip_renderer *r)
 {
-    if (!r->pt_cull) {
-        r->pt_grid.bound = nullptr;
-        return VRHIP_OK;
-    }
-    if (!r->pt_dirty && r->pt_grid.bound) return VRHIP_OK;
+    if (!r->pt_dirty && r->cell_bound) return VRHIP_OK;
     VolumeSlot &s = r->vols[r->timestep];
     uint32_t mres = std::max(r->res[0], std::max(r->res[1], r->res[2]));
     int shift = 3;
-    while (((mres + (1u << shift) - 1) >> shift) > 128u) ++shift;
-    PtView g;
+    while (((mres + (1u << shift) - 1) >> shift) > 256u) ++shift;
+    CellView g;
     g.shift = shift;
     g.cx = (int)((r->res[0] + (1u << shift) - 1) >> shift);
     g.cy = (int)((r->res[1] + (1u << shift) - 1) >> shift);
     g.cz = (int)((r->res[2] + (1u << shift) - 1) >> shift);
     const size_t n_cells = (size_t)g.cx * g.cy * g.cz;
-    if (n_cells > r->pt_bound_cap) {
+    if (n_cells > r->cell_cap) {
         VR_HIP(r, hipStreamSynchronize(r->stream));
-        if (r->pt_bound) VR_HIP(r, hipFree(r->pt_bound));
-        r->pt_bound = nullptr;
-        r->pt_bound_cap = 0;
-        VR_HIP(r, hipMalloc((void **)&r->pt_bound, n_cells * sizeof(float)));
-        r->pt_bound_cap = n_cells;
+        if (r->cell_bound) VR_HIP(r, hipFree(r->cell_bound));
+        if (r->cell_empty) VR_HIP(r, hipFree(r->cell_empty));
+        r->cell_bound = nullptr;
+        r->cell_empty = nullptr;
+        r->cell_cap = 0;
+        VR_HIP(r, hipMalloc((void **)&r->cell_bound, n_cells * sizeof(float)));
+        VR_HIP(r, hipMalloc((void **)&r->cell_empty, ((n_cells + 31) / 32) * sizeof(uint32_t)));
+        r->cell_cap = n_cells;
     }
-    if (!r->pt_sparse) VR_HIP(r, hipMalloc((void **)&r->pt_sparse, 13 * 4096 * sizeof(float)));
-    g.bound = r->pt_bound;
+    if (!r->cell_sparse) VR_HIP(r, hipMalloc((void **)&r->cell_sparse, 13 * 4096 * sizeof(float)));
     if (!s.pt_minmax) VR_HIP(r, hipMalloc((void **)&s.pt_minmax, n_cells * sizeof(float2)));
     if (!s.pt_minmax_valid) {
-        VR_HIP(r, vr_launch_pt_minmax(make_vol_view(r, s.dev), r->format, g, s.pt_minmax, r->stream));
+        VR_HIP(r, vr_launch_cell_minmax(make_vol_view(r, s.dev), r->format, g, s.pt_minmax, r->stream));
         s.pt_minmax_valid = true;
     }
-    VR_HIP(r, vr_launch_pt_bound(s.pt_minmax, g, inv_max_of(r->format), make_tf_view(r),
-                                 r->pt_sparse, r->pt_bound, r->stream));
-    r->pt_grid = g;
+    VR_HIP(r, vr_launch_cell_bounds(s.pt_minmax, g, inv_max_of(r->format), make_tf_view(r),
+                                    r->cell_sparse, r->cell_bound, r->cell_empty, r->stream));
+    g.bound = r->cell_bound;
+    g.empty = r->cell_empty;
+    r->cells = g;
     r->pt_dirty = false;
     return VRHIP_OK;
 }
@@ -476,7 +479,9 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
     a->render = r->render;
     a->raycast = r->raycast;
     a->pathtrace = r->pathtrace;
-    a->pt = r->pt_grid;
+    a->cells = r->cells;
+    if (!r->pt_cull) a->cells.bound = nullptr;
+    if (!r->skip_empty) a->cells.empty = nullptr;
     a->format = r->format;
     a->use_ess = r->use_ess ? 1 : 0;
     a->instr = r->stats_enabled ? 1 : 0;
@@ -511,8 +516,14 @@ int prepare_render(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t 
     }
     rc = ensure_fb(r, width, height);
     if (rc) return rc;
-    rc = r->render.technique == 0 ? ensure_skipmap(r) : ensure_pt_grid(r);
-    if (rc) return rc;
+    if (r->render.technique == 0) {
+        rc = ensure_skipmap(r);
+        if (rc) return rc;
+    }
+    if (r->render.technique == 1 ? r->pt_cull : r->skip_empty) {
+        rc = ensure_cells(r);
+        if (rc) return rc;
+    }
     return ensure_queue(r, width, height, tile_w, tile_h, tile_ids, n_tiles);
 }
 
@@ -598,7 +609,8 @@ int vrhip_create(int device_id, vrhip_renderer **out)
     }
     r->stream = r->own_stream;
     if (const char *b = getenv("VRHIP_ROUND_BUDGET")) r->round_budget = (uint32_t)atoi(b);   // tuning
-    if (getenv("VRHIP_PT_NO_CULL")) r->pt_cull = false;   // experiments: path tracer without the majorant grid
+    if (getenv("VRHIP_PT_NO_CULL")) r->pt_cull = false;        // experiments: no opacity-bound culling
+    if (getenv("VRHIP_NO_EMPTY_SKIP")) r->skip_empty = false;  // experiments: no empty-run skipping
     r->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     r->devname = std::string(prop.name) + " (" + prop.gcnArchName + ")";
     *out = r;
@@ -619,8 +631,9 @@ void vrhip_destroy(vrhip_renderer *r)
     if (r->queue_head) (void)hipFree(r->queue_head);
     if (r->cont) (void)hipFree(r->cont);
     if (r->skip_bits) (void)hipFree(r->skip_bits);
-    if (r->pt_bound) (void)hipFree(r->pt_bound);
-    if (r->pt_sparse) (void)hipFree(r->pt_sparse);
+    if (r->cell_bound) (void)hipFree(r->cell_bound);
+    if (r->cell_empty) (void)hipFree(r->cell_empty);
+    if (r->cell_sparse) (void)hipFree(r->cell_sparse);
     if (r->ev0) (void)hipEventDestroy(r->ev0);
     if (r->ev1) (void)hipEventDestroy(r->ev1);
     if (r->evm) (void)hipEventDestroy(r->evm);
