@@ -67,6 +67,23 @@ def main():
         print("  DDA iterations/frame %.0f (%.0f cycles each)  rounds/frame %.0f (%.0f cycles each)  "
               "tiles|groups/frame %.0f" % (o[9] / frames, o[2] / max(o[9], 1), rounds,
                                            total / frames / max(rounds, 1), tiles))
+    # timeline: when do the waves of each phase end (last frame)?
+    import numpy as np
+    spans = (C.c_uint64 * (2 * 2 * 8192))()
+    f = vr.lib.vrhip_debug_wave_spans
+    f.argtypes = [C.POINTER(C.c_uint64)]
+    if f(spans) == 0:
+        a = np.frombuffer(spans, dtype=np.uint64).reshape(2, 2, 8192).astype(np.int64)
+        for ph in (0, 1):
+            st, en = a[ph, 0], a[ph, 1]
+            ok = en > 0
+            if not ok.any():
+                continue
+            # persistent grid: every wave starts with the launch, so its lifetime is its end time
+            life = np.sort((en[ok] - st[ok]) / 1e3)
+            print(" phase %d: %d waves; lifetime in kcycles: p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f "
+                  "mean %.0f" % (ph + 1, ok.sum(), *(np.percentile(life, q) for q in (10, 50, 90, 99, 100)),
+                                 life.mean()))
     vr.close()
 
 

@@ -82,7 +82,16 @@ struct FrameView {
     uint32_t *cont_count;  // zeroed before each launch
     uint32_t *cont_head;   // zeroed before each launch
     uint32_t round_budget;
+    // Phase-2 scheduling: `cost` keeps, per pixel, the phase-2 rounds the pixel's ray needed in the
+    // previous frame.  Suspended rays are sorted by it, longest first (counting sort into
+    // `order`), so that the longest chains start first and the 16 rays of a group are alike.
+    // Purely a schedule: the image does not depend on it.
+    uint16_t *cost;        // W*H, or nullptr
+    uint32_t *order;       // permutation of the suspended rays, or nullptr (append order)
+    uint32_t *sort_ws;     // kSortBins counts + kSortBins cursors, zeroed before each launch
 };
+constexpr uint32_t kSortBins = 256;
+constexpr uint32_t kControlWords = 4 + 2 * kSortBins;   // queue head, cont count, cont head, pad, sort_ws
 
 // Cell grid: the volume cut into cells of 2^shift voxels per axis.  For every cell the renderer
 // keeps (min, max) of the voxels a trilinear fetch whose low-corner texel lies in the cell -- or

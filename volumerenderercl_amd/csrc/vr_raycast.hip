@@ -638,7 +638,7 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_kernel(
                 r.r0 = d.r0; r.r1 = d.r1; r.r2 = d.r2;
                 r.cx = d.c0; r.cy = d.c1; r.cz = d.c2;
                 r.tv0 = d.tv0; r.tv1 = d.tv1; r.tv2 = d.tv2;
-                r.pad = 0;
+                r.pad = fr.cost ? (uint32_t)fr.cost[(size_t)gy * fr.W + gx] : 0u;   // sort key
 #ifdef VR_RAYLEN
                 r.pad = d.nsmp;
 #endif
@@ -728,7 +728,9 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
         VR_COUNT(11);
         const uint32_t ri = q * kRaysPerWave + rsel;
         const bool have = ri < n_rays;
-        const ContRec rec = fr.cont[have ? ri : 0];
+        const uint32_t rix = have ? (fr.order ? fr.order[ri] : ri) : 0u;
+        const ContRec rec = fr.cont[rix];
+        uint32_t my_rounds = 0;   // rounds this ray stays alive: next frame's sort key
         const uint32_t gx = rec.pix & 0xffffu, gy = rec.pix >> 16;
 
         RayCtx c;
@@ -761,6 +763,7 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
             VR_STAMP(2);
             if (!__ballot(d.state != S_DONE)) break;
             VR_COUNT(10);
+            my_rounds += d.state != S_DONE ? 1u : 0u;
             bool more_empty = false;
             if (skip_empty && lookahead_pays(d.state == S_SAMPLE, guess_empty)) {
                 if (d.state == S_SAMPLE) {
@@ -811,7 +814,10 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
                 VR_STAMP(6);
             }
         }
-        if (have && slot == 0) write_pixel(fr, rp, c, d, gx, gy, (size_t)rec.out_index);
+        if (have && slot == 0) {
+            write_pixel(fr, rp, c, d, gx, gy, (size_t)rec.out_index);
+            if (fr.cost) fr.cost[(size_t)gy * fr.W + gx] = (uint16_t)(my_rounds < 65535u ? my_rounds : 65535u);
+        }
         VR_STAMP(7);
     }
     VR_STAMP_FLUSH_AT(16);
@@ -819,6 +825,69 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
     if (INSTR) {
         const unsigned long long cc[6] = {c_taken, 0, c_shaded, c_bricks, c_skipped, 0};
         flush_counters(stats, lane, cc);
+    }
+}
+
+// ------------------------------------------------------------------ phase-2 ordering
+
+// Counting sort of the suspended rays by their key (ContRec::pad = rounds needed last frame,
+// clamped to kSortBins - 1), longest first.  Two small launches between the phases.
+__global__ __launch_bounds__(kBlockDim) void vr_cont_hist_kernel(const ContRec *cont,
+                                                                 const uint32_t *count,
+                                                                 uint32_t *bins)
+{
+    __shared__ uint32_t s_bins[kSortBins];
+    for (uint32_t i = threadIdx.x; i < kSortBins; i += kBlockDim) s_bins[i] = 0;
+    __syncthreads();
+    const uint32_t n = *count;
+    for (uint32_t i = blockIdx.x * kBlockDim + threadIdx.x; i < n; i += gridDim.x * kBlockDim) {
+        const uint32_t k = cont[i].pad < kSortBins ? cont[i].pad : kSortBins - 1u;
+        atomicAdd(&s_bins[k], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kSortBins; i += kBlockDim)
+        if (s_bins[i]) atomicAdd(&bins[i], s_bins[i]);
+}
+
+__global__ __launch_bounds__(kBlockDim) void vr_cont_scatter_kernel(const ContRec *cont,
+                                                                    const uint32_t *count,
+                                                                    const uint32_t *bins,
+                                                                    uint32_t *cursors,
+                                                                    uint32_t *order)
+{
+    __shared__ uint32_t s_off[kSortBins], s_cnt[kSortBins], s_base[kSortBins];
+    // descending keys: bin k starts after all bins above it
+    for (uint32_t k = threadIdx.x; k < kSortBins; k += kBlockDim) {
+        uint32_t o = 0;
+        for (uint32_t j = k + 1; j < kSortBins; ++j) o += bins[j];
+        s_off[k] = o;
+    }
+    const uint32_t n = *count;
+    const uint32_t chunk = kBlockDim * 4u;
+    for (uint32_t c0 = blockIdx.x * chunk; c0 < n; c0 += gridDim.x * chunk) {
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < kSortBins; k += kBlockDim) s_cnt[k] = 0;
+        __syncthreads();
+        uint32_t key[4], rank[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t i = c0 + (uint32_t)j * kBlockDim + threadIdx.x;
+            key[j] = kSortBins;
+            rank[j] = 0;
+            if (i < n) {
+                key[j] = cont[i].pad < kSortBins ? cont[i].pad : kSortBins - 1u;
+                rank[j] = atomicAdd(&s_cnt[key[j]], 1u);
+            }
+        }
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < kSortBins; k += kBlockDim)
+            s_base[k] = s_cnt[k] ? atomicAdd(&cursors[k], s_cnt[k]) : 0u;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t i = c0 + (uint32_t)j * kBlockDim + threadIdx.x;
+            if (i < n) order[s_off[key[j]] + s_base[key[j]] + rank[j]] = i;
+        }
     }
 }
 
@@ -876,6 +945,15 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && a.mid_event) e = hipEventRecord(a.mid_event, stream);
     if (e != hipSuccess || a.frame.round_budget == 0) return e;
+    if (a.frame.order) {   // longest rays first (keys: last frame's phase-2 rounds per pixel)
+        hipLaunchKernelGGL(vr_cont_hist_kernel, dim3(128), block, 0, stream, a.frame.cont,
+                           a.frame.cont_count, a.frame.sort_ws);
+        hipLaunchKernelGGL(vr_cont_scatter_kernel, dim3(128), block, 0, stream, a.frame.cont,
+                           a.frame.cont_count, a.frame.sort_ws, a.frame.sort_ws + kSortBins,
+                           a.frame.order);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
     // phase 2: persistent grid; exits at once when nothing was suspended
     dim3 grid2(cus * (uint32_t)nb2);
     hipLaunchKernelGGL(k2, grid2, block, lds, stream, a.vol, a.bricks, a.tf, a.skip, a.cells, a.frame, a.cam,
@@ -905,6 +983,18 @@ hipError_t launch_typed(const RaycastLaunch &a, hipStream_t stream)
 } // namespace
 
 #ifdef VR_STAMPS
+// diagnostic builds only: start/end clock of every wave of the last launches
+extern "C" int vrhip_debug_wave_spans(unsigned long long *out /* [2][2][8192] */)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_span), sizeof(unsigned long long) * 2 * 2 * 8192) != hipSuccess)
+        return -1;
+    unsigned long long *z = (unsigned long long *)calloc(2 * 2 * 8192, sizeof(unsigned long long));
+    if (!z) return -1;
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_wave_span), z, sizeof(unsigned long long) * 2 * 2 * 8192);
+    free(z);
+    return e == hipSuccess ? 0 : -1;
+}
 // diagnostic builds only: read (and optionally clear) the per-phase cycle totals
 extern "C" int vrhip_debug_stamps(unsigned long long out[32], int reset)
 {

@@ -28,10 +28,11 @@ enum : int { S_DONE = 0, S_BRICK = 1, S_SAMPLE = 2 };
 // the stamp values leave the kernel through g_stamps alone and feed no output.
 #ifdef VR_STAMPS
 __device__ unsigned long long g_stamps[32];   // [0,16) phase 1, [16,32) phase 2
+__device__ unsigned long long g_wave_span[2][2][8192];   // [phase][start|end][wave]: s_memtime of every wave
 #define VR_STAMP_DECL unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = vr_stamp(), st_first = st_last
 #define VR_STAMP(i) do { unsigned long long n_ = vr_stamp(); st_acc[i] += n_ - st_last; st_last = n_; } while (0)
 #define VR_COUNT(i) st_acc[i] += 1
-#define VR_STAMP_FLUSH_AT(b) do { if ((threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_stamps[(b) + i_], st_acc[i_]); atomicAdd(&g_stamps[(b) + 12], vr_stamp() - st_first); } } while (0)
+#define VR_STAMP_FLUSH_AT(b) do { if ((threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_stamps[(b) + i_], st_acc[i_]); atomicAdd(&g_stamps[(b) + 12], vr_stamp() - st_first); unsigned w_ = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & 8191u; g_wave_span[(b) ? 1 : 0][0][w_] = st_first; g_wave_span[(b) ? 1 : 0][1][w_] = vr_stamp(); } } while (0)
 __device__ __forceinline__ unsigned long long vr_stamp()
 {
     unsigned long long t;

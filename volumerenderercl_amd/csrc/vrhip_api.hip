@@ -84,7 +84,10 @@ struct vrhip_renderer {
     // work queue of 8x8 wave tiles (centre first) for the current frame/tile set
     WaveTile *queue_dev = nullptr;
     uint32_t queue_n = 0, queue_cap = 0;
-    uint32_t *queue_head = nullptr;   // 4 control words: queue head, cont count, cont head, pad
+    uint32_t *queue_head = nullptr;   // kControlWords: queue head, cont count, cont head, pad, sort bins + cursors
+    uint16_t *cost = nullptr;         // per pixel: phase-2 rounds of the previous frame (sort key)
+    uint32_t *order = nullptr;        // sorted permutation of the suspended rays
+    bool sort_cont = true;            // VRHIP_NO_SORT=1 disables
     ContRec *cont = nullptr;          // suspended rays of the two-phase march
     size_t cont_cap = 0;
     uint32_t round_budget = 16;       // phase-1 sample rounds per patch (0 = single phase)
@@ -293,6 +296,10 @@ int ensure_fb(vrhip_renderer *r, uint32_t w, uint32_t h)
     r->fb = nullptr;
     VR_HIP(r, hipMalloc((void **)&r->fb, (size_t)w * h * sizeof(float4)));
     VR_HIP(r, hipMemsetAsync(r->fb, 0, (size_t)w * h * sizeof(float4), r->stream));
+    if (r->cost) VR_HIP(r, hipFree(r->cost));
+    r->cost = nullptr;
+    VR_HIP(r, hipMalloc((void **)&r->cost, (size_t)w * h * sizeof(uint16_t)));
+    VR_HIP(r, hipMemsetAsync(r->cost, 0, (size_t)w * h * sizeof(uint16_t), r->stream));
     r->fb_w = w;
     r->fb_h = h;
     return VRHIP_OK;
@@ -443,6 +450,9 @@ int ensure_queue(vrhip_renderer *r, uint32_t W, uint32_t H, uint32_t tile_w, uin
         r->cont = nullptr;
         r->cont_cap = 0;
         VR_HIP(r, hipMalloc((void **)&r->cont, need * sizeof(ContRec)));
+        if (r->order) VR_HIP(r, hipFree(r->order));
+        r->order = nullptr;
+        VR_HIP(r, hipMalloc((void **)&r->order, need * sizeof(uint32_t)));
         r->cont_cap = need;
     }
     return VRHIP_OK;
@@ -474,6 +484,9 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
     a->frame.cont_count = r->queue_head + 1;
     a->frame.cont_head = r->queue_head + 2;
     a->frame.round_budget = r->cont ? r->round_budget : 0;
+    a->frame.cost = r->sort_cont ? r->cost : nullptr;
+    a->frame.order = r->sort_cont && r->cost ? r->order : nullptr;
+    a->frame.sort_ws = r->queue_head + 4;
     a->frame.fb = r->fb;
     a->cam = r->cam;
     a->render = r->render;
@@ -492,7 +505,7 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
 int launch_timed(vrhip_renderer *r, const RaycastLaunch &a)
 {
     if (a.instr) VR_HIP(r, hipMemsetAsync(r->stats_dev, 0, sizeof(DevStats), r->stream));
-    VR_HIP(r, hipMemsetAsync(r->queue_head, 0, 4 * sizeof(uint32_t), r->stream));
+    VR_HIP(r, hipMemsetAsync(r->queue_head, 0, kControlWords * sizeof(uint32_t), r->stream));
     VR_HIP(r, hipEventRecord(r->ev0, r->stream));
     RaycastLaunch b = a;
     b.mid_event = r->evm;
@@ -555,7 +568,7 @@ int count_touched_impl(vrhip_renderer *r, uint32_t width, uint32_t height, uint3
     a.frame.fb = scratch;
     if (e == hipSuccess) e = hipMemsetAsync(r->stats_dev, 0, sizeof(DevStats), r->stream);
     a.frame.round_budget = 0;   // the traffic pass runs single-phase (no speculative touches)
-    if (e == hipSuccess) e = hipMemsetAsync(r->queue_head, 0, 4 * sizeof(uint32_t), r->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(r->queue_head, 0, kControlWords * sizeof(uint32_t), r->stream);
     if (e == hipSuccess) e = vr_launch_frame(a, r->stream);
     std::vector<uint32_t> host(words);
     if (e == hipSuccess)
@@ -602,13 +615,14 @@ int vrhip_create(int device_id, vrhip_renderer **out)
         (e = hipEventCreate(&r->evb0)) != hipSuccess ||
         (e = hipEventCreate(&r->evb1)) != hipSuccess ||
         (e = hipMalloc((void **)&r->stats_dev, sizeof(DevStats))) != hipSuccess ||
-        (e = hipMalloc((void **)&r->queue_head, 4 * sizeof(uint32_t))) != hipSuccess) {
+        (e = hipMalloc((void **)&r->queue_head, kControlWords * sizeof(uint32_t))) != hipSuccess) {
         std::string msg = std::string("ERROR: vrhip_create (") + hipGetErrorString(e) + ")";
         delete r;
         return fail(nullptr, VRHIP_ERR_HIP, msg);
     }
     r->stream = r->own_stream;
     if (const char *b = getenv("VRHIP_ROUND_BUDGET")) r->round_budget = (uint32_t)atoi(b);   // tuning
+    if (getenv("VRHIP_NO_SORT")) r->sort_cont = false;         // experiments: phase 2 in append order
     if (getenv("VRHIP_PT_NO_CULL")) r->pt_cull = false;        // experiments: no opacity-bound culling
     if (getenv("VRHIP_NO_EMPTY_SKIP")) r->skip_empty = false;  // experiments: no empty-run skipping
     r->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -630,6 +644,8 @@ void vrhip_destroy(vrhip_renderer *r)
     if (r->queue_dev) (void)hipFree(r->queue_dev);
     if (r->queue_head) (void)hipFree(r->queue_head);
     if (r->cont) (void)hipFree(r->cont);
+    if (r->cost) (void)hipFree(r->cost);
+    if (r->order) (void)hipFree(r->order);
     if (r->skip_bits) (void)hipFree(r->skip_bits);
     if (r->cell_bound) (void)hipFree(r->cell_bound);
     if (r->cell_empty) (void)hipFree(r->cell_empty);
