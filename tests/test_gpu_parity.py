@@ -137,6 +137,30 @@ def test_pathtrace_accumulates_like_oracle(vr):
     vr.setIteration(0)
 
 
+@pytest.mark.parametrize("view", ["far", "rot30", "close", "inside", "offaxis"])
+def test_uninstrumented_frame_matches_oracle(vr, view):
+    """The production kernels (no statistics): DDA pre-pass + live patch list, phase 1, sorted
+    phase 2.  Most other parity cases run the instrumented variants, which skip the pre-pass."""
+    vol = common.noise_volume((64, 64, 64), UCHAR, seed=31, smooth=True)
+    vol[vol < 60] = 0
+    table = common.tffs()["default"]
+    views = dict(common.views())
+    views["far"] = frontend.view_matrix(translation=(0.0, 0.0, 6.0))
+    views["offaxis"] = frontend.view_matrix(frontend.quat_from_axis_angle((0.3, 1, 0.2), 70.0),
+                                            translation=(0.9, -0.6, 3.5))
+    W, H = 200, 136
+    _setup(vr, vol, UCHAR, table, views[view])
+    vr.setStatsEnabled(False)
+    ref = None
+    for it in range(2):     # second frame: accumulation + phase-2 order from the first frame's costs
+        vr.setIteration(it)
+        got = vr.runRaycastNoGL(W, H)
+        vr.setIteration(it)
+        ref, _, _ = common.oracle_frame(vr, vol, UCHAR, table, W, H, in_accum=ref)
+        np.testing.assert_array_equal(got, ref)
+    vr.setIteration(0)
+
+
 def test_empty_skipping_is_exact(vr, monkeypatch):
     """Ray caster: stepping over runs of samples in empty cells (opacity exactly 0) leaves the
     image and every work counter unchanged."""

@@ -55,6 +55,12 @@ struct WaveTile {
     uint32_t out_base;     // index of its first pixel in FrameView::out
 };
 
+// A patch with at least one ray that reaches a non-skipped brick (DDA pre-pass), and which rays.
+struct LiveTile {
+    WaveTile wt;
+    uint32_t mask_lo, mask_hi;   // bit = lane (8 * row + column) of the patch
+};
+
 // Dynamic state of a suspended ray (two-phase march): everything else is recomputed from the
 // pixel.  64 bytes.
 struct ContRec {
@@ -82,6 +88,11 @@ struct FrameView {
     uint32_t *cont_count;  // zeroed before each launch
     uint32_t *cont_head;   // zeroed before each launch
     uint32_t round_budget;
+    // DDA pre-pass (ESS, un-instrumented): a light, high-occupancy kernel walks every ray to its
+    // first non-skipped brick; rays that never reach one get their (background) pixel there and
+    // phase 1 only visits the patches listed in `live`.  nullptr: phase 1 walks the whole queue.
+    LiveTile *live;
+    uint32_t *live_count;  // zeroed before each launch
     // Phase-2 scheduling: `cost` keeps, per pixel, the phase-2 rounds the pixel's ray needed in the
     // previous frame.  Suspended rays are sorted by it, longest first (counting sort into
     // `order`), so that the longest chains start first and the 16 rays of a group are alike.

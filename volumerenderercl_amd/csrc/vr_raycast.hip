@@ -504,6 +504,51 @@ VR_DEV void flush_counters(DevStats *stats, uint32_t lane, const unsigned long l
     }
 }
 
+// ------------------------------------------------------------------ DDA pre-pass
+
+// Most rays of a typical frame cross the volume without ever meeting a brick the ESS bitmap
+// does not skip: all they do is the DDA walk.  In the marching kernels (two waves per SIMD) that
+// walk is a latency chain; here it runs alone in a kernel small enough for high occupancy (the
+// bitmap is read through the caches).  One wave per 8x8 patch, same set-up and dda_step as the
+// march, hence the same decisions.  Rays that end without a sample write their pixel here;
+// patches with rays that reach a brick to sample go to the `live` list for phase 1.
+template <typename VT>
+__global__ __launch_bounds__(kBlockDim) void vr_dda_prepass_kernel(
+    VolView vv, BrickView bricks, SkipView skip, FrameView fr, vrhip_camera_params cam,
+    vrhip_rendering_params rp, vrhip_raycast_params rc)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t q = blockIdx.x * (kBlockDim / 64) + (threadIdx.x >> 6);
+    if (q >= fr.n_wave_tiles) return;
+    const WaveTile wt = fr.queue[q];
+    const uint32_t lx = lane & 7u, ly = lane >> 3;
+    const uint32_t gx = (uint32_t)wt.tx8 * 8u + lx, gy = (uint32_t)wt.ty8 * 8u + ly;
+    const bool inside = gx < fr.W && gy < fr.H;
+    const f3 resf = mk3(vv.fw, vv.fh, vv.fd);
+    const f3 voxLen = mk3(1.f / vv.fw, 1.f / vv.fh, 1.f / vv.fd);
+    const Grid grid = make_grid(bricks, rc, skip.n_words, true);
+    RayCtx c;
+    RayDyn d;
+    setup_ray<true>(gx, gy, inside, fr, cam, rp, rc, resf, voxLen, grid, c, d);
+    fetch_skip_word(skip.bits, grid, d);
+    unsigned long long n0 = 0, n1 = 0;
+    while (__ballot(d.state == S_BRICK)) dda_step<0>(skip.bits, grid, c, d, n0, n1);
+    const bool live = d.state == S_SAMPLE;
+    const unsigned long long m = __ballot(live);
+    if (inside && !live) {
+        // what the march would leave for a ray without samples: background colour, alpha 0
+        write_pixel(fr, rp, c, d, gx, gy, (size_t)wt.out_base + (size_t)ly * fr.out_stride + lx);
+    }
+    if (m && lane == 0) {
+        const uint32_t slot = atomicAdd(fr.live_count, 1u);
+        LiveTile lt;
+        lt.wt = wt;
+        lt.mask_lo = (uint32_t)m;
+        lt.mask_hi = (uint32_t)(m >> 32);
+        fr.live[slot] = lt;
+    }
+}
+
 // ------------------------------------------------------------------ phase 1
 
 template <typename VT, bool ESS, int INSTR, bool SKIP_LDS>
@@ -541,12 +586,22 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_kernel(
     // every wave pulls 8x8 patches until the queue is drained (exit condition reached by every
     // wave: the head only grows).  The next ticket is drawn while the current patch is marched,
     // which hides the contended atomic; every wave draws exactly one ticket past the end.
+    const bool use_live = ESS && INSTR == 0 && fr.live != nullptr;
+    const uint32_t n_tiles = use_live ? *fr.live_count : fr.n_wave_tiles;
     uint32_t q_next = 0;
     if (lane == 0) q_next = atomicAdd(fr.queue_head, 1u);
     for (;;) {
         const uint32_t q = __builtin_amdgcn_readfirstlane(q_next);
-        if (q >= fr.n_wave_tiles) break;
-        const WaveTile wt = fr.queue[q];
+        if (q >= n_tiles) break;
+        WaveTile wt;
+        unsigned long long live_mask = ~0ull;
+        if (use_live) {
+            const LiveTile lt = fr.live[q];
+            wt = lt.wt;
+            live_mask = (unsigned long long)lt.mask_lo | ((unsigned long long)lt.mask_hi << 32);
+        } else {
+            wt = fr.queue[q];
+        }
         if (lane == 0) q_next = atomicAdd(fr.queue_head, 1u);
         VR_STAMP(0);
         VR_COUNT(11);
@@ -557,6 +612,9 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_kernel(
         RayCtx c;
         RayDyn d;
         setup_ray<ESS>(gx, gy, inside, fr, cam, rp, rc, resf, voxLen, grid, c, d);
+        // rays the pre-pass has finished (their pixel is written) stay out of the march
+        const bool prepass_done = !((live_mask >> lane) & 1ull);
+        if (prepass_done) d.state = S_DONE;
         if (ESS) fetch_skip_word(sb, grid, d);
         if (INSTR && c.valid) { c_hit++; c_nominal += (unsigned long long)c.nominal; }
         VR_STAMP(1);
@@ -646,7 +704,7 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_kernel(
                 fr.cont[base + rank] = r;
             }
         }
-        if (inside && !cont)
+        if (inside && !cont && !prepass_done)
             write_pixel(fr, rp, c, d, gx, gy, (size_t)wt.out_base + (size_t)ly * fr.out_stride + lx);
         VR_STAMP(7);
     }
@@ -940,7 +998,16 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
     uint32_t cap = cus * (uint32_t)nb1;
     dim3 grid(want < cap ? want : cap), block(kBlockDim);
     if (grid.x == 0) return hipSuccess;
-    hipLaunchKernelGGL(k1, grid, block, lds, stream, a.vol, a.bricks, a.tf, a.skip, a.cells, a.frame, a.cam,
+    FrameView frame = a.frame;
+    if (ESS && INSTR == 0 && frame.live) {
+        hipLaunchKernelGGL(vr_dda_prepass_kernel<VT>, dim3(want), block, 0, stream, a.vol, a.bricks,
+                           a.skip, frame, a.cam, a.render, a.raycast);
+        hipError_t pe = hipGetLastError();
+        if (pe != hipSuccess) return pe;
+    } else {
+        frame.live = nullptr;
+    }
+    hipLaunchKernelGGL(k1, grid, block, lds, stream, a.vol, a.bricks, a.tf, a.skip, a.cells, frame, a.cam,
                        a.render, a.raycast, a.stats, a.touched);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && a.mid_event) e = hipEventRecord(a.mid_event, stream);
@@ -956,7 +1023,7 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
     }
     // phase 2: persistent grid; exits at once when nothing was suspended
     dim3 grid2(cus * (uint32_t)nb2);
-    hipLaunchKernelGGL(k2, grid2, block, lds, stream, a.vol, a.bricks, a.tf, a.skip, a.cells, a.frame, a.cam,
+    hipLaunchKernelGGL(k2, grid2, block, lds, stream, a.vol, a.bricks, a.tf, a.skip, a.cells, frame, a.cam,
                        a.render, a.raycast, a.stats, a.touched);
     return hipGetLastError();
 }

@@ -88,6 +88,8 @@ struct vrhip_renderer {
     uint16_t *cost = nullptr;         // per pixel: phase-2 rounds of the previous frame (sort key)
     uint32_t *order = nullptr;        // sorted permutation of the suspended rays
     bool sort_cont = true;            // VRHIP_NO_SORT=1 disables
+    LiveTile *live = nullptr;         // DDA pre-pass output: patches with rays that sample
+    bool prepass = true;              // VRHIP_NO_PREPASS=1 disables
     ContRec *cont = nullptr;          // suspended rays of the two-phase march
     size_t cont_cap = 0;
     uint32_t round_budget = 16;       // phase-1 sample rounds per patch (0 = single phase)
@@ -435,6 +437,9 @@ int ensure_queue(vrhip_renderer *r, uint32_t W, uint32_t H, uint32_t tile_w, uin
     if (q.size() > r->queue_cap) {
         if (r->queue_dev) VR_HIP(r, hipFree(r->queue_dev));
         r->queue_dev = nullptr;
+        if (r->live) VR_HIP(r, hipFree(r->live));
+        r->live = nullptr;
+        VR_HIP(r, hipMalloc((void **)&r->live, q.size() * sizeof(LiveTile)));
         VR_HIP(r, hipMalloc((void **)&r->queue_dev, q.size() * sizeof(WaveTile)));
         r->queue_cap = (uint32_t)q.size();
     }
@@ -484,6 +489,8 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
     a->frame.cont_count = r->queue_head + 1;
     a->frame.cont_head = r->queue_head + 2;
     a->frame.round_budget = r->cont ? r->round_budget : 0;
+    a->frame.live = r->prepass ? r->live : nullptr;
+    a->frame.live_count = r->queue_head + 3;
     a->frame.cost = r->sort_cont ? r->cost : nullptr;
     a->frame.order = r->sort_cont && r->cost ? r->order : nullptr;
     a->frame.sort_ws = r->queue_head + 4;
@@ -622,6 +629,7 @@ int vrhip_create(int device_id, vrhip_renderer **out)
     }
     r->stream = r->own_stream;
     if (const char *b = getenv("VRHIP_ROUND_BUDGET")) r->round_budget = (uint32_t)atoi(b);   // tuning
+    if (getenv("VRHIP_NO_PREPASS")) r->prepass = false;        // experiments: phase 1 walks every patch
     if (getenv("VRHIP_NO_SORT")) r->sort_cont = false;         // experiments: phase 2 in append order
     if (getenv("VRHIP_PT_NO_CULL")) r->pt_cull = false;        // experiments: no opacity-bound culling
     if (getenv("VRHIP_NO_EMPTY_SKIP")) r->skip_empty = false;  // experiments: no empty-run skipping
@@ -645,6 +653,7 @@ void vrhip_destroy(vrhip_renderer *r)
     if (r->queue_head) (void)hipFree(r->queue_head);
     if (r->cont) (void)hipFree(r->cont);
     if (r->cost) (void)hipFree(r->cost);
+    if (r->live) (void)hipFree(r->live);
     if (r->order) (void)hipFree(r->order);
     if (r->skip_bits) (void)hipFree(r->skip_bits);
     if (r->cell_bound) (void)hipFree(r->cell_bound);
