@@ -410,6 +410,32 @@ VR_DEV bool skip_empty_run(uint32_t mask, const RayCtx &c, RayDyn &d, bool count
     return run;
 }
 
+// Phase 2: the four lanes of a ray look at four consecutive windows of kLook samples; the run is
+// then stepped over in chunks of kLook for as long as some ray of the wave is still skipping.
+VR_DEV bool skip_empty_run_wide(unsigned long long mask, const RayCtx &c, RayDyn &d, bool count,
+                                unsigned long long &c_taken)
+{
+    bool run = d.state == S_SAMPLE;
+    float tk = d.t;
+    for (int chunk = 0; chunk < 4; ++chunk) {
+        if (!__ballot(run)) break;
+        const uint32_t m = (uint32_t)(mask >> (kLook * chunk));
+#pragma unroll
+        for (int k = 0; k < kLook; ++k) {
+            if (run) {
+                if (!(tk < d.t_exit) || !((m >> k) & 1u)) run = false;
+                else {
+                    if (count) c_taken++;
+                    VR_RAYLEN_INC(d);
+                    if (tk >= c.tfar) { d.state = S_DONE; run = false; }
+                    else { tk = tk + c.stepSize; d.t = tk; }
+                }
+            }
+        }
+    }
+    return run;
+}
+
 // The lookahead costs a few hundred instructions for the whole wave: it runs when at least half
 // of the sampling lanes expect their next sample to be empty (their last one was).
 VR_DEV bool lookahead_pays(bool sampling, bool guess_empty)
@@ -825,10 +851,18 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
             bool more_empty = false;
             if (skip_empty && lookahead_pays(d.state == S_SAMPLE, guess_empty)) {
                 if (d.state == S_SAMPLE) {
-                    // the four lanes of a ray hold the same state and take the same decisions
-                    const uint32_t em = empty_mask<VT, INSTR>(cells, vol, c, d.t);
-                    more_empty = skip_empty_run(em, c, d, count, c_taken);
-                    guess_empty = (em & 1u) != 0u;
+                    // the four lanes of a ray hold the same state and take the same decisions;
+                    // lane `slot` looks at samples [kLook * slot, kLook * (slot + 1)) of the run
+                    // (its window start is approximate, which is all the cell lookup needs)
+                    const float t_win = d.t + (float)(kLook * (int)slot) * c.stepSize;
+                    const int em = (int)empty_mask<VT, INSTR>(cells, vol, c, t_win);
+                    const unsigned long long m64 =
+                        (unsigned long long)(uint32_t)quad_bcast<0>(em) |
+                        ((unsigned long long)(uint32_t)quad_bcast<1>(em) << 16) |
+                        ((unsigned long long)(uint32_t)quad_bcast<2>(em) << 32) |
+                        ((unsigned long long)(uint32_t)quad_bcast<3>(em) << 48);
+                    more_empty = skip_empty_run_wide(m64, c, d, count, c_taken);
+                    guess_empty = (m64 & 1ull) != 0ull;
                     after_segment<ESS>(c, d);
                 }
             }

@@ -92,7 +92,7 @@ struct vrhip_renderer {
     bool prepass = true;              // VRHIP_NO_PREPASS=1 disables
     ContRec *cont = nullptr;          // suspended rays of the two-phase march
     size_t cont_cap = 0;
-    uint32_t round_budget = 16;       // phase-1 sample rounds per patch (0 = single phase)
+    uint32_t round_budget = 10;       // phase-1 sample rounds per patch (0 = single phase)
     std::vector<uint32_t> queue_key;   // W, H, tile_w, tile_h, tile ids...
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr, evb0 = nullptr, evb1 = nullptr;
