@@ -246,15 +246,19 @@ def main():
         roofline = {
             "kernel": ("vr_pathtrace_kernel <%s>, one launch per sample-per-pixel pass" % fmt_name.lower())
                       if technique == 1 else
-                      "ray-cast pass = vr_raycast_kernel + vr_raycast_split_kernel <%s, ESS=%s>, "
-                      "two back-to-back launches per frame" % (fmt_name.lower(), ess),
+                      "ray-cast pass <%s, ESS=%s> = vr_dda_prepass_kernel + vr_raycast_kernel + "
+                      "(counting sort) + vr_raycast_split_kernel, back-to-back launches per frame"
+                      % (fmt_name.lower(), ess),
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic["hbm_bytes_per_pass"] if traffic else None,
-            "traffic_detail": traffic,
+            "traffic_detail": ({k: traffic.get(k) for k in ("source", "fetch_bytes_raw_per_pass",
+                                                             "write_bytes_per_pass", "fetch_correction",
+                                                             "calibration", "note")}
+                               if traffic else None),
             "algorithmic_bytes_per_launch": int(alg_bytes),
             "avg_launch_ms": kernel_s * 1e3,
             "last_pass_ms_hip_events": {"phase1": last_phases[0] * 1e3, "phase2": last_phases[1] * 1e3,

@@ -49,8 +49,11 @@ def main():
         raw = res["kernels"][bb[0]]["FETCH_SIZE"]["avg_KiB_per_dispatch"] * 1024.0
         res["calibration"] = {"kernel": bb[0], "known_read_bytes": volume_bytes,
                               "FETCH_SIZE_bytes_raw": raw, "measured_factor": volume_bytes / raw}
-    p1 = [k for k in res["kernels"] if k.startswith("vr_raycast_kernel") and ", 0, " in k]
-    p2 = [k for k in res["kernels"] if k.startswith("vr_raycast_split_kernel") and ", 0, " in k]
+    # every launch of the timed (un-instrumented) pass: pre-pass, phase 1, sort, phase 2
+    p1 = [k for k in res["kernels"] if (k.startswith("vr_raycast_kernel") and ", 0, " in k)
+          or k.startswith("vr_dda_prepass_kernel") or k.startswith("vr_pathtrace_kernel") and ", 0>" in k]
+    p2 = [k for k in res["kernels"] if (k.startswith("vr_raycast_split_kernel") and ", 0, " in k)
+          or k.startswith("vr_cont_")]
     fetch = sum(res["kernels"][k]["FETCH_SIZE"]["avg_KiB_per_dispatch"] for k in p1 + p2) * 1024.0
     write = sum(res["kernels"][k]["WRITE_SIZE"]["avg_KiB_per_dispatch"] for k in p1 + p2) * 1024.0
     res["fetch_bytes_raw_per_pass"] = fetch

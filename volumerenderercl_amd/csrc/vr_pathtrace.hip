@@ -217,10 +217,18 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
             // majorant cull: no value a fetch in this cell can return maps to an opacity that
             // reaches the walk's threshold -> the step is a rejection whatever the voxels hold
             if (cull) {
+                // cell of step k from the walk's texel-space line u(t) = a + b * t (one fma per
+                // axis; exact to far better than the texel of halo the cells carry)
+                const float hx = 0.5f * vol.fw, hy = 0.5f * vol.fh, hz = 0.5f * vol.fd;
+                const float ax = __builtin_fmaf(px.org.x, hx, hx - 0.5f), bx = px.wdir.x * hx;
+                const float ay = __builtin_fmaf(px.org.y, hy, hy - 0.5f), by = px.wdir.y * hy;
+                const float az = __builtin_fmaf(px.org.z, hz, hz - 0.5f), bz = px.wdir.z * hz;
                 float bnd[B];
 #pragma unroll
                 for (int k = 0; k < B; ++k)
-                    bnd[k] = grid.bound[vol.cell_index(sk[k].x, sk[k].y, sk[k].z, grid)];
+                    bnd[k] = grid.bound[vol.cell_index_texel(__builtin_fmaf(bx, tk[k], ax),
+                                                             __builtin_fmaf(by, tk[k], ay),
+                                                             __builtin_fmaf(bz, tk[k], az), grid)];
 #pragma unroll
                 for (int k = 0; k < B; ++k) need[k] = need[k] && !(bnd[k] < px.thr);
             }

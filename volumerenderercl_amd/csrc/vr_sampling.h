@@ -124,6 +124,16 @@ struct Vol {
                    (uint32_t)g.cx + (uint32_t)(x0 >> g.shift);
     }
 
+    // the same from texel-space coordinates (u = px * fw - 0.5 ...) that need only be good to a
+    // texel: the cells' extents carry a one-texel halo (CellView)
+    VR_DEV uint32_t cell_index_texel(float u, float v, float s, const CellView &g) const
+    {
+        const int x0 = iclamp((int)floorf(u), 0, w1), y0 = iclamp((int)floorf(v), 0, h1);
+        const int z0 = iclamp((int)floorf(s), 0, d1);
+        return ((uint32_t)(z0 >> g.shift) * (uint32_t)g.cy + (uint32_t)(y0 >> g.shift)) *
+                   (uint32_t)g.cx + (uint32_t)(x0 >> g.shift);
+    }
+
     // -gradientCentralDiff(vol, pos).xyz (volumeraycast.cl:159-178, :814).  The six taps sit
     // exactly one texel from the centre sample (offset = 1/volRes, :162): they are evaluated
     // in texel space -- the centre's filter weights with indices shifted by -+1 and clamped to
