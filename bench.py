@@ -138,11 +138,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
         args.gpus = world
+    # rehearsal knob for a one-GPU box: every rank on device 0 over gloo (RCCL refuses two ranks
+    # on one device); the driver's multi-GPU runs use one GPU per rank and RCCL
+    rehearsal = os.environ.get("VRHIP_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     from volumerenderercl_amd import VolumeRenderCL, frontend
     from volumerenderercl_amd import tiles as vtiles
@@ -181,6 +189,11 @@ def main():
         vr.setIteration(k if technique == 1 else 0)   # path tracer: progressive running mean
         return driver.render_frame(frame)
 
+    def submit(seed, k=0):   # world > 1: render my tiles of the frame and start its gather
+        vr.setSeed(seed)
+        vr.setIteration(k if technique == 1 else 0)
+        driver.submit()
+
     for k in range(args.warmup):
         render(seeds[k])
     torch.cuda.synchronize(dev)
@@ -190,8 +203,16 @@ def main():
     ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(stream)
-    for k in range(args.steps):
-        render(seeds[args.warmup + k], k)
+    if world == 1:
+        for k in range(args.steps):
+            render(seeds[args.warmup + k], k)
+    else:
+        # one frame in flight: the gather + assembly of frame k overlap the rendering of k + 1
+        submit(seeds[args.warmup], 0)
+        for k in range(1, args.steps):
+            submit(seeds[args.warmup + k], k)
+            driver.collect(frame)
+        driver.collect(frame)
     ev1.record(stream)
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -302,7 +323,7 @@ def main():
                                H + (8 - H % 8), args.view, tff_name, illum, "on" if ess else "off")
                             + (" -- technique 1 (path tracer, max_extinction 100): illumType/ESS/ERT/"
                                "samplingRate unused" if technique == 1 else ""),
-                "parallelism": "tiles%dx%d/%d ranks, volume replicated, RCCL gather" % (
+                "parallelism": "tiles%dx%d/%d ranks, volume replicated, RCCL gather (one frame in flight)" % (
                     args.tile, args.tile, world) if world > 1 else "single GPU, full frame",
             },
             "msamples_nominal_per_s": work["samples_nominal"] / wall / 1e6,

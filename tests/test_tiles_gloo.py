@@ -49,8 +49,20 @@ def _worker(rank, world, port, W, H, T, q):
     frame = torch.zeros((H, W, 4)) if rank == 0 else None
     for _ in range(2):   # two frames: buffers are reusable
         out = drv.render_frame(frame)
+    first = out.numpy().copy() if rank == 0 else None
+    # pipelined: one frame in flight while the next is rendered
+    outs = []
+    drv.submit()
+    for k in range(3):
+        if k < 2:
+            drv.submit()
+        o = drv.collect(frame)
+        if rank == 0:
+            outs.append(o.numpy().copy())
     if rank == 0:
-        q.put(out.numpy().copy())
+        for o in outs:
+            np.testing.assert_array_equal(o, first)
+        q.put(first)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -32,10 +32,19 @@ class TileSplit:
 
 
 class TileDriver:
-    """Renders one frame: full-frame launch at world == 1, tiles + gather otherwise.
+    """Renders frames: full-frame launch at world == 1, tiles + gather otherwise.
 
     `render_tiles_fn(tile_ids, out)` fills out[k] (tile_h x tile_w x 4 floats) for tile k;
-    the default drives vrhip_render_tiles on the renderer's GPU."""
+    the default drives vrhip_render_tiles on the renderer's GPU.
+
+    Two ways to drive it:
+      * render_frame(frame): one frame, synchronous (render, gather, assemble);
+      * submit() / collect(frame): pipelined -- submit() renders this rank's tiles of the next
+        frame into one of two buffers and starts the gather asynchronously (RCCL runs it on its
+        own stream), collect() waits for the oldest gather in flight and assembles that frame
+        on rank 0.  With one frame in flight the gather + assembly of frame k overlap the
+        rendering of frame k + 1, so the frame rate is set by the slower of the two, not their sum.
+    """
 
     def __init__(self, vr, split, device, render_tiles_fn=None, dist=None):
         import torch
@@ -46,20 +55,61 @@ class TileDriver:
         if dist is None and s.world > 1:
             import torch.distributed as dist
         self.dist = dist
+        self.pending = []          # (buffer index, work handle) of the gathers in flight
+        self.next_buf = 0
         if s.world > 1:
-            self.local = torch.zeros((s.cap, s.th, s.tw, 4), dtype=torch.float32, device=device)
+            self.local = [torch.zeros((s.cap, s.th, s.tw, 4), dtype=torch.float32, device=device)
+                          for _ in range(2)]
             if s.rank == 0:
-                self.staging = [torch.zeros_like(self.local) for _ in range(s.world)]
-                # padded frame viewed as [tiles_y, tiles_x, th, tw, 4]
-                self.padded = torch.zeros((s.tiles_y * s.th, s.tiles_x * s.tw, 4),
-                                          dtype=torch.float32, device=device)
-                self.tile_view = self.padded.view(s.tiles_y, s.th, s.tiles_x, s.tw, 4).permute(
-                    0, 2, 1, 3, 4)
-                self.idx = []
+                # one block per buffer: [rank, slot, th, tw, 4]; the gather writes rank r's
+                # tiles into staging[b][r]
+                self.staging = [torch.zeros((s.world, s.cap, s.th, s.tw, 4), dtype=torch.float32,
+                                            device=device) for _ in range(2)]
+                # tile id -> row of staging.view(world * cap, ...)
+                perm = np.zeros(s.n_tiles, dtype=np.int64)
                 for r in range(s.world):
-                    t = torch.as_tensor(s.tiles_of[r].astype(np.int64), device=device)
-                    self.idx.append((t // s.tiles_x, t % s.tiles_x))
+                    perm[s.tiles_of[r].astype(np.int64)] = r * s.cap + np.arange(len(s.tiles_of[r]))
+                self.perm = torch.as_tensor(perm, device=device)
+                self.exact = (s.W % s.tw == 0) and (s.H % s.th == 0)
+                if not self.exact:
+                    self.padded = torch.zeros((s.tiles_y * s.th, s.tiles_x * s.tw, 4),
+                                              dtype=torch.float32, device=device)
 
+    # ---- pipelined interface
+    def submit(self):
+        """Render this rank's tiles of the next frame and start its gather (world > 1)."""
+        s = self.split
+        if s.world == 1:
+            raise RuntimeError("submit/collect are for world > 1; use render_frame")
+        if len(self.pending) >= 2:
+            raise RuntimeError("two frames already in flight: collect() first")
+        b = self.next_buf
+        self.next_buf ^= 1
+        if self.render_tiles_fn is None:
+            self.vr.render_tiles(s.W, s.H, s.tw, s.th, s.my_tiles, self.local[b].data_ptr())
+        else:
+            self.render_tiles_fn(s.my_tiles, self.local[b])
+        glist = [self.staging[b][r] for r in range(s.world)] if s.rank == 0 else None
+        work = self.dist.gather(self.local[b], glist, dst=0, async_op=True)
+        self.pending.append((b, work))
+
+    def collect(self, frame):
+        """Finish the oldest frame in flight; returns the assembled frame on rank 0."""
+        s = self.split
+        b, work = self.pending.pop(0)
+        work.wait()
+        if s.rank != 0:
+            return None
+        tiles_sorted = self.staging[b].view(s.world * s.cap, s.th, s.tw, 4).index_select(0, self.perm)
+        tv = tiles_sorted.view(s.tiles_y, s.tiles_x, s.th, s.tw, 4).permute(0, 2, 1, 3, 4)
+        if self.exact:
+            frame.view(s.tiles_y, s.th, s.tiles_x, s.tw, 4).copy_(tv)
+        else:
+            self.padded.view(s.tiles_y, s.th, s.tiles_x, s.tw, 4).copy_(tv)
+            frame.copy_(self.padded[: s.H, : s.W])
+        return frame
+
+    # ---- one synchronous frame
     def render_frame(self, frame):
         """Returns the assembled H x W x 4 frame on rank 0 (None elsewhere)."""
         s = self.split
@@ -74,15 +124,5 @@ class TileDriver:
                 x0, y0, w, h = s.tile_rect(t)
                 frame[y0:y0 + h, x0:x0 + w] = out[k, :h, :w]
             return frame
-        if self.render_tiles_fn is None:
-            self.vr.render_tiles(s.W, s.H, s.tw, s.th, s.my_tiles, self.local.data_ptr())
-        else:
-            self.render_tiles_fn(s.my_tiles, self.local)
-        self.dist.gather(self.local, self.staging if s.rank == 0 else None, dst=0)
-        if s.rank != 0:
-            return None
-        for r in range(s.world):
-            ty, tx = self.idx[r]
-            self.tile_view[ty, tx] = self.staging[r][: len(s.tiles_of[r])]
-        frame.copy_(self.padded[: s.H, : s.W])
-        return frame
+        self.submit()
+        return self.collect(frame)
