@@ -70,7 +70,12 @@ typedef struct vrhip_pathtrace_params {
     float max_extinction;
 } vrhip_pathtrace_params;
 
-/* Work counters of the last instrumented render (SURVEY 8d "sample" definitions). */
+/* Work counters of the last instrumented render (SURVEY 8d "sample" definitions).
+ * technique 0: samples = executions of the inner loop body (volumeraycast.cl:790-880), bricks =
+ * DDA steps / steps skipped by ESS.  technique 1: samples_taken = tracking steps inside the
+ * volume (sample_interaction :419-431); the two brick counters are reused for the opacity-bound
+ * culling: bricks_visited = steps whose bound was consulted, bricks_skipped = steps whose voxel
+ * fetch was skipped; samples_nominal and samples_shaded stay 0. */
 typedef struct vrhip_stats {
     uint64_t samples_taken;
     uint64_t samples_nominal;
