@@ -447,3 +447,40 @@ def test_cpp_host_cli_matches_oracle(tmp_path):
     rc.brickRes[:] = brf + [0]
     ref, _, _ = vro.render_tile(vol, vro.UCHAR, tff, cam, rp, rc, W=W, H=H)
     assert np.abs(got - ref).max() <= TOL
+
+
+def test_cpp_host_cli_pathtrace_matches_oracle(tmp_path):
+    """Headless path tracing through the C++ host: 3 samples per pixel accumulated with the
+    std::mt19937 seed stream of the reference's VolumeRenderCL member."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "volumerenderercl_amd", "vrhip_render")
+    out = str(tmp_path / "pt")
+    W, H, N = 64, 48, 32
+    cmd = [exe, "--synth", "sphere", str(N), "FLOAT", "--size", str(W), str(H), "--rotate", "1", "1",
+           "0", "30", "--pathtrace", "--extinction", "60", "--frames", "3", "--out", out]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    got = np.fromfile(out + ".rgba.f32", dtype=np.float32).reshape(H, W, 4)
+    vol = vro.synth_volume("sphere", [N, N, N], vro.FLOAT)
+    tff = frontend.tff_from_stops()
+    cam = vro.CameraParams()
+    cam.viewMat[:] = frontend.view_matrix(frontend.quat_from_axis_angle((1, 1, 0), 30.0))
+    cam.bbox_bl[:] = [-1, -1, -1, 0]
+    cam.bbox_tr[:] = [1, 1, 1, 0]
+    rp = vro.RenderingParams()
+    rp.backgroundColor[:] = [1, 1, 1, 0]
+    rp.modelScale[:] = [1, 1, 1, 0]
+    rp.illumType, rp.useLinear, rp.technique = 1, 1, 1
+    rc = vro.RaycastParams()
+    rc.samplingRate = 1.5
+    _, brf, _ = vro.brick_layout([N, N, N])
+    rc.brickRes[:] = brf + [0]
+    mt = frontend.Mt19937()
+    ref = None
+    for it in range(3):
+        rp.seed, rp.iteration = mt(), it
+        ref, _, _ = vro.render_tile(vol, vro.FLOAT, tff, cam, rp, rc, pt=vro.PathtraceParams(60.0),
+                                    W=W, H=H, in_accum=ref)
+    assert np.abs(got - ref).max() <= TOL

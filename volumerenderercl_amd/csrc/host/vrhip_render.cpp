@@ -96,6 +96,7 @@ void write_ppm(const std::string &path, const std::vector<float> &rgba, size_t w
         "         [--size W H] [--rotate AX AY AZ DEG] [--translate X Y Z] [--view M0..M15]\n"
         "         [--tf default|FILE] [--illum N] [--no-ess] [--ortho] [--nearest] [--rate R]\n"
         "         [--bg R G B] [--gradient-bg] [--seed S] [--frames N] [--device D] --out PREFIX\n"
+        "         [--pathtrace] [--extinction E]   (technique 1; --frames = samples per pixel)\n"
         "writes PREFIX.rgba.f32 (W*H*4 float32, row 0 = top), PREFIX.ppm and prints one JSON line\n";
     std::exit(2);
 }
@@ -109,6 +110,8 @@ int main(int argc, char **argv)
     size_t W = 1024, H = 1024;
     double q[4] = {1, 0, 0, 0}, tr[3] = {0, 0, 2};
     bool have_view = false, ess = true, ortho = false, linear = true, gradient_bg = false, pin = false;
+    bool pathtrace = false;
+    double extinction = 100.0;
     std::array<float, 16> view{};
     unsigned illum = 1, seed = 0;
     int frames = 1, device = 0;
@@ -139,6 +142,8 @@ int main(int argc, char **argv)
         else if (a == "--bg") { need(i, 3); for (int k = 0; k < 3; ++k) bg[size_t(k)] = float(std::atof(argv[++i])); }
         else if (a == "--seed") { need(i, 1); seed = unsigned(std::strtoul(argv[++i], nullptr, 10)); pin = true; }
         else if (a == "--frames") { need(i, 1); frames = std::atoi(argv[++i]); }
+        else if (a == "--pathtrace") pathtrace = true;
+        else if (a == "--extinction") { need(i, 1); extinction = std::atof(argv[++i]); }
         else if (a == "--device") { need(i, 1); device = std::atoi(argv[++i]); }
         else if (a == "--out") { need(i, 1); out = argv[++i]; }
         else usage();
@@ -168,6 +173,10 @@ int main(int argc, char **argv)
         vr.setUseGradient(gradient_bg);
         vr.setBackground(bg);
         vr.updateSamplingRate(rate);
+        if (pathtrace) {
+            vr.setTechnique(VolumeRenderCL::TECH_PATHTRACE);
+            vr.setExtinction(extinction);
+        }
         if (pin) vr.setSeed(seed);
         vr.updateOutputImg(W, H, 0);
         vr.updateView(have_view ? view : view_matrix(q, tr));
