@@ -840,6 +840,14 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
                     if (!__ballot(d.state == S_BRICK)) break;
                     if (it >= kMaxBrickSteps && __ballot(d.state == S_SAMPLE)) break;
                     VR_COUNT(9);
+#ifdef VR_DDA_TWICE   // diagnostic build: what does a phase-2 DDA step cost?
+                    {
+                        RayDyn d2 = d;
+                        dda_step<0>(sb, grid, c, d2, dummy0, dummy1);
+                        asm volatile("" ::"v"(d2.t), "v"(d2.state), "v"(d2.skw), "v"(d2.tv0), "v"(d2.tv1),
+                                     "v"(d2.tv2), "v"(d2.c0), "v"(d2.c1), "v"(d2.c2), "v"(d2.t_exit));
+                    }
+#endif
                     if (count) dda_step<INSTR>(sb, grid, c, d, c_bricks, c_skipped);
                     else dda_step<0>(sb, grid, c, d, dummy0, dummy1);
                 }
@@ -855,6 +863,12 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
                     // lane `slot` looks at samples [kLook * slot, kLook * (slot + 1)) of the run
                     // (its window start is approximate, which is all the cell lookup needs)
                     const float t_win = d.t + (float)(kLook * (int)slot) * c.stepSize;
+#ifdef VR_TWICE_LOOK   // diagnostic build: sensitivity to the lookahead's cost
+                    {
+                        const int em2 = (int)empty_mask<VT, INSTR>(cells, vol, c, t_win + 1e-7f);
+                        asm volatile("" ::"v"(em2));
+                    }
+#endif
                     const int em = (int)empty_mask<VT, INSTR>(cells, vol, c, t_win);
                     const unsigned long long m64 =
                         (unsigned long long)(uint32_t)quad_bcast<0>(em) |
@@ -887,12 +901,35 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
                 }
                 float p0[kBatch], p1[kBatch], p2[kBatch], opk[kBatch];
                 bool litk[kBatch];
+#ifdef VR_TWICE_EVAL   // diagnostic build: sensitivity of the frame time to the evaluation's cost
+                {
+                    float tk2[kBatch];
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k) tk2[k] = tk[k] + 1e-7f;
+                    eval_batch<VT, INSTR>(vol, s_tff, tffn, s_stage, c, rp, rc, refInterval, tk2, vk, p0, p1,
+                                          p2, opk, litk);
+                    asm volatile("" ::"v"(p0[0]), "v"(p0[1]), "v"(p0[2]), "v"(p0[3]), "v"(p1[0]), "v"(p1[1]),
+                                 "v"(p1[2]), "v"(p1[3]), "v"(p2[0]), "v"(p2[1]), "v"(p2[2]), "v"(p2[3]),
+                                 "v"(opk[0]), "v"(opk[1]), "v"(opk[2]), "v"(opk[3]));
+                }
+#endif
                 eval_batch<VT, INSTR>(vol, s_tff, tffn, s_stage, c, rp, rc, refInterval, tk, vk, p0, p1, p2,
                                       opk, litk);
                 VR_STAMP(3);
                 int fl[kBatch];
 #pragma unroll
                 for (int k = 0; k < kBatch; ++k) fl[k] = (vk[k] ? 1 : 0) | (litk[k] ? 2 : 0);
+#ifdef VR_TWICE_COMP   // diagnostic build: sensitivity to the compositing replay's cost
+                {
+                    RayDyn d2 = d;
+                    unsigned long long z0 = 0, z1 = 0;
+                    composite_from<0>(c, d2, p0, p1, p2, opk, tk, fl, false, z0, z1);
+                    composite_from<1>(c, d2, p0, p1, p2, opk, tk, fl, false, z0, z1);
+                    composite_from<2>(c, d2, p0, p1, p2, opk, tk, fl, false, z0, z1);
+                    composite_from<3>(c, d2, p0, p1, p2, opk, tk, fl, false, z0, z1);
+                    asm volatile("" ::"v"(d2.t), "v"(d2.state), "v"(d2.alpha), "v"(d2.r0), "v"(d2.r1), "v"(d2.r2));
+                }
+#endif
                 composite_from<0>(c, d, p0, p1, p2, opk, tk, fl, count, c_taken, c_shaded);
                 composite_from<1>(c, d, p0, p1, p2, opk, tk, fl, count, c_taken, c_shaded);
                 composite_from<2>(c, d, p0, p1, p2, opk, tk, fl, count, c_taken, c_shaded);
