@@ -484,3 +484,18 @@ def test_cpp_host_cli_pathtrace_matches_oracle(tmp_path):
         ref, _, _ = vro.render_tile(vol, vro.FLOAT, tff, cam, rp, rc, pt=vro.PathtraceParams(60.0),
                                     W=W, H=H, in_accum=ref)
     assert np.abs(got - ref).max() <= TOL
+
+
+def test_large_tf_and_odd_viewport(vr):
+    """4096-entry transfer function (64 KiB of LDS for the table alone) on a viewport that is not
+    a multiple of the patch size, FLOAT volume with a non-cubic shape."""
+    vol = common.noise_volume((50, 38, 61), FLOAT, seed=17, smooth=True)
+    table = frontend.tff_from_stops(n=4096)
+    W, H = 203, 117
+    _setup(vr, vol, FLOAT, table, common.views()["rot30"])
+    got, ref, stats = _compare(vr, vol, FLOAT, table, W, H)
+    assert stats["rays_hit"] > 0
+    vr.setStatsEnabled(False)
+    got2 = vr.runRaycastNoGL(W, H)      # production kernels on the same frame
+    vr.setIteration(0)
+    np.testing.assert_array_equal(got2, ref)
