@@ -128,7 +128,7 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
     vol.fw = vv.fw; vol.fh = vv.fh; vol.fd = vv.fd;
     vol.inv_max = vv.inv_max;
     vol.nbx = vv.nbx; vol.nby = vv.nby;
-    vol.ystride = vv.ystride; vol.zstride = vv.zstride;
+    vol.ystride = vv.ystride; vol.zstride = (uint32_t)vv.zstride;
     vol.touched = touched;
     // the traffic-instrumented variant must not touch speculative voxels: one step per round
     constexpr int B = INSTR == 2 ? 1 : kPtBatch;

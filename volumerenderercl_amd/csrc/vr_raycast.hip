@@ -500,7 +500,7 @@ VR_DEV Vol<VT, INSTR> make_vol(const VolView &vv, uint32_t *touched)
     vol.fw = vv.fw; vol.fh = vv.fh; vol.fd = vv.fd;
     vol.inv_max = vv.inv_max;
     vol.nbx = vv.nbx; vol.nby = vv.nby;
-    vol.ystride = vv.ystride; vol.zstride = vv.zstride;
+    vol.ystride = vv.ystride; vol.zstride = (uint32_t)vv.zstride;
     vol.touched = touched;
     return vol;
 }

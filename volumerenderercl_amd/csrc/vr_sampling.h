@@ -55,7 +55,7 @@ struct Vol {
     float fw, fh, fd;
     float inv_max;
     uint32_t nbx, nby, ystride;     // micro-brick layout (vr_internal.h)
-    unsigned long long zstride;
+    uint32_t zstride;               // fits 32 bits (<= 2048 * 2048 * 64): one 32x32->64 multiply per z
     uint32_t *touched;
 
     // per-axis parts of the element index of voxel (x, y, z) in the 4x4x4 micro-brick layout
@@ -66,7 +66,8 @@ struct Vol {
     }
     VR_DEV unsigned long long zoff(int z) const
     {
-        return (unsigned long long)(uint32_t)(z >> 2) * zstride + (unsigned long long)((z & 3) << 4);
+        return (unsigned long long)(uint32_t)(z >> 2) * (unsigned long long)zstride +
+               (unsigned long long)((z & 3) << 4);
     }
 
     VR_DEV void touch(int x, int y, int z) const
