@@ -353,14 +353,22 @@ VR_DEV void eval_batch(const Vol<VT, INSTR> &vol, const float4 *s_tff, int tffn,
     }
 }
 
-constexpr int kLook = 16;   // samples looked ahead per round for empty runs
+#ifndef VR_LOOK1
+#define VR_LOOK1 16
+#endif
+#ifndef VR_LOOK2
+#define VR_LOOK2 8
+#endif
+// samples looked ahead for empty runs per lane and round (<= 32): phase 1 (one lane per ray) and
+// phase 2 (four lanes per ray, each with its own window)
+constexpr int kLook1 = VR_LOOK1, kLook2 = VR_LOOK2;
 
 // Bit k set: sample k of the run t0, t0 + stepSize, ... lies in an EMPTY cell (CellView): its
 // fetch can only map to opacity 0, so compositing it changes nothing (:864-879 with alpha == 0).
 // The cell is found from a linearised texel position (u0 + k * du): the cell extents carry a
 // one-texel halo for exactly this purpose, so the lookahead costs a few instructions per sample
 // and no voxel access.
-template <typename VT, int INSTR>
+template <typename VT, int INSTR, int kLook>
 VR_DEV uint32_t empty_mask(const CellView &cv, const Vol<VT, INSTR> &vol, const RayCtx &c, float t0)
 {
     const f3 p0 = add3(c.cam, scale3(c.dir, t0 - c.offset));
@@ -389,10 +397,11 @@ VR_DEV uint32_t empty_mask(const CellView &cv, const Vol<VT, INSTR> &vol, const 
 
 // Step over the leading empty samples of the run (the reference's own t sequence and loop
 // exits, :790 and :868-879; nothing else of the loop body has an effect for them).  Returns
-// true when all kLook samples were consumed and the run may continue.
+// true when all kLook1 samples were consumed and the run may continue.
 VR_DEV bool skip_empty_run(uint32_t mask, const RayCtx &c, RayDyn &d, bool count,
                            unsigned long long &c_taken)
 {
+    constexpr int kLook = kLook1;
     bool run = d.state == S_SAMPLE;
     float tk = d.t;
 #pragma unroll
@@ -410,16 +419,18 @@ VR_DEV bool skip_empty_run(uint32_t mask, const RayCtx &c, RayDyn &d, bool count
     return run;
 }
 
-// Phase 2: the four lanes of a ray look at four consecutive windows of kLook samples; the run is
-// then stepped over in chunks of kLook for as long as some ray of the wave is still skipping.
-VR_DEV bool skip_empty_run_wide(unsigned long long mask, const RayCtx &c, RayDyn &d, bool count,
+// Phase 2: the four lanes of a ray look at four consecutive windows of kLook2 samples; the run is
+// then stepped over in chunks of kLook2 for as long as some ray of the wave is still skipping.
+VR_DEV bool skip_empty_run_wide(const uint32_t (&masks)[4], const RayCtx &c, RayDyn &d, bool count,
                                 unsigned long long &c_taken)
 {
+    constexpr int kLook = kLook2;
     bool run = d.state == S_SAMPLE;
     float tk = d.t;
+#pragma unroll
     for (int chunk = 0; chunk < 4; ++chunk) {
         if (!__ballot(run)) break;
-        const uint32_t m = (uint32_t)(mask >> (kLook * chunk));
+        const uint32_t m = masks[chunk];
 #pragma unroll
         for (int k = 0; k < kLook; ++k) {
             if (run) {
@@ -666,8 +677,8 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_kernel(
             bool more_empty = false;
             if (skip_empty && lookahead_pays(d.state == S_SAMPLE, guess_empty)) {
                 if (d.state == S_SAMPLE) {
-                    // ---- step over a run of up to kLook samples in empty cells
-                    const uint32_t em = empty_mask<VT, INSTR>(cells, vol, c, d.t);
+                    // ---- step over a run of up to kLook1 samples in empty cells
+                    const uint32_t em = empty_mask<VT, INSTR, kLook1>(cells, vol, c, d.t);
                     more_empty = skip_empty_run(em, c, d, INSTR != 0, c_taken);
                     guess_empty = (em & 1u) != 0u;
                     after_segment<ESS>(c, d);
@@ -860,23 +871,20 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
             if (skip_empty && lookahead_pays(d.state == S_SAMPLE, guess_empty)) {
                 if (d.state == S_SAMPLE) {
                     // the four lanes of a ray hold the same state and take the same decisions;
-                    // lane `slot` looks at samples [kLook * slot, kLook * (slot + 1)) of the run
+                    // lane `slot` looks at samples [kLook2 * slot, kLook2 * (slot + 1)) of the run
                     // (its window start is approximate, which is all the cell lookup needs)
-                    const float t_win = d.t + (float)(kLook * (int)slot) * c.stepSize;
+                    const float t_win = d.t + (float)(kLook2 * (int)slot) * c.stepSize;
 #ifdef VR_TWICE_LOOK   // diagnostic build: sensitivity to the lookahead's cost
                     {
-                        const int em2 = (int)empty_mask<VT, INSTR>(cells, vol, c, t_win + 1e-7f);
+                        const int em2 = (int)empty_mask<VT, INSTR, kLook2>(cells, vol, c, t_win + 1e-7f);
                         asm volatile("" ::"v"(em2));
                     }
 #endif
-                    const int em = (int)empty_mask<VT, INSTR>(cells, vol, c, t_win);
-                    const unsigned long long m64 =
-                        (unsigned long long)(uint32_t)quad_bcast<0>(em) |
-                        ((unsigned long long)(uint32_t)quad_bcast<1>(em) << 16) |
-                        ((unsigned long long)(uint32_t)quad_bcast<2>(em) << 32) |
-                        ((unsigned long long)(uint32_t)quad_bcast<3>(em) << 48);
-                    more_empty = skip_empty_run_wide(m64, c, d, count, c_taken);
-                    guess_empty = (m64 & 1ull) != 0ull;
+                    const int em = (int)empty_mask<VT, INSTR, kLook2>(cells, vol, c, t_win);
+                    const uint32_t m4[4] = {(uint32_t)quad_bcast<0>(em), (uint32_t)quad_bcast<1>(em),
+                                            (uint32_t)quad_bcast<2>(em), (uint32_t)quad_bcast<3>(em)};
+                    more_empty = skip_empty_run_wide(m4, c, d, count, c_taken);
+                    guess_empty = (m4[0] & 1u) != 0u;
                     after_segment<ESS>(c, d);
                 }
             }
