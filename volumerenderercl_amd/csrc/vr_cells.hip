@@ -30,15 +30,32 @@ __global__ __launch_bounds__(kThreads) void vr_cell_minmax_kernel(VolView vv, Ce
     const VT *p = (const VT *)vv.data;
     float mn = __builtin_inff(), mx = -__builtin_inff();
     bool bad = false;
-    for (int dz = 0; dz < n; ++dz) {
-        const int z = min(max(z0 + dz, 0), vv.d - 1);
-        for (int i = (int)lane; i < n * n; i += 64) {
-            const int dy = i / n, dx = i - dy * n;
+    // the in-slice part of a lane's addresses does not depend on z: kPerLane voxels of a slice per
+    // lane and pass (one pass up to shift 4), their (x, y) offsets computed once per pass
+    constexpr int kPerLane = 6;
+    for (int base = 0; base < n * n; base += 64 * kPerLane) {
+        unsigned long long xy[kPerLane];
+        bool have[kPerLane];
+#pragma unroll
+        for (int j = 0; j < kPerLane; ++j) {
+            const int i = base + (int)lane + 64 * j;
+            have[j] = i < n * n;
+            const int dy = have[j] ? i / n : 0, dx = have[j] ? i - dy * n : 0;
             const int x = min(max(x0 + dx, 0), vv.w - 1), y = min(max(y0 + dy, 0), vv.h - 1);
-            const float v = (float)p[vr_voxel_index(vv, x, y, z)];
-            bad = bad || !(v == v);
-            mn = v < mn ? v : mn;
-            mx = v > mx ? v : mx;
+            xy[j] = vr_voxel_index(vv, x, y, 0);
+        }
+        for (int dz = 0; dz < n; ++dz) {
+            const int z = min(max(z0 + dz, 0), vv.d - 1);
+            const unsigned long long zo = vr_voxel_index(vv, 0, 0, z);
+#pragma unroll
+            for (int j = 0; j < kPerLane; ++j) {
+                if (have[j]) {
+                    const float v = (float)p[zo + xy[j]];
+                    bad = bad || !(v == v);
+                    mn = v < mn ? v : mn;
+                    mx = v > mx ? v : mx;
+                }
+            }
         }
     }
     for (int off = 32; off > 0; off >>= 1) {
