@@ -48,7 +48,8 @@ typedef struct vrhip_camera_params {
 typedef struct vrhip_rendering_params {
     float backgroundColor[4];
     float modelScale[4]; /* cl_float3 in a 16-byte slot */
-    uint32_t illumType;  /* 0 off, 1 central differences (2-5: VRHIP_ERR_UNSUPPORTED) */
+    uint32_t illumType;  /* 0 off, 1 central differences, 2 TF-opacity differences, 3 Sobel,
+                            4 gradient magnitude through the TF, 5 cel (volumeraycast.cl:796-830) */
     uint32_t imgEss;
     uint32_t showEss;
     uint32_t useLinear;

@@ -390,6 +390,70 @@ static f3 neg_gradient_central_diff(const vol_t *v, f3 pos)
     return neg3(n);
 }
 
+/* |s2 - s1| of gradientCentralDiff (:177, fast_length), same texel-space taps: the value
+ * illumType 4 feeds to the transfer function (:796-799). */
+static float gradient_central_diff_len(const vol_t *v, f3 pos)
+{
+    float ub = pos.x * v->fw - 0.5f, vb = pos.y * v->fh - 0.5f, wb = pos.z * v->fd - 0.5f;
+    float fx = floorf(ub), fy = floorf(vb), fz = floorf(wb);
+    float a = ub - fx, b = vb - fy, c = wb - fz;
+    int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+    int X[4], Y[4], Z[4];
+    for (int k = 0; k < 4; ++k) {
+        X[k] = iclamp(ix - 1 + k, 0, v->w - 1);
+        Y[k] = iclamp(iy - 1 + k, 0, v->h - 1);
+        Z[k] = iclamp(iz - 1 + k, 0, v->d - 1);
+    }
+    f3 s1, s2;
+    s1.x = vol_tri(v, X + 0, Y + 1, Z + 1, a, b, c);
+    s2.x = vol_tri(v, X + 2, Y + 1, Z + 1, a, b, c);
+    s1.y = vol_tri(v, X + 1, Y + 0, Z + 1, a, b, c);
+    s2.y = vol_tri(v, X + 1, Y + 2, Z + 1, a, b, c);
+    s1.z = vol_tri(v, X + 1, Y + 1, Z + 0, a, b, c);
+    s2.z = vol_tri(v, X + 1, Y + 1, Z + 2, a, b, c);
+    return len3(sub3(s2, s1));
+}
+
+/* -gradientSobel(vol, pos).xyz (volumeraycast.cl:217-277, :824).  The 27 taps sit at
+ * pos + offset * (i, j, k), i.e. whole texels from the centre sample: texel space again (the
+ * centre's weights on indices shifted by i, j, k and clamped).  Weights of the reference's table:
+ * d = (-1, 0, 1), s = (1, 2, 1); x: d[i] s[j] s[k], y: s[i] d[j] s[k], z: s[i] s[j] d[k].  Sums
+ * run in the reference's loop order (i outer, k inner), every term included. */
+static f3 neg_gradient_sobel(const vol_t *v, f3 pos)
+{
+    static const float dw[3] = {-1.f, 0.f, 1.f}, sw[3] = {1.f, 2.f, 1.f};
+    float ub = pos.x * v->fw - 0.5f, vb = pos.y * v->fh - 0.5f, wb = pos.z * v->fd - 0.5f;
+    float fx = floorf(ub), fy = floorf(vb), fz = floorf(wb);
+    float a = ub - fx, b = vb - fy, c = wb - fz;
+    int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            for (int k = 0; k < 3; ++k) {
+                int X[2] = {iclamp(ix - 1 + i, 0, v->w - 1), iclamp(ix + i, 0, v->w - 1)};
+                int Y[2] = {iclamp(iy - 1 + j, 0, v->h - 1), iclamp(iy + j, 0, v->h - 1)};
+                int Z[2] = {iclamp(iz - 1 + k, 0, v->d - 1), iclamp(iz + k, 0, v->d - 1)};
+                float smp = vol_tri(v, X, Y, Z, a, b, c);
+                gx = gx + ((dw[i] * sw[j]) * sw[k]) * smp;
+                gy = gy + ((sw[i] * dw[j]) * sw[k]) * smp;
+                gz = gz + ((sw[i] * sw[j]) * dw[k]) * smp;
+            }
+    f3 g = mk3(gx / 27.f, gy / 27.f, gz / 27.f); /* :270 */
+    if (len3(g) == 0.f) g = mk3(1.f, 1.f, 1.f); /* :272-273 */
+    return neg3(normalize3(g));
+}
+
+/* celShading, volumeraycast.cl:306-319 */
+static f3 cel_shading(f3 color, f3 toLightDir, f3 n)
+{
+    f3 l = normalize3(toLightDir);
+    float intensity = vmax(0.f, dot3(n, l));
+    if (intensity > 0.95f) return color;
+    if (intensity > 0.5f) return scale3(color, 0.6f);
+    if (intensity > 0.25f) return scale3(color, 0.4f);
+    return scale3(color, 0.2f);
+}
+
 /* volumeraycast.cl:280-291 with lightColor = materialColor = 1, exponent 40 */
 static float specular_blinn_phong(f3 normal, f3 toLightDir, f3 toCameraDir)
 {
@@ -793,21 +857,34 @@ static void render_pixel(const vol_t *v, const kargs_t *k, uint32_t gx, uint32_t
             st->samples_taken++;
             f3 pos = add3(camPos, scale3(rayDir, t - offset));
             pos = mk3(pos.x * 0.5f + 0.5f, pos.y * 0.5f + 0.5f, pos.z * 0.5f + 0.5f);
-            float density = rp->useLinear ? vol_linear(v, pos.x, pos.y, pos.z)
-                                          : vol_nearest(v, pos.x, pos.y, pos.z);
             float tfc[4];
-            tff_linear(v->s, density, tfc);
             f3 grad = mk3(0.f, 0.f, 0.f);
-            if (tfc[3] > 0.1f && rp->illumType == 1) { /* :809-830, central differences */
-                st->samples_shaded++;
-                grad = neg_gradient_central_diff(v, pos);
-                f3 c = illumination(mk3(tfc[0], tfc[1], tfc[2]), toLight, grad);
-                tfc[0] = c.x; tfc[1] = c.y; tfc[2] = c.z;
-            }
-            if (tfc[3] > 0.1f && k->rc->contours) { /* :832-837 */
-                if (!rp->illumType) grad = neg_gradient_central_diff(v, pos);
-                float e = fabsf(dot3(rayDir, grad));
-                tfc[0] *= e; tfc[1] *= e; tfc[2] *= e;
+            if (rp->illumType == 4) { /* :796-799 gradient magnitude through the TF */
+                tff_linear(v->s, gradient_central_diff_len(v, pos), tfc);
+            } else {
+                float density = rp->useLinear ? vol_linear(v, pos.x, pos.y, pos.z)
+                                              : vol_nearest(v, pos.x, pos.y, pos.z);
+                tff_linear(v->s, density, tfc);
+                if (tfc[3] > 0.1f && rp->illumType) { /* :809-830 */
+                    st->samples_shaded++;
+                    if (rp->illumType == 1 || rp->illumType == 5) {
+                        grad = neg_gradient_central_diff(v, pos);
+                    } else if (rp->illumType == 2) { /* :816-818 */
+                        float g[4];
+                        gradient_central_diff_tff(v, pos, g);
+                        grad = mk3(-g[0], -g[1], -g[2]);
+                    } else if (rp->illumType == 3) { /* :819-821 */
+                        grad = neg_gradient_sobel(v, pos);
+                    }
+                    f3 c = rp->illumType == 5 ? cel_shading(mk3(tfc[0], tfc[1], tfc[2]), toLight, grad)
+                                              : illumination(mk3(tfc[0], tfc[1], tfc[2]), toLight, grad);
+                    tfc[0] = c.x; tfc[1] = c.y; tfc[2] = c.z;
+                }
+                if (tfc[3] > 0.1f && k->rc->contours) { /* :832-837 */
+                    if (!rp->illumType) grad = neg_gradient_central_diff(v, pos);
+                    float e = fabsf(dot3(rayDir, grad));
+                    tfc[0] *= e; tfc[1] *= e; tfc[2] *= e;
+                }
             }
             tfc[0] = env[0] - tfc[0]; /* :856 */
             tfc[1] = env[1] - tfc[1];
@@ -852,7 +929,7 @@ int vro_render_tile(const vro_scene *scene, const vro_camera_params *cam,
     if (scene->format < 0 || scene->format > 2 || scene->tff_n == 0) return -1;
     if (x0 + w > W || y0 + h > H) return -1;
     if (use_ess && (!scene->bricks || !scene->prefix || scene->prefix_n == 0)) return -1;
-    if (render->illumType > 1) return -2; /* shading modes 2-5: SURVEY 8(f2), not built */
+    if (render->illumType > 5) return -2;
     if (raycast->useAO || render->imgEss || render->showEss) return -2;
 
     vol_t v;

@@ -82,6 +82,14 @@ CASES = [
     (USHORT, (40, 56, 36), (64, 64), "close", "opaque", {"ess": False}),
     (FLOAT, (48, 48, 48), (80, 64), "rot30", "default", {}),
     (FLOAT, (36, 36, 36), (64, 64), "default", "haze", {"illum": 0}),
+    # shading modes 2-5: TF-opacity gradient, Sobel, gradient-magnitude TF, cel
+    (UCHAR, (48, 48, 48), (80, 64), "rot30", "default", {"illum": 2}),
+    (UCHAR, (40, 44, 36), (64, 64), "rot30", "opaque", {"illum": 3, "contours": True}),
+    (UCHAR, (40, 40, 40), (64, 64), "close", "default", {"illum": 4}),
+    (USHORT, (40, 40, 40), (64, 64), "rot30", "opaque", {"illum": 4, "ess": False}),
+    (FLOAT, (40, 40, 40), (72, 56), "rot30", "default", {"illum": 5}),
+    (FLOAT, (32, 32, 32), (64, 48), "default", "opaque", {"illum": 3, "ess": False}),
+    (UCHAR, (40, 40, 40), (64, 48), "inside", "default", {"illum": 5, "aerial": True}),
 ]
 
 
@@ -376,8 +384,12 @@ def test_error_behaviour(vr):
         r.runRaycastNoGL(32, 32)
     r.setTransferFunction(frontend.tff_from_stops())
     r.updateView(frontend.view_matrix())
-    r.setIllumination(3)
-    with pytest.raises(RuntimeError):                # outside the hot path, loud
+    r.setIllumination(6)
+    with pytest.raises((RuntimeError, ValueError)):  # unknown shading mode, loud
+        r.runRaycastNoGL(32, 32)
+    r.setIllumination(1)
+    r.setAmbientOcclusion(True)
+    with pytest.raises(RuntimeError):                # outside the hot path (SURVEY 8f), loud
         r.runRaycastNoGL(32, 32)
     r.close()
 

@@ -53,25 +53,6 @@ VR_DEV f3 dir_phase_function(uint32_t rnd)
     return mk3(c * sin_theta, s * sin_theta, cos_theta);
 }
 
-// gradientCentralDiffTff (:181-206), un-negated: xyz = normalised difference of the
-// TF opacities one texel either side, w = its length.
-template <typename VT, int INSTR>
-VR_DEV float4 gradient_tff(const Vol<VT, INSTR> &vol, const float4 *s_tff, int tffn, f3 p)
-{
-    const f3 off = mk3(1.0f / vol.fw, 1.0f / vol.fh, 1.0f / vol.fd);
-    f3 s1, s2;
-    s1.x = tff_linear_alpha(s_tff, tffn, vol.linear(p.x + (-off.x), p.y + 0.0f, p.z + 0.0f));
-    s1.y = tff_linear_alpha(s_tff, tffn, vol.linear(p.x + 0.0f, p.y + (-off.y), p.z + 0.0f));
-    s1.z = tff_linear_alpha(s_tff, tffn, vol.linear(p.x + 0.0f, p.y + 0.0f, p.z + (-off.z)));
-    s2.x = tff_linear_alpha(s_tff, tffn, vol.linear(p.x + off.x, p.y + 0.0f, p.z + 0.0f));
-    s2.y = tff_linear_alpha(s_tff, tffn, vol.linear(p.x + 0.0f, p.y + off.y, p.z + 0.0f));
-    s2.z = tff_linear_alpha(s_tff, tffn, vol.linear(p.x + 0.0f, p.y + 0.0f, p.z + off.z));
-    const f3 g = sub3(s2, s1);
-    f3 n = normalize3(g);
-    if (dot3(g, g) == 0.0f) n = mk3(0.57735f, 0.57735f, 0.57735f);
-    return make_float4(n.x, n.y, n.z, len3(g));
-}
-
 // illumination (:294-303) with specularBlinnPhong (:280-291)
 VR_DEV f3 illumination(f3 color, f3 toLightDir, f3 n)
 {

@@ -218,7 +218,7 @@ constexpr int kStageF4 = (kBlockDim / 64) * kStageFloatsPerWave / 4;   // float4
 // over the dense slot list (usually one pass over the active lanes; per-ray constants come from
 // the owner lane by ds_bpermute) and hands four scalars per sample back.  Every sample sees the
 // same fp32 operations as before, in another lane.
-template <typename VT, int INSTR>
+template <typename VT, int INSTR, bool XS>
 VR_DEV void eval_batch(const Vol<VT, INSTR> &vol, const float4 *s_tff, int tffn, float *s_stage,
                        const RayCtx &c, const vrhip_rendering_params &rp,
                        const vrhip_raycast_params &rcp, float refInterval,
@@ -234,7 +234,9 @@ VR_DEV void eval_batch(const Vol<VT, INSTR> &vol, const float4 *s_tff, int tffn,
         pk[k] = mk3(pos.x * 0.5f + 0.5f, pos.y * 0.5f + 0.5f, pos.z * 0.5f + 0.5f);
         dens[k] = 0.f;
     }
-    if (rp.useLinear) {
+    if (XS && rp.illumType == 4) {
+        // handled below
+    } else if (rp.useLinear) {
 #pragma unroll
         for (int k = 0; k < kBatch; ++k)
             if (INSTR != 2 || vk[k]) dens[k] = vol.linear(pk[k].x, pk[k].y, pk[k].z);
@@ -243,20 +245,27 @@ VR_DEV void eval_batch(const Vol<VT, INSTR> &vol, const float4 *s_tff, int tffn,
         for (int k = 0; k < kBatch; ++k)
             if (INSTR != 2 || vk[k]) dens[k] = vol.nearest(pk[k].x, pk[k].y, pk[k].z);
     }
+    if (XS && rp.illumType == 4) {
+        // gradient magnitude through the transfer function (:796-799): no density fetch
+#pragma unroll 1
+        for (int k = 0; k < kBatch; ++k)
+            dens[k] = (INSTR != 2 || vk[k]) ? vol.gradient_len(pk[k].x, pk[k].y, pk[k].z) : 0.f;
+    }
     float4 tfc[kBatch];
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) tfc[k] = tff_linear(s_tff, tffn, dens[k]);
 
     // ---- which samples need the expensive part, and their slots
-    const bool want_grad = rp.illumType == 1 || (rcp.contours && !rp.illumType);
+    const bool shade_mode = XS ? (rp.illumType != 0 && rp.illumType != 4) : rp.illumType == 1;   // :809
+    const bool want_grad = shade_mode || (rcp.contours && !rp.illumType);
     const uint32_t lane = threadIdx.x & 63u;
     bool lit[kBatch], need[kBatch];
     uint32_t slot[kBatch];
     uint32_t n_slots = 0;
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
-        lit[k] = vk[k] && tfc[k].w > 0.1f;                    // :812, before the depth cue
-        shaded[k] = lit[k] && rp.illumType == 1;
+        lit[k] = vk[k] && tfc[k].w > 0.1f && !(XS && rp.illumType == 4);   // :809/:832, before the depth cue
+        shaded[k] = lit[k] && shade_mode;
         if (rcp.aerial) {                                     // :858-862
             float depthCue = 1.f - (tk[k] - c.tnear) / c.sampleDist;
             tfc[k].w *= depthCue;
@@ -310,11 +319,22 @@ VR_DEV void eval_batch(const Vol<VT, INSTR> &vol, const float4 *s_tff, int tffn,
             float o_ndl = 0.f, o_sp = 0.f, o_cnt = 0.f, o_op = 0.f;
             if (__ballot(shade)) {
                 if (shade) {
-                    const f3 g = vol.neg_gradient(qx, qy, qz);
-                    // illumination (:294-303) with specularBlinnPhong (:280-291)
+                    f3 g;
+                    if (XS && rp.illumType == 2) {    // :816-818 central differences of TF opacities
+                        const float4 gq = gradient_tff<VT, INSTR>(vol, s_tff, tffn, mk3(qx, qy, qz));
+                        g = mk3(-gq.x, -gq.y, -gq.z);
+                    } else if (XS && rp.illumType == 3) {   // :819-821 Sobel
+                        g = vol.neg_sobel(qx, qy, qz);
+                    } else {                          // 1, 5, and contours without illumination
+                        g = vol.neg_gradient(qx, qy, qz);
+                    }
+                    // illumination (:294-303) with specularBlinnPhong (:280-291); cel shading
+                    // (:306-319) only needs the diffuse term
                     o_ndl = vmax(0.f, dot3(g, lgt));
-                    o_sp = hvalid ? vr_powr(vmax(dot3(g, hv), 0.f), 40.f) : 0.0f;
-                    o_sp = o_sp * 0.15f;
+                    if (!(XS && rp.illumType == 5)) {
+                        o_sp = hvalid ? vr_powr(vmax(dot3(g, hv), 0.f), 40.f) : 0.0f;
+                        o_sp = o_sp * 0.15f;
+                    }
                     o_cnt = fabsf(dot3(dirv, g));             // contours (:846-848)
                 }
             }
@@ -336,10 +356,14 @@ VR_DEV void eval_batch(const Vol<VT, INSTR> &vol, const float4 *s_tff, int tffn,
 
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
-        if (lit[k] && rp.illumType == 1) {
+        if (lit[k] && shade_mode && !(XS && rp.illumType == 5)) {
             tfc[k].x = ((tfc[k].x * 0.15f) + ((tfc[k].x * ndl[k]) * 0.7f)) + spc[k];
             tfc[k].y = ((tfc[k].y * 0.15f) + ((tfc[k].y * ndl[k]) * 0.7f)) + spc[k];
             tfc[k].z = ((tfc[k].z * 0.15f) + ((tfc[k].z * ndl[k]) * 0.7f)) + spc[k];
+        }
+        if (XS && lit[k] && rp.illumType == 5) {   // celShading (:306-319), intensity = ndl
+            const float f = ndl[k] > 0.95f ? 1.0f : ndl[k] > 0.5f ? 0.6f : ndl[k] > 0.25f ? 0.4f : 0.2f;
+            if (!(ndl[k] > 0.95f)) { tfc[k].x *= f; tfc[k].y *= f; tfc[k].z *= f; }
         }
         if (lit[k] && rcp.contours) {
             tfc[k].x *= cnt[k]; tfc[k].y *= cnt[k]; tfc[k].z *= cnt[k];
@@ -588,7 +612,7 @@ __global__ __launch_bounds__(kBlockDim) void vr_dda_prepass_kernel(
 
 // ------------------------------------------------------------------ phase 1
 
-template <typename VT, bool ESS, int INSTR, bool SKIP_LDS>
+template <typename VT, bool ESS, int INSTR, bool SKIP_LDS, bool XS>
 __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_kernel(
     VolView vv, BrickView bricks, TfView tf, SkipView skip, CellView cells, FrameView fr,
     vrhip_camera_params cam, vrhip_rendering_params rp, vrhip_raycast_params rc, DevStats *stats,
@@ -618,7 +642,8 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_kernel(
     const uint32_t *sb = SKIP_LDS ? s_skip : skip.bits;
     // empty-run skipping needs the linear sampler's footprint; the traffic-instrumented variant
     // reproduces the reference's fetch set instead
-    const bool skip_empty = INSTR != 2 && cells.empty != nullptr && rp.useLinear != 0;
+    const bool skip_empty = INSTR != 2 && cells.empty != nullptr && rp.useLinear != 0 &&
+                            !(XS && rp.illumType == 4);
 
     // every wave pulls 8x8 patches until the queue is drained (exit condition reached by every
     // wave: the head only grows).  The next ticket is drawn while the current patch is marched,
@@ -699,7 +724,7 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_kernel(
                     if (INSTR == 2) vk[k] = false;
                 }
                 float p0[kBatch], p1[kBatch], p2[kBatch], opk[kBatch];
-                eval_batch<VT, INSTR>(vol, s_tff, tffn, s_stage, c, rp, rc, refInterval, tk, vk, p0, p1, p2,
+                eval_batch<VT, INSTR, XS>(vol, s_tff, tffn, s_stage, c, rp, rc, refInterval, tk, vk, p0, p1, p2,
                                       opk, litk);
                 VR_STAMP(3);
                 // sequential front-to-back compositing (:865-879)
@@ -781,7 +806,7 @@ VR_DEV void composite_from(const RayCtx &c, RayDyn &d, const float (&p0)[kBatch]
 // lane replays the compositing of all 16 in ray order, fetching the other lanes' results with
 // in-quad DPP broadcasts -- the fp32 operation sequence per ray is exactly phase 1's (and the
 // reference's), the serial chain of a long ray is 4x shorter.
-template <typename VT, bool ESS, int INSTR, bool SKIP_LDS>
+template <typename VT, bool ESS, int INSTR, bool SKIP_LDS, bool XS>
 __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
     VolView vv, BrickView bricks, TfView tf, SkipView skip, CellView cells, FrameView fr,
     vrhip_camera_params cam, vrhip_rendering_params rp, vrhip_raycast_params rc, DevStats *stats,
@@ -811,7 +836,8 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
     const float refInterval = 1.f / rc.samplingRate;
     const Grid grid = make_grid(bricks, rc, skip.n_words, ESS);
     const uint32_t *sb = SKIP_LDS ? s_skip : skip.bits;
-    const bool skip_empty = INSTR != 2 && cells.empty != nullptr && rp.useLinear != 0;
+    const bool skip_empty = INSTR != 2 && cells.empty != nullptr && rp.useLinear != 0 &&
+                            !(XS && rp.illumType == 4);
     const uint32_t n_groups = (n_rays + kRaysPerWave - 1u) / kRaysPerWave;
 
     uint32_t q_next = 0;
@@ -914,14 +940,14 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
                     float tk2[kBatch];
 #pragma unroll
                     for (int k = 0; k < kBatch; ++k) tk2[k] = tk[k] + 1e-7f;
-                    eval_batch<VT, INSTR>(vol, s_tff, tffn, s_stage, c, rp, rc, refInterval, tk2, vk, p0, p1,
+                    eval_batch<VT, INSTR, XS>(vol, s_tff, tffn, s_stage, c, rp, rc, refInterval, tk2, vk, p0, p1,
                                           p2, opk, litk);
                     asm volatile("" ::"v"(p0[0]), "v"(p0[1]), "v"(p0[2]), "v"(p0[3]), "v"(p1[0]), "v"(p1[1]),
                                  "v"(p1[2]), "v"(p1[3]), "v"(p2[0]), "v"(p2[1]), "v"(p2[2]), "v"(p2[3]),
                                  "v"(opk[0]), "v"(opk[1]), "v"(opk[2]), "v"(opk[3]));
                 }
 #endif
-                eval_batch<VT, INSTR>(vol, s_tff, tffn, s_stage, c, rp, rc, refInterval, tk, vk, p0, p1, p2,
+                eval_batch<VT, INSTR, XS>(vol, s_tff, tffn, s_stage, c, rp, rc, refInterval, tk, vk, p0, p1, p2,
                                       opk, litk);
                 VR_STAMP(3);
                 int fl[kBatch];
@@ -1057,11 +1083,11 @@ hipError_t prepare_variant(K kernel, size_t lds, int *nb_out, const char *what, 
     return hipSuccess;
 }
 
-template <typename VT, bool ESS, int INSTR, bool SKIP_LDS>
+template <typename VT, bool ESS, int INSTR, bool SKIP_LDS, bool XS>
 hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
 {
-    auto k1 = vr_raycast_kernel<VT, ESS, INSTR, SKIP_LDS>;
-    auto k2 = vr_raycast_split_kernel<VT, ESS, INSTR, SKIP_LDS>;
+    auto k1 = vr_raycast_kernel<VT, ESS, INSTR, SKIP_LDS, XS>;
+    auto k2 = vr_raycast_split_kernel<VT, ESS, INSTR, SKIP_LDS, XS>;
     size_t lds = (size_t)kStageF4 * sizeof(float4) + (size_t)a.tf.tff_n * sizeof(float4);
     if (ESS && SKIP_LDS) lds += ((size_t)a.skip.n_words + 1) * sizeof(uint32_t);
     static int nb1 = 0, nb2 = 0;
@@ -1111,19 +1137,22 @@ template <typename VT>
 hipError_t launch_typed(const RaycastLaunch &a, hipStream_t stream)
 {
     const bool lds = a.skip.in_lds != 0;
+    // the rarely used shading modes 2-5 live in kernel variants of their own (XS), so that their
+    // code and registers do not tax the default ones
+    const bool xs = a.render.illumType >= 2;
     if (a.use_ess) {
         if (lds) {
-            if (a.instr == 0) return launch_variant<VT, true, 0, true>(a, stream);
-            if (a.instr == 1) return launch_variant<VT, true, 1, true>(a, stream);
-            return launch_variant<VT, true, 2, true>(a, stream);
+            if (a.instr == 0) return xs ? launch_variant<VT, true, 0, true, true>(a, stream) : launch_variant<VT, true, 0, true, false>(a, stream);
+            if (a.instr == 1) return xs ? launch_variant<VT, true, 1, true, true>(a, stream) : launch_variant<VT, true, 1, true, false>(a, stream);
+            return xs ? launch_variant<VT, true, 2, true, true>(a, stream) : launch_variant<VT, true, 2, true, false>(a, stream);
         }
-        if (a.instr == 0) return launch_variant<VT, true, 0, false>(a, stream);
-        if (a.instr == 1) return launch_variant<VT, true, 1, false>(a, stream);
-        return launch_variant<VT, true, 2, false>(a, stream);
+        if (a.instr == 0) return xs ? launch_variant<VT, true, 0, false, true>(a, stream) : launch_variant<VT, true, 0, false, false>(a, stream);
+        if (a.instr == 1) return xs ? launch_variant<VT, true, 1, false, true>(a, stream) : launch_variant<VT, true, 1, false, false>(a, stream);
+        return xs ? launch_variant<VT, true, 2, false, true>(a, stream) : launch_variant<VT, true, 2, false, false>(a, stream);
     }
-    if (a.instr == 0) return launch_variant<VT, false, 0, false>(a, stream);
-    if (a.instr == 1) return launch_variant<VT, false, 1, false>(a, stream);
-    return launch_variant<VT, false, 2, false>(a, stream);
+    if (a.instr == 0) return xs ? launch_variant<VT, false, 0, false, true>(a, stream) : launch_variant<VT, false, 0, false, false>(a, stream);
+    if (a.instr == 1) return xs ? launch_variant<VT, false, 1, false, true>(a, stream) : launch_variant<VT, false, 1, false, false>(a, stream);
+    return xs ? launch_variant<VT, false, 2, false, true>(a, stream) : launch_variant<VT, false, 2, false, false>(a, stream);
 }
 
 } // namespace

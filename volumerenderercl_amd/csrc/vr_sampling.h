@@ -182,6 +182,65 @@ struct Vol {
         return neg3(n);
     }
 
+    // fast_length(s2 - s1) of gradientCentralDiff (:177) with the same texel-space taps: what
+    // illumType 4 feeds to the transfer function (:796-799)
+    VR_DEV float gradient_len(float px, float py, float pz) const
+    {
+        float ub = px * fw - 0.5f, vb = py * fh - 0.5f, sb = pz * fd - 0.5f;
+        float fx = floorf(ub), fy = floorf(vb), fz = floorf(sb);
+        float a = ub - fx, b = vb - fy, c = sb - fz;
+        int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+        f3 s1, s2;
+        s1.x = tri_at(ix - 1, iy, iz, a, b, c);
+        s2.x = tri_at(ix + 1, iy, iz, a, b, c);
+        s1.y = tri_at(ix, iy - 1, iz, a, b, c);
+        s2.y = tri_at(ix, iy + 1, iz, a, b, c);
+        s1.z = tri_at(ix, iy, iz - 1, a, b, c);
+        s2.z = tri_at(ix, iy, iz + 1, a, b, c);
+        return len3(sub3(s2, s1));
+    }
+
+    // trilinear blend with weights (a, b, c) of the 2x2x2 texels whose low corner is (x, y, z),
+    // indices clamped to the edge: a fetch a whole number of texels away from the centre sample
+    VR_DEV float tri_at(int x, int y, int z, float a, float b, float c) const
+    {
+        const int x0 = iclamp(x, 0, w1), x1 = iclamp(x + 1, 0, w1);
+        const int y0 = iclamp(y, 0, h1), y1 = iclamp(y + 1, 0, h1);
+        const int z0 = iclamp(z, 0, d1), z1 = iclamp(z + 1, 0, d1);
+        const uint32_t xo0 = xoff(x0), xo1 = xoff(x1), yo0 = yoff(y0), yo1 = yoff(y1);
+        const unsigned long long zo0 = zoff(z0), zo1 = zoff(z1);
+        float c00 = lerpf(raw(xo0, yo0, zo0, x0, y0, z0), raw(xo1, yo0, zo0, x1, y0, z0), a);
+        float c10 = lerpf(raw(xo0, yo1, zo0, x0, y1, z0), raw(xo1, yo1, zo0, x1, y1, z0), a);
+        float c01 = lerpf(raw(xo0, yo0, zo1, x0, y0, z1), raw(xo1, yo0, zo1, x1, y0, z1), a);
+        float c11 = lerpf(raw(xo0, yo1, zo1, x0, y1, z1), raw(xo1, yo1, zo1, x1, y1, z1), a);
+        return lerpf(lerpf(c00, c10, b), lerpf(c01, c11, b), c) * inv_max;
+    }
+
+    // -gradientSobel(vol, pos).xyz (volumeraycast.cl:217-277, :824): 27 taps whole texels from the
+    // centre sample, the reference's weights (d = (-1,0,1), s = (1,2,1); x: d[i] s[j] s[k], ...)
+    // and loop order.  A rolled loop: the mode is rare and must not cost the others registers.
+    VR_DEV f3 neg_sobel(float px, float py, float pz) const
+    {
+        float ub = px * fw - 0.5f, vb = py * fh - 0.5f, sb = pz * fd - 0.5f;
+        float fx = floorf(ub), fy = floorf(vb), fz = floorf(sb);
+        float a = ub - fx, b = vb - fy, c = sb - fz;
+        int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll 1
+        for (int t = 0; t < 27; ++t) {
+            const int i = t / 9, j = (t / 3) % 3, k = t % 3;
+            const float di = (float)(i - 1), dj = (float)(j - 1), dk = (float)(k - 1);
+            const float si = i == 1 ? 2.f : 1.f, sj = j == 1 ? 2.f : 1.f, sk = k == 1 ? 2.f : 1.f;
+            const float smp = tri_at(ix - 1 + i, iy - 1 + j, iz - 1 + k, a, b, c);
+            gx = gx + ((di * sj) * sk) * smp;
+            gy = gy + ((si * dj) * sk) * smp;
+            gz = gz + ((si * sj) * dk) * smp;
+        }
+        f3 g = mk3(gx / 27.f, gy / 27.f, gz / 27.f);
+        if (len3(g) == 0.f) g = mk3(1.f, 1.f, 1.f);
+        return neg3(normalize3(g));
+    }
+
     // read_imagef(vol, nearestSmp, pos).x -- normalised, CLAMP (border 0), NEAREST
     VR_DEV float nearest(float px, float py, float pz) const
     {
@@ -218,6 +277,25 @@ VR_DEV float tff_linear_alpha(const float4 *tff, int n, float x)
     int i = (int)fl;
     int i0 = iclamp(i, 0, n - 1), i1 = iclamp(i + 1, 0, n - 1);
     return lerpf(tff[i0].w, tff[i1].w, a);
+}
+
+// gradientCentralDiffTff (:181-206), un-negated: xyz = normalised difference of the TF opacities
+// one texel either side, w = its length.  (illumType 2 and the path tracer.)
+template <typename VT, int INSTR>
+VR_DEV float4 gradient_tff(const Vol<VT, INSTR> &vol, const float4 *s_tff, int tffn, f3 p)
+{
+    const f3 off = mk3(1.0f / vol.fw, 1.0f / vol.fh, 1.0f / vol.fd);
+    f3 s1, s2;
+    s1.x = tff_linear_alpha(s_tff, tffn, vol.linear(p.x + (-off.x), p.y + 0.0f, p.z + 0.0f));
+    s1.y = tff_linear_alpha(s_tff, tffn, vol.linear(p.x + 0.0f, p.y + (-off.y), p.z + 0.0f));
+    s1.z = tff_linear_alpha(s_tff, tffn, vol.linear(p.x + 0.0f, p.y + 0.0f, p.z + (-off.z)));
+    s2.x = tff_linear_alpha(s_tff, tffn, vol.linear(p.x + off.x, p.y + 0.0f, p.z + 0.0f));
+    s2.y = tff_linear_alpha(s_tff, tffn, vol.linear(p.x + 0.0f, p.y + off.y, p.z + 0.0f));
+    s2.z = tff_linear_alpha(s_tff, tffn, vol.linear(p.x + 0.0f, p.y + 0.0f, p.z + off.z));
+    const f3 g = sub3(s2, s1);
+    f3 n = normalize3(g);
+    if (dot3(g, g) == 0.0f) n = mk3(0.57735f, 0.57735f, 0.57735f);
+    return make_float4(n.x, n.y, n.z, len3(g));
 }
 
 // read_imageui(tffPrefix, nearestSmp, x).x -- border 0 outside [0, n-1]

@@ -322,8 +322,8 @@ int check_renderable(vrhip_renderer *r, uint32_t width, uint32_t height)
     }
     VR_REQUIRE(r, r->render.technique <= 1, VRHIP_ERR_INVALID, "Unknown rendering technique.");
     // the path-tracing branch of the kernel returns before illumType is looked at (:686-706)
-    VR_REQUIRE(r, r->render.illumType <= 1 || r->render.technique == 1, VRHIP_ERR_UNSUPPORTED,
-               "illumType 2-5 are outside the hot path (SURVEY 8f2).");
+    VR_REQUIRE(r, r->render.illumType <= 5 || r->render.technique == 1, VRHIP_ERR_INVALID,
+               "Unknown illumination type.");
     VR_REQUIRE(r, r->render.technique == 0 || r->pathtrace.max_extinction > 0.f, VRHIP_ERR_INVALID,
                "max_extinction must be positive.");
     VR_REQUIRE(r, !r->render.imgEss && !r->render.showEss && !r->raycast.useAO,
