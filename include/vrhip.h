@@ -112,6 +112,13 @@ int vrhip_synth_volume(vrhip_renderer *r, int kind, const uint32_t res[3], int f
                        uint32_t timestep);
 /* Copy timestep `t` back as a dense x-fastest array (bytes must equal its size). */
 int vrhip_download_volume(vrhip_renderer *r, uint32_t timestep, void *host_dst, size_t bytes);
+/* volumeDownsampling's device part (volumerendercl.cpp:238-300 + kernel `downsampling`,
+ * volumeraycast.cl:966-994): low-res size = ceil(res / factor) per axis; the low-res volume of
+ * timestep `t` is copied to host_dst as a dense x-fastest array in the volume's type.  Call with
+ * host_dst == NULL to query out_res only.  factor < 2 -> VRHIP_ERR_INVALID ("Factor must be
+ * greater or equal 2."); low-res x size < 64 -> VRHIP_ERR_INVALID (the reference's minimum). */
+int vrhip_downsample_volume(vrhip_renderer *r, uint32_t timestep, int factor, void *host_dst,
+                            size_t bytes, uint32_t out_res[3]);
 int vrhip_clear_volumes(vrhip_renderer *r);
 /* setTimestep (volumerendercl.cpp:1167-1174) */
 int vrhip_set_timestep(vrhip_renderer *r, uint32_t timestep);

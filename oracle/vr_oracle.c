@@ -526,6 +526,50 @@ int vro_generate_bricks(const void *voxels, const uint32_t res[3], int format,
     return 0;
 }
 
+/* downsampling, volumeraycast.cl:966-994 with the host's size rule (volumerendercl.cpp:245-251):
+ * low-res size = ceil(res / factor); every low-res voxel is the sum of the normalised values of
+ * its ceil(res / lowres)^3 box (clipped to the volume) divided by the FULL box volume, written
+ * back in the volume's type (UNORM: saturate, round to nearest even). */
+int vro_downsample(const void *voxels, const uint32_t res[3], int format, int factor, void *out,
+                   uint32_t out_res[3])
+{
+    if (!voxels || !out || format < 0 || format > 2 || factor < 2) return -1;
+    uint32_t lo[3];
+    int vpc[3];
+    for (int i = 0; i < 3; ++i) {
+        lo[i] = (uint32_t)ceil((double)res[i] / (double)factor);
+        vpc[i] = (int)ceilf((float)res[i] / (float)lo[i]);
+        out_res[i] = lo[i];
+    }
+    const float inv_max = format == VRO_UCHAR ? 1.0f / 255.0f : format == VRO_USHORT ? 1.0f / 65535.0f : 1.0f;
+    const size_t row = res[0], slice = (size_t)res[0] * res[1];
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int cz = 0; cz < (int)lo[2]; ++cz)
+        for (int cy = 0; cy < (int)lo[1]; ++cy)
+            for (int cx = 0; cx < (int)lo[0]; ++cx) {
+                int l[3] = {vpc[0] * cx, vpc[1] * cy, vpc[2] * cz}, u[3];
+                for (int i = 0; i < 3; ++i) u[i] = iclamp(l[i] + vpc[i], 0, (int)res[i]);
+                float value = 0.f;
+                for (int k = l[2]; k < u[2]; ++k)
+                    for (int j = l[1]; j < u[1]; ++j)
+                        for (int i = l[0]; i < u[0]; ++i) {
+                            size_t idx = k * slice + j * row + i;
+                            float raw = format == VRO_UCHAR ? (float)((const uint8_t *)voxels)[idx]
+                                        : format == VRO_USHORT ? (float)((const uint16_t *)voxels)[idx]
+                                                               : ((const float *)voxels)[idx];
+                            value += raw * inv_max;
+                        }
+                value /= (float)(vpc[0] * vpc[1] * vpc[2]);
+                size_t o = ((size_t)cz * lo[1] + cy) * lo[0] + cx;
+                if (format == VRO_FLOAT) ((float *)out)[o] = value;
+                else if (format == VRO_UCHAR)
+                    ((uint8_t *)out)[o] = (uint8_t)rintf(vclamp(value * 255.0f, 0.f, 255.0f));
+                else
+                    ((uint16_t *)out)[o] = (uint16_t)rintf(vclamp(value * 65535.0f, 0.f, 65535.0f));
+            }
+    return 0;
+}
+
 /* ---------------------------------------------------------- path tracer */
 
 #define VRO_PI_F 3.14159274101257f /* M_PI_F */

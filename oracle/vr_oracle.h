@@ -115,6 +115,10 @@ void vro_prefix_sum(const uint8_t *tff_rgba, uint32_t n, uint32_t *prefix);
 
 /* generateBricks kernel, volumeraycast.cl:932-961. `out` holds 2*tex[0]*tex[1]*tex[2]
  * values of the volume's own type. */
+/* downsampling kernel + host size rule (volumeraycast.cl:966-994, volumerendercl.cpp:245-251);
+ * out must hold ceil(res/factor)^3 elements of the volume's type. */
+int vro_downsample(const void *voxels, const uint32_t res[3], int format, int factor, void *out,
+                   uint32_t out_res[3]);
 int vro_generate_bricks(const void *voxels, const uint32_t res[3], int format,
                         const uint32_t tex[3], void *out);
 

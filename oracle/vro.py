@@ -145,6 +145,21 @@ def generate_bricks(vol, fmt):
     return out
 
 
+def downsample(vol, fmt, factor):
+    """volumeDownsampling's kernel + size rule. vol: ndarray [z, y, x]; returns the low-res ndarray."""
+    vol = np.ascontiguousarray(vol, dtype=_NP_DTYPE[fmt])
+    res = [vol.shape[2], vol.shape[1], vol.shape[0]]
+    lo = [-(-r // factor) for r in res]
+    out = np.zeros((lo[2], lo[1], lo[0]), dtype=_NP_DTYPE[fmt])
+    out_res = (C.c_uint32 * 3)()
+    f = lib().vro_downsample
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_uint32)]
+    rc = f(vol.ctypes.data_as(C.c_void_p), _u3(res), fmt, int(factor), out.ctypes.data_as(C.c_void_p), out_res)
+    assert rc == 0 and list(out_res) == lo
+    return out
+
+
 def synth_volume(kind, res, fmt):
     """kind: 'sphere' | 'shells'. Returns ndarray [z, y, x]."""
     out = np.zeros((res[2], res[1], res[0]), dtype=_NP_DTYPE[fmt])

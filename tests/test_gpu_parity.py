@@ -511,3 +511,46 @@ def test_large_tf_and_odd_viewport(vr):
     got2 = vr.runRaycastNoGL(W, H)      # production kernels on the same frame
     vr.setIteration(0)
     np.testing.assert_array_equal(got2, ref)
+
+
+@pytest.mark.parametrize("fmt,res,factor", [(UCHAR, (130, 70, 66), 2), (USHORT, (200, 64, 40), 3),
+                                            (FLOAT, (128, 48, 50), 2), (UCHAR, (260, 33, 47), 4)])
+def test_downsample_matches_oracle(vr, fmt, res, factor):
+    """downsampling kernel (volumeraycast.cl:966-994) with the host's size rule: bit-exact."""
+    vol = common.noise_volume(res, fmt, seed=8, smooth=False)
+    vr.loadVolumeArrays([vol], fmt)
+    got = vr.downsampleVolume(0, factor)
+    ref = vro.downsample(vol, fmt, factor)
+    np.testing.assert_array_equal(got, ref)
+    with pytest.raises((ValueError, RuntimeError)):
+        vr.downsampleVolume(0, 1)                       # "Factor must be greater or equal 2."
+    with pytest.raises((ValueError, RuntimeError)):
+        vr.downsampleVolume(0, 64)                      # below the 64-voxel minimum
+
+
+def test_cpp_host_downsampling_writes_dat_raw(tmp_path):
+    """volumeDownsampling through the C++ host: <name>_<N>.raw/.dat next to the .dat, raw bytes
+    equal to the oracle's, and the pair loads again (UCHAR: the reference writes the format as the
+    enum's integer, which its own reader then infers from the file size)."""
+    import os
+    import subprocess
+    from volumerenderercl_amd import datraw
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "volumerenderercl_amd", "vrhip_render")
+    vol = common.noise_volume((128, 40, 36), UCHAR, seed=2, smooth=False)
+    (tmp_path / "v.raw").write_bytes(vol.tobytes())
+    (tmp_path / "v.dat").write_text("ObjectFileName: v.raw\nResolution: 128 40 36\nFormat: UCHAR\n"
+                                    "SliceThickness: 1 1 2\n")
+    res = subprocess.run([exe, "--dat", str(tmp_path / "v.dat"), "--downsample", "2"],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    base = str(tmp_path / "v_64")
+    raw = np.fromfile(base + ".raw", dtype=np.uint8)
+    ref = vro.downsample(vol, vro.UCHAR, 2)
+    np.testing.assert_array_equal(raw, ref.reshape(-1))
+    text = open(base + ".dat").read()
+    assert "Resolution: \t\t64 20 18" in text and "SliceThickness: \t1 1 2" in text
+    assert "Format: \t\t\t0" in text
+    rd = datraw.DatRawReader()
+    rd.read_files(datraw.Properties(base + ".dat"))
+    np.testing.assert_array_equal(rd.data()[0].reshape(-1), ref.reshape(-1))

@@ -122,3 +122,23 @@ def test_pathtrace_opaque_volume_closed_form():
     assert np.all(g <= 0.15 + 1e-6)
     # 1 primary + 1 shadow step for interior hits; grazing rays leave the box on the first step
     assert st["samples_taken"] <= 2 * st["rays_hit"]
+
+
+def test_downsample_box_mean():
+    """downsampling (volumeraycast.cl:966-994): box sums over ceil(res/lowres)^3 voxels divided
+    by the full box volume, UNORM written with round-to-nearest-even; constant volumes stay
+    constant where the box is complete and fade at a clipped border."""
+    rng = np.random.default_rng(5)
+    vol = rng.integers(0, 256, size=(8, 6, 10), dtype=np.uint8)       # z, y, x
+    lo = vro.downsample(vol, vro.UCHAR, 2)
+    assert lo.shape == (4, 3, 5)
+    blocks = vol.reshape(4, 2, 3, 2, 5, 2).astype(np.float64).mean(axis=(1, 3, 5))
+    assert np.abs(lo.astype(np.float64) - blocks).max() <= 0.5 + 1e-3
+    const = np.full((6, 6, 7), 200, np.uint8)                          # x = 7: last box clipped
+    lo = vro.downsample(const, vro.UCHAR, 2)
+    assert lo.shape == (3, 3, 4)
+    assert np.all(lo[:, :, :3] == 200) and np.all(lo[:, :, 3] == 100)
+    f = np.linspace(0, 1, 4 * 4 * 6, dtype=np.float32).reshape(4, 4, 6)
+    lo = vro.downsample(f, vro.FLOAT, 3)                               # res (6,4,4) -> (2,2,2)
+    assert lo.shape == (2, 2, 2)
+    np.testing.assert_allclose(lo[0, 0, 0], f[:2, :2, :3].sum() / 12.0, rtol=1e-6)

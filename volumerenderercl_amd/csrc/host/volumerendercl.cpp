@@ -6,6 +6,7 @@
 #include <cstring>
 #include <iostream>
 #include <numeric>
+#include <fstream>
 #include <stdexcept>
 
 VolumeRenderCL::VolumeRenderCL() : _modelScale{1.0f, 1.0f, 1.0f}
@@ -325,11 +326,41 @@ const std::vector<std::string> VolumeRenderCL::getDeviceNames(size_t, const std:
 
 const std::string VolumeRenderCL::getCurrentDeviceName() { return _currentDevice; }
 
-const std::string VolumeRenderCL::volumeDownsampling(const size_t, const int factor)
+// volumerendercl.cpp:238-341: down-sample time step t on the GPU, write <dat name>_<N>.raw/.dat
+// next to the loaded .dat, return the path without extension.  The .dat text is the reference's,
+// including its quirks: `Format:` carries the enum's integer and `ObjectFileName:` is cut with
+// substr(first + 1, lastindex) where lastindex is a position, not a length.
+const std::string VolumeRenderCL::volumeDownsampling(const size_t t, const int factor)
 {
     if (!_dr.has_data()) throw std::runtime_error("No volume data is loaded.");
     if (factor < 2) throw std::invalid_argument("Factor must be greater or equal 2.");
-    throw std::runtime_error("ERROR: volume down-sampling is outside the hot path (SURVEY 8f4)");
+    uint32_t lo[3] = {0, 0, 0};
+    int rc = vrhip_downsample_volume(_r, uint32_t(t), factor, nullptr, 0, lo);
+    if (rc == VRHIP_ERR_INVALID) throw std::invalid_argument(vrhip_last_error(_r));
+    check("vrhip_downsample_volume", rc);
+    const DatRawReader::Properties &p = _dr.properties();
+    const size_t mult = p.format == DatRawReader::UCHAR ? 1 : p.format == DatRawReader::USHORT ? 2 : 4;
+    std::vector<unsigned char> outputData(size_t(lo[0]) * lo[1] * lo[2] * mult);
+    check("vrhip_downsample_volume", vrhip_downsample_volume(_r, uint32_t(t), factor, outputData.data(),
+                                                             outputData.size(), lo));
+    size_t lastindex = p.dat_file_name.find_last_of(".");
+    std::string rawname = p.dat_file_name.substr(0, lastindex);
+    rawname += "_";
+    rawname += std::to_string(lo[0]);
+    std::ofstream file(rawname + ".raw", std::ios::out | std::ios::binary);
+    file.write(reinterpret_cast<const char *>(outputData.data()), std::streamsize(outputData.size()));
+    file.close();
+    std::ofstream datFile(rawname + ".dat", std::ios::out);
+    lastindex = rawname.find_last_of(".");
+    size_t firstindex = rawname.find_last_of("/\\");
+    std::string rawnameShort = rawname.substr(firstindex + 1, lastindex);
+    datFile << "ObjectFileName: \t" << rawnameShort << ".raw\n";
+    datFile << "Resolution: \t\t" << lo[0] << " " << lo[1] << " " << lo[2] << "\n";
+    datFile << "SliceThickness: \t" << p.slice_thickness.at(0) << " " << p.slice_thickness.at(1) << " "
+            << p.slice_thickness.at(2) << "\n";
+    datFile << "Format: \t\t\t" << p.format << "\n";
+    datFile.close();
+    return rawname;
 }
 
 void VolumeRenderCL::createEnvironmentMap(const std::string &file_name)

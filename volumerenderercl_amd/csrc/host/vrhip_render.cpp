@@ -97,6 +97,7 @@ void write_ppm(const std::string &path, const std::vector<float> &rgba, size_t w
         "         [--tf default|FILE] [--illum N] [--no-ess] [--ortho] [--nearest] [--rate R]\n"
         "         [--bg R G B] [--gradient-bg] [--seed S] [--frames N] [--device D] --out PREFIX\n"
         "         [--pathtrace] [--extinction E]   (technique 1; --frames = samples per pixel)\n"
+        "         [--downsample FACTOR]            (volumeDownsampling: writes <dat>_<N>.raw/.dat, no frame)\n"
         "writes PREFIX.rgba.f32 (W*H*4 float32, row 0 = top), PREFIX.ppm and prints one JSON line\n";
     std::exit(2);
 }
@@ -112,6 +113,7 @@ int main(int argc, char **argv)
     bool have_view = false, ess = true, ortho = false, linear = true, gradient_bg = false, pin = false;
     bool pathtrace = false;
     double extinction = 100.0;
+    int downsample = 0;
     std::array<float, 16> view{};
     unsigned illum = 1, seed = 0;
     int frames = 1, device = 0;
@@ -143,12 +145,13 @@ int main(int argc, char **argv)
         else if (a == "--seed") { need(i, 1); seed = unsigned(std::strtoul(argv[++i], nullptr, 10)); pin = true; }
         else if (a == "--frames") { need(i, 1); frames = std::atoi(argv[++i]); }
         else if (a == "--pathtrace") pathtrace = true;
+        else if (a == "--downsample") { need(i, 1); downsample = std::atoi(argv[++i]); }
         else if (a == "--extinction") { need(i, 1); extinction = std::atof(argv[++i]); }
         else if (a == "--device") { need(i, 1); device = std::atoi(argv[++i]); }
         else if (a == "--out") { need(i, 1); out = argv[++i]; }
         else usage();
     }
-    if ((dat.empty() && synth_kind.empty()) || out.empty()) usage();
+    if ((dat.empty() && synth_kind.empty()) || (out.empty() && !downsample)) usage();
 
     try {
         VolumeRenderCL vr;
@@ -161,6 +164,11 @@ int main(int argc, char **argv)
             DatRawReader::data_format f = synth_fmt == "USHORT" ? DatRawReader::USHORT
                                           : synth_fmt == "FLOAT" ? DatRawReader::FLOAT : DatRawReader::UCHAR;
             vr.loadSyntheticVolume(synth_kind, synth_n, f);
+        }
+        if (downsample) {   // volumeDownsampling (volumerendercl.cpp:238-341) and nothing else
+            const std::string base = vr.volumeDownsampling(0, downsample);
+            std::printf("{\"downsampled\": \"%s\"}\n", base.c_str());
+            return 0;
         }
         std::vector<unsigned char> table =
             tf == "default" ? tff_from_stops({{0.0, {0, 0, 0, 0}}, {0.1, {125, 125, 125, 0}}, {1.0, {0, 0, 0, 255}}})

@@ -205,6 +205,57 @@ __global__ __launch_bounds__(kThreads) void vr_synth_kernel(VolView vol, int kin
 
 } // namespace
 
+// downsampling (volumeraycast.cl:966-994): one thread per low-res voxel, the box summed in the
+// reference's k, j, i order; dense x-fastest output in the volume's type.
+template <typename VT>
+__global__ __launch_bounds__(kThreads) void vr_downsample_kernel(VolView vol, int lx, int ly, int lz,
+                                                                 int vx, int vy, int vz, VT *out)
+{
+    const size_t n = (size_t)lx * ly * lz;
+    const size_t o = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (o >= n) return;
+    const int cx = (int)(o % (size_t)lx), cy = (int)((o / (size_t)lx) % (size_t)ly);
+    const int cz = (int)(o / ((size_t)lx * ly));
+    const int x0 = vx * cx, y0 = vy * cy, z0 = vz * cz;
+    const int x1 = min(x0 + vx, vol.w), y1 = min(y0 + vy, vol.h), z1 = min(z0 + vz, vol.d);
+    const VT *p = (const VT *)vol.data;
+    float value = 0.f;
+    for (int k = z0; k < z1; ++k)
+        for (int j = y0; j < y1; ++j)
+            for (int i = x0; i < x1; ++i) value += (float)p[vr_voxel_index(vol, i, j, k)] * vol.inv_max;
+    value /= (float)(vx * vy * vz);
+    if (sizeof(VT) == 4) {
+        reinterpret_cast<float *>(out)[o] = value;
+    } else {
+        const float top = sizeof(VT) == 1 ? 255.0f : 65535.0f;
+        const float q = rintf(fminf(fmaxf(value * top, 0.f), top));   // convert_*_sat_rte
+        out[o] = (VT)q;
+    }
+}
+
+hipError_t vr_launch_downsample(const VolView &vol, int format, const int lo[3], const int vpc[3],
+                                void *out, hipStream_t stream)
+{
+    const size_t n = (size_t)lo[0] * lo[1] * lo[2];
+    dim3 grid((unsigned)((n + kThreads - 1) / kThreads)), block(kThreads);
+    switch (format) {
+    case VRHIP_UCHAR:
+        hipLaunchKernelGGL(vr_downsample_kernel<uint8_t>, grid, block, 0, stream, vol, lo[0], lo[1], lo[2],
+                           vpc[0], vpc[1], vpc[2], (uint8_t *)out);
+        break;
+    case VRHIP_USHORT:
+        hipLaunchKernelGGL(vr_downsample_kernel<uint16_t>, grid, block, 0, stream, vol, lo[0], lo[1], lo[2],
+                           vpc[0], vpc[1], vpc[2], (uint16_t *)out);
+        break;
+    case VRHIP_FLOAT:
+        hipLaunchKernelGGL(vr_downsample_kernel<float>, grid, block, 0, stream, vol, lo[0], lo[1], lo[2],
+                           vpc[0], vpc[1], vpc[2], (float *)out);
+        break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 hipError_t vr_launch_build_bricks(const VolView &vol, int format, const uint32_t tex[3],
                                   void *bricks_out, hipStream_t stream)
 {

@@ -168,6 +168,9 @@ hipError_t vr_launch_skipmap(const BrickView &bricks, int format, float inv_max,
 
 hipError_t vr_launch_build_bricks(const VolView &vol, int format, const uint32_t tex[3],
                                   void *bricks_out, hipStream_t stream);
+// downsampling kernel (volumeraycast.cl:966-994): lo = low-res size, vpc = voxels per cell
+hipError_t vr_launch_downsample(const VolView &vol, int format, const int lo[3], const int vpc[3],
+                                void *out_dense, hipStream_t stream);
 // synthetic field written straight into the micro-brick layout
 hipError_t vr_launch_synth(int kind, const VolView &vol, int format, hipStream_t stream);
 // dense x-fastest slices [z0, z0+nz) (device memory, `dense` points at slice z0) <-> bricks

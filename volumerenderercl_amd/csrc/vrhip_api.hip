@@ -741,6 +741,39 @@ int vrhip_download_volume(vrhip_renderer *r, uint32_t timestep, void *host_dst, 
     return VRHIP_OK;
 }
 
+int vrhip_downsample_volume(vrhip_renderer *r, uint32_t timestep, int factor, void *host_dst,
+                            size_t bytes, uint32_t out_res[3])
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    VR_REQUIRE(r, timestep < r->vols.size() && r->vols[timestep].dev, VRHIP_ERR_NODATA,
+               "No volume data is loaded.");
+    VR_REQUIRE(r, factor >= 2, VRHIP_ERR_INVALID, "Factor must be greater or equal 2.");
+    int lo[3], vpc[3];
+    for (int i = 0; i < 3; ++i) {
+        lo[i] = (int)std::ceil((double)r->res[i] / (double)factor);        // volumerendercl.cpp:245-251
+        vpc[i] = (int)std::ceil((float)r->res[i] / (float)lo[i]);           // volumeraycast.cl:974-975
+        if (out_res) out_res[i] = (uint32_t)lo[i];
+    }
+    VR_REQUIRE(r, lo[0] >= 64, VRHIP_ERR_INVALID,
+               "Could not create down-sampled volume data set, because the resolution would be "
+               "smaller than the minimum (64x64x64).");   // :253-259
+    if (!host_dst) return VRHIP_OK;
+    const size_t need = (size_t)lo[0] * lo[1] * lo[2] * fmt_bytes(r->format);
+    VR_REQUIRE(r, bytes == need, VRHIP_ERR_INVALID, "vrhip_downsample_volume: size mismatch");
+    if (set_device(r)) return VRHIP_ERR_HIP;
+    void *dev = nullptr;
+    VR_HIP(r, hipMalloc(&dev, need));
+    hipError_t e = vr_launch_downsample(make_vol_view(r, r->vols[timestep].dev), r->format, lo, vpc,
+                                        dev, r->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(host_dst, dev, need, hipMemcpyDeviceToHost, r->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
+    (void)hipFree(dev);
+    if (e != hipSuccess)
+        return fail(r, VRHIP_ERR_HIP,
+                    std::string("ERROR: vrhip_downsample_volume (") + hipGetErrorString(e) + ")");
+    return VRHIP_OK;
+}
+
 int vrhip_clear_volumes(vrhip_renderer *r)
 {
     if (!r) return VRHIP_ERR_INVALID;

@@ -219,6 +219,16 @@ class VolumeRenderCL:
         self._calc_scaling()
         self._vol_loaded = True
 
+    def downsampleVolume(self, t, factor):
+        """Device part of volumeDownsampling (volumerendercl.cpp:238-300 + kernel
+        `downsampling`): returns the low-res ndarray [z, y, x] of time step t."""
+        lo = (C.c_uint32 * 3)()
+        self._check(self._lib.vrhip_downsample_volume(self._h, int(t), int(factor), None, 0, lo))
+        out = np.empty((lo[2], lo[1], lo[0]), dtype=NP_DTYPE[self._format])
+        self._check(self._lib.vrhip_downsample_volume(self._h, int(t), int(factor),
+                                                      out.ctypes.data_as(C.c_void_p), out.nbytes, lo))
+        return out
+
     def downloadVolume(self, t=0):
         out = np.empty((self._res[2], self._res[1], self._res[0]), dtype=NP_DTYPE[self._format])
         self._check(self._lib.vrhip_download_volume(self._h, t, out.ctypes.data_as(C.c_void_p),
