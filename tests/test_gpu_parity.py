@@ -554,3 +554,42 @@ def test_cpp_host_downsampling_writes_dat_raw(tmp_path):
     rd = datraw.DatRawReader()
     rd.read_files(datraw.Properties(base + ".dat"))
     np.testing.assert_array_equal(rd.data()[0].reshape(-1), ref.reshape(-1))
+
+
+def test_cpp_host_cli_reads_gui_state_and_tff(tmp_path):
+    """The headless host consumes the reference GUI's own saved files: JSON camera
+    state and a gradient-stop .tff."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "volumerenderercl_amd", "vrhip_render")
+    q = frontend.quat_from_axis_angle((0.2, 1, 0.1), 40.0)
+    stops = [(0.0, (0, 0, 0, 0)), (0.3, (220, 60, 20, 10)), (0.8, (20, 90, 200, 120)), (1.0, (255, 255, 255, 255))]
+    frontend.write_cam_state(str(tmp_path / "s.json"), q, (0.1, -0.2, 2.5), rayStepSize=1.0,
+                             useAerial=True, showContours=True)
+    frontend.write_tff_stops(str(tmp_path / "t.tff"), stops)
+    W, H, N = 72, 56, 40
+    out = str(tmp_path / "f")
+    cmd = [exe, "--synth", "sphere", str(N), "UCHAR", "--size", str(W), str(H), "--state",
+           str(tmp_path / "s.json"), "--tf-stops", str(tmp_path / "t.tff"), "--seed", str(SEED), "--out", out]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    got = np.fromfile(out + ".rgba.f32", dtype=np.float32).reshape(H, W, 4)
+    st = frontend.read_cam_state(str(tmp_path / "s.json"))
+    vol = vro.synth_volume("sphere", [N, N, N], vro.UCHAR)
+    tff = frontend.tff_from_stops(frontend.read_tff_stops(str(tmp_path / "t.tff")))
+    cam = vro.CameraParams()
+    cam.viewMat[:] = frontend.view_matrix(st["rotation"], st["translation"])
+    cam.bbox_bl[:] = [-1, -1, -1, 0]
+    cam.bbox_tr[:] = [1, 1, 1, 0]
+    rp = vro.RenderingParams()
+    rp.backgroundColor[:] = [1, 1, 1, 0]
+    rp.modelScale[:] = [1, 1, 1, 0]
+    rp.illumType, rp.useLinear, rp.seed = 1, 1, SEED
+    rc = vro.RaycastParams()
+    rc.samplingRate = st["rayStepSize"]
+    rc.contours, rc.aerial = 1, 1
+    _, brf, _ = vro.brick_layout([N, N, N])
+    rc.brickRes[:] = brf + [0]
+    ref, _, _ = vro.render_tile(vol, vro.UCHAR, tff, cam, rp, rc, W=W, H=H)
+    assert np.abs(got - ref).max() <= TOL

@@ -12,6 +12,9 @@
 #include <iostream>
 #include <sstream>
 #include <stdexcept>
+#include <map>
+#include <cctype>
+#include <iterator>
 #include <string>
 #include <vector>
 
@@ -57,6 +60,82 @@ std::vector<unsigned char> tff_from_raw_file(const std::string &path)
     return out;
 }
 
+// `.tff` gradient-stop file (MainWindow::readTff, mainwindow.cpp:583-620): `pos r g b a` per line
+std::vector<unsigned char> tff_from_stops_file(const std::string &path)
+{
+    std::ifstream in(path);
+    if (!in) throw std::invalid_argument("Could not open transfer function file " + path);
+    std::vector<Stop> stops;
+    std::string line;
+    while (std::getline(in, line)) {
+        std::istringstream ls(line);
+        double v[5];
+        int n = 0;
+        while (n < 5 && (ls >> v[n])) ++n;
+        if (n < 5) continue;
+        Stop st;
+        st.pos = v[0];
+        for (int c = 0; c < 4; ++c) st.c[c] = int(v[1 + c]);
+        stops.push_back(st);
+    }
+    if (stops.empty()) throw std::invalid_argument("Empty transfer function file.");
+    return tff_from_stops(stops);
+}
+
+// The GUI's JSON state (MainWindow::loadCamState, mainwindow.cpp:374-410; VolumeRenderWidget::read,
+// volumerenderwidget.cpp:1457-1480): a flat object of strings, numbers and booleans.
+struct CamState {
+    bool has_rot = false, has_tr = false;
+    double q[4] = {1, 0, 0, 0}, t[3] = {0, 0, 2};
+    std::map<std::string, double> num;
+    std::map<std::string, bool> flag;
+};
+
+CamState read_cam_state(const std::string &path)
+{
+    std::ifstream in(path);
+    if (!in) throw std::invalid_argument("Couldn't open state file " + path);
+    std::string js((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    CamState st;
+    size_t i = 0;
+    auto skip = [&]() { while (i < js.size() && std::isspace((unsigned char)js[i])) ++i; };
+    auto str = [&]() {
+        std::string out;
+        ++i;   // opening quote
+        while (i < js.size() && js[i] != '"') {
+            if (js[i] == '\\' && i + 1 < js.size()) ++i;
+            out += js[i++];
+        }
+        ++i;
+        return out;
+    };
+    skip();
+    if (i >= js.size() || js[i] != '{') throw std::invalid_argument("Invalid state file " + path);
+    ++i;
+    for (;;) {
+        skip();
+        if (i >= js.size() || js[i] == '}') break;
+        if (js[i] == ',') { ++i; continue; }
+        if (js[i] != '"') throw std::invalid_argument("Invalid state file " + path);
+        const std::string key = str();
+        skip();
+        if (i < js.size() && js[i] == ':') ++i;
+        skip();
+        if (i < js.size() && js[i] == '"') {
+            std::istringstream vs(str());
+            if (key == "camRotation") { st.has_rot = bool(vs >> st.q[0] >> st.q[1] >> st.q[2] >> st.q[3]); }
+            else if (key == "camTranslation") { st.has_tr = bool(vs >> st.t[0] >> st.t[1] >> st.t[2]); }
+        } else if (js.compare(i, 4, "true") == 0) { st.flag[key] = true; i += 4; }
+        else if (js.compare(i, 5, "false") == 0) { st.flag[key] = false; i += 5; }
+        else {
+            size_t used = 0;
+            st.num[key] = std::stod(js.substr(i), &used);
+            i += used;
+        }
+    }
+    return st;
+}
+
 // updateViewMatrix (volumerenderwidget.cpp:1079-1098): M = R(q) T(t) S(t.z), row-major
 std::array<float, 16> view_matrix(const double q[4], const double t[3])
 {
@@ -98,6 +177,7 @@ void write_ppm(const std::string &path, const std::vector<float> &rgba, size_t w
         "         [--bg R G B] [--gradient-bg] [--seed S] [--frames N] [--device D] --out PREFIX\n"
         "         [--pathtrace] [--extinction E]   (technique 1; --frames = samples per pixel)\n"
         "         [--downsample FACTOR]            (volumeDownsampling: writes <dat>_<N>.raw/.dat, no frame)\n"
+        "         [--state FILE.json] [--tf-stops FILE.tff]   (files saved by the reference GUI)\n"
         "writes PREFIX.rgba.f32 (W*H*4 float32, row 0 = top), PREFIX.ppm and prints one JSON line\n";
     std::exit(2);
 }
@@ -114,6 +194,8 @@ int main(int argc, char **argv)
     bool pathtrace = false;
     double extinction = 100.0;
     int downsample = 0;
+    std::string state_file, tf_stops;
+    bool contours = false, aerial = false;
     std::array<float, 16> view{};
     unsigned illum = 1, seed = 0;
     int frames = 1, device = 0;
@@ -146,6 +228,10 @@ int main(int argc, char **argv)
         else if (a == "--frames") { need(i, 1); frames = std::atoi(argv[++i]); }
         else if (a == "--pathtrace") pathtrace = true;
         else if (a == "--downsample") { need(i, 1); downsample = std::atoi(argv[++i]); }
+        else if (a == "--state") { need(i, 1); state_file = argv[++i]; }
+        else if (a == "--tf-stops") { need(i, 1); tf_stops = argv[++i]; }
+        else if (a == "--contours") contours = true;
+        else if (a == "--aerial") aerial = true;
         else if (a == "--extinction") { need(i, 1); extinction = std::atof(argv[++i]); }
         else if (a == "--device") { need(i, 1); device = std::atoi(argv[++i]); }
         else if (a == "--out") { need(i, 1); out = argv[++i]; }
@@ -170,15 +256,37 @@ int main(int argc, char **argv)
             std::printf("{\"downsampled\": \"%s\"}\n", base.c_str());
             return 0;
         }
+        bool use_ao = false, show_box = false;
+        if (!state_file.empty()) {   // what the GUI's widgets would forward after loadCamState
+            const CamState st = read_cam_state(state_file);
+            if (st.has_rot) for (int k = 0; k < 4; ++k) q[k] = st.q[k];
+            if (st.has_tr) for (int k = 0; k < 3; ++k) tr[k] = st.t[k];
+            if (st.num.count("rayStepSize")) rate = st.num.at("rayStepSize");
+            if (st.num.count("imgResFactor")) {
+                W = size_t(std::floor(double(W) * st.num.at("imgResFactor")));
+                H = size_t(std::floor(double(H) * st.num.at("imgResFactor")));
+            }
+            if (st.flag.count("useLerp")) linear = st.flag.at("useLerp");
+            if (st.flag.count("useOrtho")) ortho = st.flag.at("useOrtho");
+            if (st.flag.count("showContours")) contours = st.flag.at("showContours");
+            if (st.flag.count("useAerial")) aerial = st.flag.at("useAerial");
+            if (st.flag.count("useAO")) use_ao = st.flag.at("useAO");
+            if (st.flag.count("showBox")) show_box = st.flag.at("showBox");
+        }
         std::vector<unsigned char> table =
-            tf == "default" ? tff_from_stops({{0.0, {0, 0, 0, 0}}, {0.1, {125, 125, 125, 0}}, {1.0, {0, 0, 0, 255}}})
-                            : tff_from_raw_file(tf);
+            !tf_stops.empty() ? tff_from_stops_file(tf_stops)
+            : tf == "default" ? tff_from_stops({{0.0, {0, 0, 0, 0}}, {0.1, {125, 125, 125, 0}}, {1.0, {0, 0, 0, 255}}})
+                              : tff_from_raw_file(tf);
         vr.setTransferFunction(table);
         vr.setIllumination(illum);
         vr.setObjEss(ess);
         vr.setCamOrtho(ortho);
         vr.setLinearInterpolation(linear);
         vr.setUseGradient(gradient_bg);
+        vr.setContours(contours);
+        vr.setAerial(aerial);
+        if (use_ao) vr.setAmbientOcclusion(true);   // outside the hot path: throws
+        if (show_box) vr.setShowESS(true);
         vr.setBackground(bg);
         vr.updateSamplingRate(rate);
         if (pathtrace) {

@@ -148,3 +148,106 @@ def prefix_sum(tff):
     """volumerendercl.cpp:879-884."""
     tff = np.asarray(tff, dtype=np.uint8).reshape(-1, 4)
     return np.cumsum(tff[:, 3].astype(np.uint64)).astype(np.uint32)
+
+
+# ---- the reference GUI's saved files (SURVEY 8f1): camera state, transfer functions ----------
+
+def read_tff_stops(path):
+    """`.tff` gradient-stop file (MainWindow::readTff / saveTff, mainwindow.cpp:583-657): one
+    stop per line, `position r g b a`; lines with fewer than 5 fields are skipped."""
+    stops = []
+    with open(path) as f:
+        for line in f:
+            p = line.split()
+            if len(p) < 5:
+                continue
+            stops.append((float(p[0]), tuple(int(float(v)) for v in p[1:5])))
+    if not stops:
+        raise ValueError("Empty transfer function file.")
+    return stops
+
+
+def write_tff_stops(path, stops):
+    with open(path, "w") as f:
+        for pos, c in stops:
+            f.write("%s %d %d %d %d\n" % (repr(float(pos)), c[0], c[1], c[2], c[3]))
+
+
+def read_raw_tff(path):
+    """Raw transfer function text file (MainWindow::loadRawTff / saveRawTff, mainwindow.cpp:
+    662-727): whitespace-separated numbers, each cast to unsigned char; RGBA8 table."""
+    import numpy as np
+    with open(path) as f:
+        vals = [float(v) for v in f.read().split()]
+    tff = np.array([int(v) & 0xFF for v in vals], dtype=np.uint8)
+    if tff.size == 0 or tff.size % 4:
+        raise ValueError("Invalid raw transfer function file " + path)
+    return tff
+
+
+def write_raw_tff(path, tff):
+    import numpy as np
+    with open(path, "w") as f:
+        f.write("".join("%d " % int(c) for c in np.asarray(tff, dtype=np.uint8).reshape(-1)))
+
+
+def read_cam_state(path):
+    """JSON state file (MainWindow::loadCamState, mainwindow.cpp:374-410 and
+    VolumeRenderWidget::read, volumerenderwidget.cpp:1457-1480).  Returns a dict with the keys
+    present in the file: rotation (w, x, y, z), translation (x, y, z), imgResFactor, rayStepSize,
+    useLerp, useAO, showContours, useAerial, showBox, useOrtho."""
+    import json
+    with open(path) as f:
+        js = json.load(f)
+    out = {}
+    if "camRotation" in js:
+        p = str(js["camRotation"]).split(" ")
+        if len(p) >= 4:
+            out["rotation"] = tuple(float(v) for v in p[:4])
+    if "camTranslation" in js:
+        p = str(js["camTranslation"]).split(" ")
+        if len(p) >= 3:
+            out["translation"] = tuple(float(v) for v in p[:3])
+    for k in ("imgResFactor", "rayStepSize"):
+        if isinstance(js.get(k), (int, float)) and not isinstance(js.get(k), bool):
+            out[k] = float(js[k])
+    for k in ("useLerp", "useAO", "showContours", "useAerial", "showBox", "useOrtho"):
+        if isinstance(js.get(k), bool):
+            out[k] = js[k]
+    return out
+
+
+def write_cam_state(path, rotation=DEFAULT_ROTATION, translation=DEFAULT_TRANSLATION, **flags):
+    """MainWindow::saveCamState + VolumeRenderWidget::write (mainwindow.cpp:415-452,
+    volumerenderwidget.cpp:1496-1505): floats go through double as QString::number does."""
+    import json
+    import numpy as np
+    js = {"imgResFactor": float(flags.get("imgResFactor", 1.0)),
+          "rayStepSize": float(flags.get("rayStepSize", 1.5))}
+    for k, d in (("useLerp", True), ("useAO", False), ("showContours", False), ("useAerial", False),
+                 ("showBox", False), ("useOrtho", False)):
+        js[k] = bool(flags.get(k, d))
+    js["camRotation"] = " ".join("%.6g" % float(np.float32(v)) for v in rotation)
+    js["camTranslation"] = " ".join("%.6g" % float(np.float32(v)) for v in translation)
+    with open(path, "w") as f:
+        json.dump(js, f, indent=4)
+
+
+def apply_cam_state(vr, state):
+    """Apply a state read by read_cam_state to a VolumeRenderCL (what the GUI's widgets forward)."""
+    vr.updateView(view_matrix(state.get("rotation", DEFAULT_ROTATION),
+                              state.get("translation", DEFAULT_TRANSLATION)))
+    if "rayStepSize" in state:
+        vr.updateSamplingRate(state["rayStepSize"])
+    if "useLerp" in state:
+        vr.setLinearInterpolation(state["useLerp"])
+    if "showContours" in state:
+        vr.setContours(state["showContours"])
+    if "useAerial" in state:
+        vr.setAerial(state["useAerial"])
+    if "useOrtho" in state:
+        vr.setCamOrtho(state["useOrtho"])
+    if state.get("useAO"):
+        vr.setAmbientOcclusion(True)     # outside the hot path: the next render raises
+    if state.get("showBox"):
+        vr.setShowESS(True)
