@@ -1020,9 +1020,11 @@ __global__ __launch_bounds__(kBlockDim) void vr_cont_scatter_kernel(const ContRe
 {
     __shared__ uint32_t s_off[kSortBins], s_cnt[kSortBins], s_base[kSortBins];
     // descending keys: bin k starts after all bins above it
+    for (uint32_t k = threadIdx.x; k < kSortBins; k += kBlockDim) s_cnt[k] = bins[k];
+    __syncthreads();
     for (uint32_t k = threadIdx.x; k < kSortBins; k += kBlockDim) {
         uint32_t o = 0;
-        for (uint32_t j = k + 1; j < kSortBins; ++j) o += bins[j];
+        for (uint32_t j = k + 1; j < kSortBins; ++j) o += s_cnt[j];
         s_off[k] = o;
     }
     const uint32_t n = *count;
