@@ -731,6 +731,63 @@ static f3 trace_volume(const vol_t *v, uint32_t rnd, f3 ray_pos, f3 ray_dir, flo
     return mk3(color[0] * w, color[1] * w, color[2] * w);
 }
 
+/* ------------------------------------------------- ambient occlusion (:38-80, :353-392) */
+
+/* hybrid Tausworthe / LCG generator on the per-pixel uint4 state (volumeraycast.cl:50-80).  The
+ * constant is a double literal: the product is taken in double and rounded to float on return
+ * (OpenCL C with fp64 available). */
+static uint32_t taus_step(uint32_t *z, int s1, int s2, int s3, uint32_t m)
+{
+    uint32_t b = (((*z << (uint32_t)s1) ^ *z) >> (uint32_t)s2);
+    *z = (((*z & m) << (uint32_t)s3) ^ b);
+    return *z;
+}
+
+static float hybrid_rand(uint32_t st[4])
+{
+    uint32_t a = taus_step(&st[0], 13, 19, 12, 4294967294u);
+    uint32_t b = taus_step(&st[1], 2, 25, 4, 4294967288u);
+    uint32_t c = taus_step(&st[2], 3, 11, 17, 4294967280u);
+    uint32_t d = st[3]; /* lcgStep returns the old value (:66-71) */
+    st[3] = 1664525u * st[3] + 1013904223u;
+    return (float)(2.3283064365387e-10 * (double)(float)(a ^ b ^ c ^ d));
+}
+
+/* getUniformRandomSampleDirectionUpper, :353-364 */
+static f3 ao_sample_dir(f3 n, uint32_t st[4])
+{
+    float z = (hybrid_rand(st) * 2.f) - 1.f;
+    float phi = (hybrid_rand(st) * 2.f) * VRO_PI_F;
+    float sn, cs;
+    vro_sincosf(phi, &sn, &cs);
+    float rad = sqrtf(1.f - z * z);
+    f3 dir = mk3(rad * sn, rad * cs, z);
+    if (dot3(n, dir) < 0) dir = mk3(dir.x * -1.f, dir.y * -1.f, dir.z * -1.f);
+    return dir;
+}
+
+/* calcAO, :368-392 (pos in [0,1] volume coordinates) */
+static float calc_ao(const vol_t *v, f3 n, uint32_t st[4], f3 pos, float stepSize, float r)
+{
+    float ao = 0.f;
+    for (int i = 0; i < 16; ++i) {
+        f3 dir = ao_sample_dir(n, st);
+        float sample = 0.f;
+        int cnt = 0;
+        while ((float)cnt * stepSize < r) {
+            ++cnt;
+            f3 p = add3(pos, scale3(scale3(dir, (float)cnt), stepSize));
+            float tfc[4];
+            tff_linear(v->s, vol_linear(v, p.x, p.y, p.z), tfc);
+            sample += tfc[3];
+            if (sample > 0.98f) break;
+        }
+        sample /= (float)cnt;
+        ao += sample;
+    }
+    return ao / 16.f;
+}
+
 /* ------------------------------------------------------------ the kernel */
 
 typedef struct {
@@ -944,7 +1001,18 @@ static void render_pixel(const vol_t *v, const kargs_t *k, uint32_t gx, uint32_t
             result[2] = result[2] - (tfc[2] * opacity) * oma;
             alpha = alpha + opacity * oma;
             if (t >= tfar) break;
-            if ((double)alpha > 0.98) break; /* ERT_THRESHOLD is a double literal (:28) */
+            if ((double)alpha > 0.98) { /* ERT_THRESHOLD is a double literal (:28) */
+                if (k->rc->useAO) { /* :870-876 ambient occlusion only on solid surfaces */
+                    uint32_t st4[4];
+                    st4[0] = st4[1] = st4[2] = st4[3] = vro_parallel_rng3(gx, gy, rp->seed); /* :611 */
+                    f3 n = neg_gradient_central_diff(v, pos);
+                    float vl = len3(voxLen);
+                    float ao = calc_ao(v, n, st4, pos, vl * 0.9f, vl * 5.f);
+                    float f = 1.f - 0.5f * ao;
+                    result[0] *= f; result[1] *= f; result[2] *= f;
+                }
+                break;
+            }
             t += stepSize;
         }
         if (!k->use_ess) break;
@@ -974,7 +1042,7 @@ int vro_render_tile(const vro_scene *scene, const vro_camera_params *cam,
     if (x0 + w > W || y0 + h > H) return -1;
     if (use_ess && (!scene->bricks || !scene->prefix || scene->prefix_n == 0)) return -1;
     if (render->illumType > 5) return -2;
-    if (raycast->useAO || render->imgEss || render->showEss) return -2;
+    if (render->imgEss || render->showEss) return -2;
 
     vol_t v;
     memset(&v, 0, sizeof v);

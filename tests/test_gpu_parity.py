@@ -36,6 +36,7 @@ def _setup(vr, vol, fmt, tff, view, **kw):
     vr.setAerial(kw.get("aerial", False))
     vr.setObjEss(kw.get("ess", True))
     vr.updateSamplingRate(kw.get("rate", 1.5))
+    vr.setAmbientOcclusion(kw.get("ao", False))
     vr.setTechnique(kw.get("technique", 0))
     vr.setExtinction(kw.get("ext", 100.0))
     bb = kw.get("bbox", (-1, -1, -1, 1, 1, 1))
@@ -90,6 +91,10 @@ CASES = [
     (FLOAT, (40, 40, 40), (72, 56), "rot30", "default", {"illum": 5}),
     (FLOAT, (32, 32, 32), (64, 48), "default", "opaque", {"illum": 3, "ess": False}),
     (UCHAR, (40, 40, 40), (64, 48), "inside", "default", {"illum": 5, "aerial": True}),
+    # ambient occlusion at early ray termination (calcAO, volumeraycast.cl:368-392, :870-876)
+    (UCHAR, (48, 48, 48), (80, 64), "rot30", "opaque", {"ao": True}),
+    (FLOAT, (40, 40, 40), (64, 64), "close", "opaque", {"ao": True, "ess": False, "illum": 0}),
+    (USHORT, (40, 44, 36), (64, 56), "rot30", "opaque", {"ao": True, "illum": 3}),
 ]
 
 
@@ -388,7 +393,7 @@ def test_error_behaviour(vr):
     with pytest.raises((RuntimeError, ValueError)):  # unknown shading mode, loud
         r.runRaycastNoGL(32, 32)
     r.setIllumination(1)
-    r.setAmbientOcclusion(True)
+    r.setShowESS(True)
     with pytest.raises(RuntimeError):                # outside the hot path, loud
         r.runRaycastNoGL(32, 32)
     r.close()
@@ -593,3 +598,24 @@ def test_cpp_host_cli_reads_gui_state_and_tff(tmp_path):
     rc.brickRes[:] = brf + [0]
     ref, _, _ = vro.render_tile(vol, vro.UCHAR, tff, cam, rp, rc, W=W, H=H)
     assert np.abs(got - ref).max() <= TOL
+
+
+def test_ambient_occlusion_changes_terminated_rays(vr):
+    """AO darkens exactly the rays that end by early ray termination (alpha channel >= 0.98) and
+    leaves the others untouched."""
+    vol = common.noise_volume((48, 48, 48), UCHAR, seed=7, smooth=False)
+    table = common.tffs()["opaque"]
+    _setup(vr, vol, UCHAR, table, common.views()["rot30"])
+    vr.setStatsEnabled(False)
+    plain = vr.runRaycastNoGL(96, 80)
+    vr.setIteration(0)
+    vr.setAmbientOcclusion(True)
+    ao = vr.runRaycastNoGL(96, 80)
+    vr.setIteration(0)
+    vr.setAmbientOcclusion(False)
+    ert = plain[..., 3] >= 0.98
+    assert ert.sum() > 100
+    np.testing.assert_array_equal(ao[~ert], plain[~ert])
+    np.testing.assert_array_equal(ao[..., 3], plain[..., 3])
+    changed = np.any(ao[ert][:, :3] != plain[ert][:, :3], axis=1)
+    assert changed.mean() > 0.1 and np.all(ao[ert][:, :3] <= plain[ert][:, :3] + 1e-7)

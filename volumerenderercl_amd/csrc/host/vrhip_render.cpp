@@ -195,7 +195,7 @@ int main(int argc, char **argv)
     double extinction = 100.0;
     int downsample = 0;
     std::string state_file, tf_stops;
-    bool contours = false, aerial = false;
+    bool contours = false, aerial = false, use_ao_flag = false;
     std::array<float, 16> view{};
     unsigned illum = 1, seed = 0;
     int frames = 1, device = 0;
@@ -232,6 +232,7 @@ int main(int argc, char **argv)
         else if (a == "--tf-stops") { need(i, 1); tf_stops = argv[++i]; }
         else if (a == "--contours") contours = true;
         else if (a == "--aerial") aerial = true;
+        else if (a == "--ao") use_ao_flag = true;
         else if (a == "--extinction") { need(i, 1); extinction = std::atof(argv[++i]); }
         else if (a == "--device") { need(i, 1); device = std::atoi(argv[++i]); }
         else if (a == "--out") { need(i, 1); out = argv[++i]; }
@@ -256,7 +257,7 @@ int main(int argc, char **argv)
             std::printf("{\"downsampled\": \"%s\"}\n", base.c_str());
             return 0;
         }
-        bool use_ao = false, show_box = false;
+        bool use_ao = use_ao_flag, show_box = false;
         if (!state_file.empty()) {   // what the GUI's widgets would forward after loadCamState
             const CamState st = read_cam_state(state_file);
             if (st.has_rot) for (int k = 0; k < 4; ++k) q[k] = st.q[k];
@@ -285,7 +286,7 @@ int main(int argc, char **argv)
         vr.setUseGradient(gradient_bg);
         vr.setContours(contours);
         vr.setAerial(aerial);
-        if (use_ao) vr.setAmbientOcclusion(true);   // outside the hot path: throws
+        vr.setAmbientOcclusion(use_ao);
         if (show_box) vr.setShowESS(true);
         vr.setBackground(bg);
         vr.updateSamplingRate(rate);

@@ -56,6 +56,8 @@ struct RayDyn {   // marching state
     int c0, c1, c2;
     float tv0, tv1, tv2;
     uint32_t cidx, skw;   // linear index of the current brick cell and its bitmap word
+    float t_ert;          // ray parameter of the sample that triggered early ray termination
+    bool ert;             // (ambient occlusion is applied there, :870-876)
 #ifdef VR_RAYLEN          // diagnostic build: samples taken by the ray, written to the alpha channel
     uint32_t nsmp;
 #endif
@@ -103,6 +105,7 @@ VR_DEV void setup_ray(uint32_t gx, uint32_t gy, bool inside, const FrameView &fr
     d.c0 = d.c1 = d.c2 = 0;
     d.tv0 = d.tv1 = d.tv2 = 0.f;
     d.cidx = 0; d.skw = 0;
+    d.t_ert = 0.f; d.ert = false;
 #ifdef VR_RAYLEN
     d.nsmp = 0;
 #endif
@@ -491,8 +494,13 @@ VR_DEV void composite(const RayCtx &c, RayDyn &d, float q0, float q1, float q2, 
     d.r2 = d.r2 - q2 * oma;
     d.alpha = d.alpha + qo * oma;
     // (double)alpha > 0.98 <=> alpha >= 0.98f (ERT_THRESHOLD, :28); `break`, then :882 breaks
-    if (ti >= c.tfar || d.alpha >= 0.98f) d.state = S_DONE;
-    else d.t = ti + c.stepSize;
+    if (ti >= c.tfar || d.alpha >= 0.98f) {
+        d.state = S_DONE;
+        d.ert = !(ti >= c.tfar);   // :868 breaks before the ERT branch (:869-877) is looked at
+        d.t_ert = ti;
+    } else {
+        d.t = ti + c.stepSize;
+    }
 }
 
 // broadcast lane L of every quad (4 consecutive lanes): one DPP move, no LDS
@@ -503,6 +511,67 @@ template <int L> VR_DEV float quad_bcast(float v)
 template <int L> VR_DEV int quad_bcast(int v)
 {
     return __builtin_amdgcn_update_dpp(0, v, L * 0x55, 0xf, 0xf, true);
+}
+
+// ------------------------------------------------------------------ ambient occlusion
+
+// hybrid Tausworthe / LCG generator on the per-pixel uint4 state (:50-80); the constant is a
+// double literal: product in double, rounded to float on return
+VR_DEV uint32_t taus_step(uint32_t &z, int s1, int s2, int s3, uint32_t m)
+{
+    const uint32_t b = (((z << (uint32_t)s1) ^ z) >> (uint32_t)s2);
+    z = (((z & m) << (uint32_t)s3) ^ b);
+    return z;
+}
+VR_DEV float hybrid_rand(uint32_t (&st)[4])
+{
+    const uint32_t a = taus_step(st[0], 13, 19, 12, 4294967294u);
+    const uint32_t b = taus_step(st[1], 2, 25, 4, 4294967288u);
+    const uint32_t c = taus_step(st[2], 3, 11, 17, 4294967280u);
+    const uint32_t d = st[3];
+    st[3] = 1664525u * st[3] + 1013904223u;
+    return (float)(2.3283064365387e-10 * (double)(float)(a ^ b ^ c ^ d));
+}
+
+// calcAO (:368-392) at the sample that triggered early ray termination, with
+// getUniformRandomSampleDirectionUpper (:353-364); scales the ray's colour by 1 - ao / 2 (:875).
+// Rare mode, rolled loops.
+template <typename VT, int INSTR>
+VR_DEV void apply_ao(const Vol<VT, INSTR> &vol, const float4 *s_tff, int tffn, const RayCtx &c,
+                     RayDyn &d, const vrhip_rendering_params &rp, uint32_t gx, uint32_t gy)
+{
+    const f3 p0 = add3(c.cam, scale3(c.dir, d.t_ert - c.offset));
+    const f3 pos = mk3(p0.x * 0.5f + 0.5f, p0.y * 0.5f + 0.5f, p0.z * 0.5f + 0.5f);
+    const f3 n = vol.neg_gradient(pos.x, pos.y, pos.z);
+    const float vl = len3(mk3(1.f / vol.fw, 1.f / vol.fh, 1.f / vol.fd));
+    const float stepSize = vl * 0.9f, r = vl * 5.f;
+    uint32_t st[4];
+    st[0] = st[1] = st[2] = st[3] = parallel_rng3(gx, gy, rp.seed);   // :611
+    float ao = 0.f;
+#pragma unroll 1
+    for (int i = 0; i < 16; ++i) {
+        const float z = (hybrid_rand(st) * 2.f) - 1.f;
+        const float phi = (hybrid_rand(st) * 2.f) * 3.14159274101257f;
+        float sn, cs;
+        vr_sincosf(phi, &sn, &cs);
+        const float rad = sqrtf(1.f - z * z);
+        f3 dir = mk3(rad * sn, rad * cs, z);
+        if (dot3(n, dir) < 0) dir = mk3(dir.x * -1.f, dir.y * -1.f, dir.z * -1.f);
+        float sample = 0.f;
+        int cnt = 0;
+#pragma unroll 1
+        while ((float)cnt * stepSize < r) {
+            ++cnt;
+            const f3 p = add3(pos, scale3(scale3(dir, (float)cnt), stepSize));
+            sample += tff_linear_alpha(s_tff, tffn, vol.linear(p.x, p.y, p.z));
+            if (sample > 0.98f) break;
+        }
+        sample /= (float)cnt;
+        ao += sample;
+    }
+    ao = ao / 16.f;
+    const float f = 1.f - 0.5f * ao;
+    d.r0 *= f; d.r1 *= f; d.r2 *= f;
 }
 
 // Running mean over iterations (:898-909, fp32 accumulate buffer) and the two writes.
@@ -766,6 +835,8 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_kernel(
                 fr.cont[base + rank] = r;
             }
         }
+        if (XS && rc.useAO && inside && !cont && !prepass_done && d.ert)
+            apply_ao<VT, INSTR>(vol, s_tff, tffn, c, d, rp, gx, gy);
         if (inside && !cont && !prepass_done)
             write_pixel(fr, rp, c, d, gx, gy, (size_t)wt.out_base + (size_t)ly * fr.out_stride + lx);
         VR_STAMP(7);
@@ -977,6 +1048,8 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
                 VR_STAMP(6);
             }
         }
+        if (XS && rc.useAO && have && slot == 0 && d.ert)
+            apply_ao<VT, INSTR>(vol, s_tff, tffn, c, d, rp, gx, gy);
         if (have && slot == 0) {
             write_pixel(fr, rp, c, d, gx, gy, (size_t)rec.out_index);
             if (fr.cost) fr.cost[(size_t)gy * fr.W + gx] = (uint16_t)(my_rounds < 65535u ? my_rounds : 65535u);
@@ -1141,7 +1214,7 @@ hipError_t launch_typed(const RaycastLaunch &a, hipStream_t stream)
     const bool lds = a.skip.in_lds != 0;
     // the rarely used shading modes 2-5 live in kernel variants of their own (XS), so that their
     // code and registers do not tax the default ones
-    const bool xs = a.render.illumType >= 2;
+    const bool xs = a.render.illumType >= 2 || a.raycast.useAO != 0;
     if (a.use_ess) {
         if (lds) {
             if (a.instr == 0) return xs ? launch_variant<VT, true, 0, true, true>(a, stream) : launch_variant<VT, true, 0, true, false>(a, stream);

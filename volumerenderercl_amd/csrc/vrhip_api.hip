@@ -326,9 +326,8 @@ int check_renderable(vrhip_renderer *r, uint32_t width, uint32_t height)
                "Unknown illumination type.");
     VR_REQUIRE(r, r->render.technique == 0 || r->pathtrace.max_extinction > 0.f, VRHIP_ERR_INVALID,
                "max_extinction must be positive.");
-    VR_REQUIRE(r, !r->render.imgEss && !r->render.showEss && !r->raycast.useAO,
-               VRHIP_ERR_UNSUPPORTED,
-               "image-order ESS / showEss / ambient occlusion are outside the hot path (SURVEY 8f).");
+    VR_REQUIRE(r, !r->render.imgEss && !r->render.showEss, VRHIP_ERR_UNSUPPORTED,
+               "image-order ESS / showEss are outside the hot path (SURVEY 8f).");
     return VRHIP_OK;
 }
 

@@ -247,7 +247,7 @@ def apply_cam_state(vr, state):
         vr.setAerial(state["useAerial"])
     if "useOrtho" in state:
         vr.setCamOrtho(state["useOrtho"])
-    if state.get("useAO"):
-        vr.setAmbientOcclusion(True)     # outside the hot path: the next render raises
+    if "useAO" in state:
+        vr.setAmbientOcclusion(state["useAO"])
     if state.get("showBox"):
         vr.setShowESS(True)
