@@ -964,6 +964,9 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
             if (!__ballot(d.state != S_DONE)) break;
             VR_COUNT(10);
             my_rounds += d.state != S_DONE ? 1u : 0u;
+#ifdef VR_CAP_ROUNDS   // diagnostic build (wrong image): is phase 2 bound by its longest rays?
+            if (my_rounds >= VR_CAP_ROUNDS) d.state = S_DONE;
+#endif
             bool more_empty = false;
             if (skip_empty && lookahead_pays(d.state == S_SAMPLE, guess_empty)) {
                 if (d.state == S_SAMPLE) {
