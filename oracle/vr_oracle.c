@@ -797,12 +797,48 @@ typedef struct {
     const vro_pathtrace_params *pt;
     int use_ess;
     uint32_t gsx, gsy; /* padded launch size */
+    const vro_frame_extras *ex;
+    uint32_t hit_w, hit_h; /* hit image dims: W/8 + 1, H/8 + 1 (volumerendercl.cpp:482-488) */
 } kargs_t;
+
+/* what a work-item of volumeRender did, for the image-order ESS bookkeeping (:659-670, :912-925) */
+enum { PX_SKIPPED = 0, PX_MISS = 1, PX_SILENT = 2, PX_END = 3, PX_DIFFERS = 4 };
+
+/* volumeraycast.cl:323-343 */
+static int check_bounding_box(f3 pos, f3 voxLen, float b0, float b1)
+{
+    return (pos.x < voxLen.x && pos.z < b0 + voxLen.z) ||
+           (pos.x < voxLen.x && pos.y < voxLen.y) ||
+           (pos.y < voxLen.y && pos.z < b0 + voxLen.z) ||
+           (pos.x > 1.f - voxLen.x && pos.z < b0 + voxLen.z) ||
+           (pos.y > 1.f - voxLen.y && pos.z < b0 + voxLen.z) ||
+           (pos.x > 1.f - voxLen.x && pos.z > b1 - voxLen.z) ||
+           (pos.y > 1.f - voxLen.y && pos.z > b1 - voxLen.z) ||
+           (pos.x < voxLen.x && pos.z > b1 - voxLen.z) ||
+           (pos.y < voxLen.y && pos.z > b1 - voxLen.z) ||
+           (pos.x > 1.f - voxLen.x && pos.y < voxLen.y) ||
+           (pos.x > 1.f - voxLen.x && pos.y > 1.f - voxLen.y) ||
+           (pos.x < voxLen.x && pos.y > 1.f - voxLen.y);
+}
+
+/* getLastHit (:513-526): 3x3 sum around the work-group; reads outside the image (undefined for
+ * a sampler-less read) are taken as 0 */
+static uint32_t last_hit(const kargs_t *k, int gx8, int gy8)
+{
+    uint32_t sum = 0;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            int x = gx8 + dx, y = gy8 + dy;
+            if (x < 0 || y < 0 || x >= (int)k->hit_w || y >= (int)k->hit_h) continue;
+            sum += k->ex->hit_in[(size_t)y * k->hit_w + x];
+        }
+    return sum;
+}
 
 /* volumeRender, volumeraycast.cl:589-926, one work-item.  `prev` is the pixel of
  * inAccumulate (or NULL).  Always writes out[4]. */
-static void render_pixel(const vol_t *v, const kargs_t *k, uint32_t gx, uint32_t gy,
-                         const float *prev, float out[4], vro_stats *st)
+static int render_pixel(const vol_t *v, const kargs_t *k, uint32_t gx, uint32_t gy,
+                        const float *prev, float out[4], vro_stats *st)
 {
     const vro_camera_params *cam = k->cam;
     const vro_rendering_params *rp = k->rp;
@@ -849,13 +885,21 @@ static void render_pixel(const vol_t *v, const kargs_t *k, uint32_t gx, uint32_t
     float env[4];
     for (int i = 0; i < 4; ++i) env[i] = rp->backgroundColor[i] * bgf;
 
+    /* :658-670 image-order ESS: nothing was hit in or around this work-group last frame */
+    if (rp->imgEss) {
+        if (!last_hit(k, (int)(gx / 8u), (int)(gy / 8u))) {
+            for (int i = 0; i < 4; ++i) out[i] = rp->showEss ? 1.f - env[i] : env[i];
+            return PX_SKIPPED;
+        }
+    }
+
     /* :672-683 */
     float tnear, tfar;
     float o[3] = {camPos.x, camPos.y, camPos.z}, d[3] = {rayDir.x, rayDir.y, rayDir.z};
     int hit = vro_intersect_bbox(o, d, cam->bbox_bl, cam->bbox_tr, &tnear, &tfar);
     if (!hit || tfar < 0) {
         memcpy(out, env, sizeof env);
-        return;
+        return PX_MISS;
     }
     st->rays_hit++;
 
@@ -870,14 +914,14 @@ static void render_pixel(const vol_t *v, const kargs_t *k, uint32_t gx, uint32_t
             col.z = prev[2] + (col.z - prev[2]) / it1;
         }
         out[0] = col.x; out[1] = col.y; out[2] = col.z; out[3] = 1.f;
-        return;
+        return PX_SILENT;
     }
 
     /* :709-733 */
     float sampleDist = tfar - tnear;
     if (sampleDist <= 0.f) { /* unreachable after the hit test; write bg */
         memcpy(out, env, sizeof env);
-        return;
+        return PX_SILENT;
     }
     f3 resf = mk3(v->fw, v->fh, v->fd);
     float stepSize = vmin(sampleDist,
@@ -923,6 +967,7 @@ static void render_pixel(const vol_t *v, const kargs_t *k, uint32_t gx, uint32_t
     }
 
     const f3 toLight = neg3(rayDir);
+    f3 pos = mk3(0.f, 0.f, 0.f); /* :722: lives outside the loops, showEss looks at the last one */
     int outer_first = 1;
     /* :763 / (non-ESS: a single pass of the inner loop with t_exit = tfar) */
     while (k->use_ess ? (t < tfar) : outer_first) {
@@ -956,7 +1001,7 @@ static void render_pixel(const vol_t *v, const kargs_t *k, uint32_t gx, uint32_t
         /* :790-880 */
         while (t < t_exit) {
             st->samples_taken++;
-            f3 pos = add3(camPos, scale3(rayDir, t - offset));
+            pos = add3(camPos, scale3(rayDir, t - offset));
             pos = mk3(pos.x * 0.5f + 0.5f, pos.y * 0.5f + 0.5f, pos.z * 0.5f + 0.5f);
             float tfc[4];
             f3 grad = mk3(0.f, 0.f, 0.f);
@@ -1021,6 +1066,13 @@ static void render_pixel(const vol_t *v, const kargs_t *k, uint32_t gx, uint32_t
         t = t_exit; /* :884 */
     }
 
+    /* :888-896 visualise the skipping: rays that never sampled (pos still 0) and rays that end
+     * next to an edge of the box get the inverted background colour */
+    if (rp->showEss && check_bounding_box(pos, voxLen, 0.f, 1.f)) {
+        for (int i = 0; i < 3; ++i) result[i] = fabsf(1.f - rp->backgroundColor[i]);
+        alpha = 1.f;
+    }
+
     /* :898-909 (float accumulation) */
     result[3] = alpha;
     if (rp->iteration != 0 && prev) {
@@ -1028,6 +1080,9 @@ static void render_pixel(const vol_t *v, const kargs_t *k, uint32_t gx, uint32_t
         for (int i = 0; i < 3; ++i) result[i] = prev[i] + (result[i] - prev[i]) / it1;
     }
     memcpy(out, result, sizeof result);
+    /* :912-925: did this work-item change its pixel? */
+    return (result[0] != env[0] || result[1] != env[1] || result[2] != env[2]) ? (PX_END | PX_DIFFERS)
+                                                                             : PX_END;
 }
 
 int vro_render_tile(const vro_scene *scene, const vro_camera_params *cam,
@@ -1036,13 +1091,42 @@ int vro_render_tile(const vro_scene *scene, const vro_camera_params *cam,
                     uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, const float *in_accum,
                     float *out, vro_stats *stats, uint8_t *touched, int threads)
 {
+    return vro_render_tile_ex(scene, cam, render, raycast, pathtrace, use_ess, W, H, x0, y0, w, h,
+                              in_accum, out, stats, touched, threads, NULL);
+}
+
+void vro_hit_image_init(uint32_t W, uint32_t H, uint8_t *hit_in, uint8_t *hit_out)
+{
+    /* volumerendercl.cpp:482-488: the input image is created from a vector of 32-bit ones but read
+     * as one byte per texel, i.e. from the bytes 1,0,0,0,1,...; the output image starts
+     * uninitialised (taken as 0 here) */
+    const size_t n = (size_t)(W / 8u + 1u) * (H / 8u + 1u);
+    for (size_t i = 0; i < n; ++i) {
+        hit_in[i] = (i % 4u) == 0u ? 1u : 0u;
+        hit_out[i] = 0u;
+    }
+}
+
+int vro_render_tile_ex(const vro_scene *scene, const vro_camera_params *cam,
+                    const vro_rendering_params *render, const vro_raycast_params *raycast,
+                    const vro_pathtrace_params *pathtrace, int use_ess, uint32_t W, uint32_t H,
+                    uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, const float *in_accum,
+                    float *out, vro_stats *stats, uint8_t *touched, int threads,
+                    const vro_frame_extras *ex)
+{
     if (!scene || !scene->voxels || !scene->tff || !cam || !render || !raycast || !out)
         return -1;
     if (scene->format < 0 || scene->format > 2 || scene->tff_n == 0) return -1;
     if (x0 + w > W || y0 + h > H) return -1;
     if (use_ess && (!scene->bricks || !scene->prefix || scene->prefix_n == 0)) return -1;
     if (render->illumType > 5) return -2;
-    if (render->imgEss || render->showEss) return -2;
+    if (render->imgEss) {
+        /* the hit image is kept per 8x8 work-group: the tile must consist of whole groups */
+        if (!ex || !ex->hit_in || !ex->hit_out) return -1;
+        if (x0 % 8u || y0 % 8u || (w % 8u && x0 + w != W) || (h % 8u && y0 + h != H)) return -1;
+        if (render->technique == 1) return -2;
+    }
+    if (ex && ex->env_rgba) return -2;
 
     vol_t v;
     memset(&v, 0, sizeof v);
@@ -1060,7 +1144,12 @@ int vro_render_tile(const vro_scene *scene, const vro_camera_params *cam,
 
     vro_pathtrace_params pt_default = {100.f};
     kargs_t k = {cam, render, raycast, pathtrace ? pathtrace : &pt_default, use_ess,
-                 vro_padded(W), vro_padded(H)};
+                 vro_padded(W), vro_padded(H), ex, W / 8u + 1u, H / 8u + 1u};
+    uint8_t *status = NULL;
+    if (render->imgEss) {
+        status = (uint8_t *)malloc((size_t)w * h);
+        if (!status) return -3;
+    }
 
     vro_stats total;
     memset(&total, 0, sizeof total);
@@ -1082,8 +1171,9 @@ int vro_render_tile(const vro_scene *scene, const vro_camera_params *cam,
             const uint32_t xb = (uint32_t)(u % cw) * 8u;
             for (uint32_t lx = xb; lx < xb + 8u && lx < w; ++lx) {
                 size_t o = ((size_t)ly * w + lx) * 4;
-                render_pixel(&v, &k, x0 + lx, y0 + (uint32_t)ly, in_accum ? in_accum + o : NULL,
-                             out + o, &st);
+                int px = render_pixel(&v, &k, x0 + lx, y0 + (uint32_t)ly,
+                                      in_accum ? in_accum + o : NULL, out + o, &st);
+                if (status) status[(size_t)ly * w + lx] = (uint8_t)px;
             }
         }
 #pragma omp critical
@@ -1097,6 +1187,28 @@ int vro_render_tile(const vro_scene *scene, const vro_camera_params *cam,
         }
     }
     if (stats) *stats = total;
+    if (status) {
+        /* :664-667, :680-681, :912-925 on a device that runs the 64 work-items of a group in
+         * lock-step: a skipped group writes 0; work-items that miss the box write 0 early; the
+         * group's first work-item, if it reaches the end, has the last word (1 if any work-item
+         * that reached the end changed its pixel); otherwise the texel keeps its old value */
+        for (uint32_t gy0 = 0; gy0 < h; gy0 += 8u)
+            for (uint32_t gx0 = 0; gx0 < w; gx0 += 8u) {
+                int any_miss = 0, any_diff = 0;
+                for (uint32_t yy = gy0; yy < gy0 + 8u && yy < h; ++yy)
+                    for (uint32_t xx = gx0; xx < gx0 + 8u && xx < w; ++xx) {
+                        const uint8_t sx = status[(size_t)yy * w + xx];
+                        any_miss |= sx == PX_MISS;
+                        any_diff |= (sx & PX_DIFFERS) != 0;
+                    }
+                const uint8_t first = status[(size_t)gy0 * w + gx0];
+                uint8_t *dst = &ex->hit_out[(size_t)((y0 + gy0) / 8u) * k.hit_w + (x0 + gx0) / 8u];
+                if (first == PX_SKIPPED) *dst = 0;
+                else if ((first & 3) == PX_END) *dst = any_diff ? 1 : 0;
+                else if (any_miss) *dst = 0;
+            }
+        free(status);
+    }
     return 0;
 }
 

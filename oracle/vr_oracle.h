@@ -139,6 +139,27 @@ int vro_render_tile(const vro_scene *scene, const vro_camera_params *cam,
                     uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, const float *in_accum,
                     float *out, vro_stats *stats, uint8_t *touched, int threads);
 
+/* Inter-frame inputs of volumeRender beyond the accumulate image. */
+typedef struct {
+    const uint8_t *hit_in;  /* imgEss: last frame's hit image, (W/8+1)*(H/8+1) bytes, row-major   */
+    uint8_t *hit_out;       /* this frame's; only the work-groups of the tile are (maybe) written */
+    const float *env_rgba;  /* environment map, float RGBA, env_w*env_h texels; NULL = none       */
+    uint32_t env_w, env_h;
+} vro_frame_extras;
+
+/* vro_render_tile plus image-order ESS (volumeraycast.cl:659-670, :912-925; needs a tile of whole
+ * 8x8 work-groups) and the environment map (:506-510, :655-656).  The caller swaps hit_in/hit_out
+ * between frames like runRaycast does (volumerendercl.cpp:524-530). */
+int vro_render_tile_ex(const vro_scene *scene, const vro_camera_params *cam,
+                       const vro_rendering_params *render, const vro_raycast_params *raycast,
+                       const vro_pathtrace_params *pathtrace, int use_ess, uint32_t W, uint32_t H,
+                       uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, const float *in_accum,
+                       float *out, vro_stats *stats, uint8_t *touched, int threads,
+                       const vro_frame_extras *ex);
+/* Initial contents of the two hit images as updateOutputImg leaves them
+ * (volumerendercl.cpp:482-488), each (W/8+1)*(H/8+1) bytes. */
+void vro_hit_image_init(uint32_t W, uint32_t H, uint8_t *hit_in, uint8_t *hit_out);
+
 /* Synthetic inputs of SURVEY 8(d): kind 0 = sphere, 1 = shells. */
 int vro_synth_volume(int kind, const uint32_t res[3], int format, void *out);
 

@@ -96,6 +96,10 @@ def lib():
             C.POINTER(RaycastParams), C.POINTER(PathtraceParams), C.c_int,
             C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
             C.c_void_p, C.c_void_p, C.POINTER(Stats), C.c_void_p, C.c_int]
+        L.vro_render_tile_ex.restype = C.c_int
+        L.vro_render_tile_ex.argtypes = L.vro_render_tile.argtypes + [C.POINTER(FrameExtras)]
+        L.vro_hit_image_init.restype = None
+        L.vro_hit_image_init.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.vro_generate_bricks.restype = C.c_int
         L.vro_generate_bricks.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int,
                                           C.POINTER(C.c_uint32), C.c_void_p]
@@ -169,10 +173,26 @@ def synth_volume(kind, res, fmt):
     return out
 
 
+class FrameExtras(C.Structure):
+    _fields_ = [("hit_in", C.c_void_p), ("hit_out", C.c_void_p), ("env_rgba", C.c_void_p),
+                ("env_w", C.c_uint32), ("env_h", C.c_uint32)]
+
+
+def hit_image_init(W, H):
+    """(hit_in, hit_out) as updateOutputImg leaves them: uint8 [(H/8+1), (W/8+1)] each."""
+    shape = (H // 8 + 1, W // 8 + 1)
+    a, b = np.zeros(shape, np.uint8), np.zeros(shape, np.uint8)
+    lib().vro_hit_image_init(W, H, a.ctypes.data, b.ctypes.data)
+    return a, b
+
+
 def render_tile(vol, fmt, tff, cam, rp, rc, pt=None, use_ess=True, W=64, H=64, tile=None,
-                in_accum=None, bricks=None, prefix=None, want_touched=False, threads=0):
+                in_accum=None, bricks=None, prefix=None, want_touched=False, threads=0,
+                hit_in=None, hit_out=None, env=None):
     """Render the tile (x0, y0, w, h) of a W x H frame with the oracle.
 
+    hit_in / hit_out: image-order ESS state (uint8 [(H/8+1), (W/8+1)], hit_out is updated in
+    place); env: environment map, float32 [h, w, 4].
     Returns (rgba float32 [h, w, 4], stats dict, touched-bitmap or None).
     """
     vol = np.ascontiguousarray(vol, dtype=_NP_DTYPE[fmt])
@@ -206,11 +226,21 @@ def render_tile(vol, fmt, tff, cam, rp, rc, pt=None, use_ess=True, W=64, H=64, t
     if in_accum is not None:
         acc = np.ascontiguousarray(in_accum, dtype=np.float32)
     pt = pt if pt is not None else PathtraceParams(100.0)
-    r = lib().vro_render_tile(C.byref(sc), C.byref(cam), C.byref(rp), C.byref(rc), C.byref(pt),
-                              1 if use_ess else 0, W, H, x0, y0, w, h,
-                              acc.ctypes.data if acc is not None else None,
-                              out.ctypes.data, C.byref(st),
-                              touched.ctypes.data if touched is not None else None, threads)
+    ex = FrameExtras()
+    if hit_in is not None:
+        assert hit_in.dtype == np.uint8 and hit_out.dtype == np.uint8
+        assert hit_in.flags.c_contiguous and hit_out.flags.c_contiguous
+        assert hit_in.shape == (H // 8 + 1, W // 8 + 1) == hit_out.shape
+        ex.hit_in, ex.hit_out = hit_in.ctypes.data, hit_out.ctypes.data
+    if env is not None:
+        env = np.ascontiguousarray(env, dtype=np.float32)
+        ex.env_rgba, ex.env_w, ex.env_h = env.ctypes.data, env.shape[1], env.shape[0]
+    r = lib().vro_render_tile_ex(C.byref(sc), C.byref(cam), C.byref(rp), C.byref(rc), C.byref(pt),
+                                 1 if use_ess else 0, W, H, x0, y0, w, h,
+                                 acc.ctypes.data if acc is not None else None,
+                                 out.ctypes.data, C.byref(st),
+                                 touched.ctypes.data if touched is not None else None, threads,
+                                 C.byref(ex))
     if r != 0:
         raise RuntimeError("vro_render_tile failed: %d" % r)
     return out, st.as_dict(), touched

@@ -142,3 +142,78 @@ def test_downsample_box_mean():
     lo = vro.downsample(f, vro.FLOAT, 3)                               # res (6,4,4) -> (2,2,2)
     assert lo.shape == (2, 2, 2)
     np.testing.assert_allclose(lo[0, 0, 0], f[:2, :2, :3].sum() / 12.0, rtol=1e-6)
+
+
+def test_show_ess_marks_skipped_rays_and_box_edges():
+    """showEss (:888-896): rays that never sample keep pos = 0 and get |1 - background| with
+    alpha 1; so do rays whose last sample lies next to an edge of the box."""
+    vol = np.zeros((32, 32, 32), np.uint8)
+    vol[8:24, 8:24, 8:24] = 200
+    cam, rp, rc = _params(illum=0)
+    rp.backgroundColor[:] = [0.25, 0.5, 1.0, 1.0]
+    tff = frontend.tff_from_stops()
+    plain, _, _ = vro.render_tile(vol, vro.UCHAR, tff, cam, rp, rc, W=64, H=64)
+    rp.showEss = 1
+    shown, st, _ = vro.render_tile(vol, vro.UCHAR, tff, cam, rp, rc, W=64, H=64)
+    marked = np.all(shown[..., :3] == np.float32([0.75, 0.5, 0.0]), axis=-1) & (shown[..., 3] == 1)
+    hit_box = plain[..., 3] != 1.0          # missed rays carry the background alpha (1)
+    # rays that meet the box but no brick to sample are marked: all of them for an empty volume
+    assert (marked & hit_box).sum() > 0 and st["samples_taken"] > 0
+    rp.showEss = 1
+    empty, st0, _ = vro.render_tile(np.zeros_like(vol), vro.UCHAR, tff, cam, rp, rc, W=64, H=64)
+    assert st0["samples_taken"] == 0
+    m0 = np.all(empty[..., :3] == np.float32([0.75, 0.5, 0.0]), axis=-1) & (empty[..., 3] == 1)
+    assert np.array_equal(m0, hit_box)
+    # unmarked pixels are those of the plain frame
+    assert np.array_equal(shown[~marked], plain[~marked])
+    assert not marked[~hit_box].any()
+
+
+def test_image_order_ess_sequence():
+    """imgEss (:659-670, :912-925): groups without a hit in their 3x3 neighbourhood last frame
+    are filled with the background; the hit image converges to the footprint of the volume."""
+    vol = np.zeros((32, 32, 32), np.uint8)
+    vol[12:20, 12:20, 12:20] = 255
+    cam, rp, rc = _params(illum=0)
+    tff = frontend.tff_from_stops()
+    W, H = 96, 80
+    plain, _, _ = vro.render_tile(vol, vro.UCHAR, tff, cam, rp, rc, W=W, H=H)
+    rp.imgEss = 1
+    hin, hout = vro.hit_image_init(W, H)
+    assert hin.shape == (H // 8 + 1, W // 8 + 1) and hin.reshape(-1)[:8].tolist() == [1, 0, 0, 0] * 2
+    frames = []
+    for _ in range(4):
+        img, _, _ = vro.render_tile(vol, vro.UCHAR, tff, cam, rp, rc, W=W, H=H, hit_in=hin,
+                                    hit_out=hout)
+        frames.append((img, hin.copy(), hout.copy()))
+        hin, hout = hout, hin        # runRaycast's swap (volumerendercl.cpp:524-530)
+    changed = np.any(plain[..., :3] != 1.0, axis=-1)
+    for img, h_in, h_out in frames:
+        for gy in range(H // 8):
+            for gx in range(W // 8):
+                nb = h_in[max(gy - 1, 0):gy + 2, max(gx - 1, 0):gx + 2].sum()
+                blk = (slice(gy * 8, gy * 8 + 8), slice(gx * 8, gx * 8 + 8))
+                if nb == 0:
+                    assert np.all(img[blk][..., :3] == 1.0) and h_out[gy, gx] == 0
+                else:
+                    assert np.array_equal(img[blk], plain[blk])
+    # the first frame starts from the reference's 1,0,0,0 byte pattern: with 13 groups per row
+    # every group has a set neighbour, so the whole image is rendered and the hit image is exact
+    h1 = frames[0][2]
+    want = np.zeros_like(h1)
+    for gy in range(H // 8):
+        for gx in range(W // 8):
+            want[gy, gx] = changed[gy * 8:gy * 8 + 8, gx * 8:gx * 8 + 8].any()
+    assert np.array_equal(h1, want)
+    # steady state: the colours equal the plain frame's (hit groups have their neighbours
+    # rendered; skipped pixels carry the background's alpha instead of 0)
+    assert np.array_equal(frames[-1][0][..., :3], plain[..., :3])
+    assert frames[-1][1].sum() < frames[0][1].size // 2
+    # a tile of whole groups gives the same pixels and hit texels as the full frame
+    hin, hout = vro.hit_image_init(W, H)
+    hout2 = hout.copy()
+    full, _, _ = vro.render_tile(vol, vro.UCHAR, tff, cam, rp, rc, W=W, H=H, hit_in=hin, hit_out=hout)
+    part, _, _ = vro.render_tile(vol, vro.UCHAR, tff, cam, rp, rc, W=W, H=H, tile=(32, 16, 40, 48),
+                                 hit_in=hin, hit_out=hout2)
+    assert np.array_equal(part, full[16:64, 32:72])
+    assert np.array_equal(hout2[2:8, 4:9], hout[2:8, 4:9]) and hout2.sum() == hout[2:8, 4:9].sum()
