@@ -160,6 +160,20 @@ int vrhip_render_frame(vrhip_renderer *r, uint32_t width, uint32_t height, float
 int vrhip_render_tiles(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t tile_w,
                        uint32_t tile_h, const uint32_t *tile_ids, uint32_t n_tiles,
                        float *out_tiles_dev);
+/* ---- image-order ESS (rendering_params.imgEss; volumeraycast.cl:659-670, :912-925) --------
+ * The renderer keeps the reference's two hit images, (width/8 + 1) x (height/8 + 1) texels of one
+ * byte, creates them on the first imgEss frame of a size with updateOutputImg's initial contents
+ * (volumerendercl.cpp:482-488) and swaps them after every imgEss frame (:524-530).  A tile render
+ * only updates the texels of its own 8x8 work-groups: with several GPUs the caller merges the
+ * images between frames (get on every rank, exchange, set; volumerenderercl_amd/tiles.py).
+ * vrhip_reset_image_ess: what updateOutputImg does to them (re-created on the next frame).
+ * get/set: hit_in = the image the next frame reads, hit_out = the one it writes; either may be
+ * NULL.  Not supported together with technique 1. */
+int vrhip_reset_image_ess(vrhip_renderer *r);
+int vrhip_get_image_ess(vrhip_renderer *r, uint32_t width, uint32_t height, uint8_t *hit_in,
+                        uint8_t *hit_out);
+int vrhip_set_image_ess(vrhip_renderer *r, uint32_t width, uint32_t height, const uint8_t *hit_in,
+                        const uint8_t *hit_out);
 /* getLastExecTime (volumerendercl.cpp:1053-1056): HIP-event time of the last ray-cast
  * kernel launch, seconds. */
 double vrhip_last_kernel_seconds(const vrhip_renderer *r);

@@ -41,6 +41,12 @@ def _setup(vr, vol, fmt, tff, view, **kw):
     vr.setExtinction(kw.get("ext", 100.0))
     bb = kw.get("bbox", (-1, -1, -1, 1, 1, 1))
     vr.setBBox(*bb)
+    vr.setShowESS(kw.get("show_ess", False))
+    vr.setImgEss(kw.get("img_ess", False))
+    if "background" in kw:
+        vr.setBackground(kw["background"])          # (alpha becomes 0 like in the reference)
+    else:
+        vr.params()[1].backgroundColor[:] = [1.0, 1.0, 1.0, 1.0]
     vr.updateView(view)
     vr.setIteration(0)
 
@@ -95,6 +101,11 @@ CASES = [
     (UCHAR, (48, 48, 48), (80, 64), "rot30", "opaque", {"ao": True}),
     (FLOAT, (40, 40, 40), (64, 64), "close", "opaque", {"ao": True, "ess": False, "illum": 0}),
     (USHORT, (40, 44, 36), (64, 56), "rot30", "opaque", {"ao": True, "illum": 3}),
+    # showEss (:888-896): rays without a sample and rays ending next to a box edge are marked
+    (UCHAR, (48, 48, 48), (96, 80), "rot30", "default",
+     {"show_ess": True, "background": (0.25, 0.5, 1.0, 1.0)}),
+    (USHORT, (40, 44, 36), (64, 56), "default", "haze", {"show_ess": True, "ess": False}),
+    (FLOAT, (40, 40, 40), (64, 64), "close", "opaque", {"show_ess": True, "illum": 0}),
 ]
 
 
@@ -393,8 +404,9 @@ def test_error_behaviour(vr):
     with pytest.raises((RuntimeError, ValueError)):  # unknown shading mode, loud
         r.runRaycastNoGL(32, 32)
     r.setIllumination(1)
-    r.setShowESS(True)
-    with pytest.raises(RuntimeError):                # outside the hot path, loud
+    r.setImgEss(True)
+    r.setTechnique(1)
+    with pytest.raises(RuntimeError):                # unsupported combination, loud
         r.runRaycastNoGL(32, 32)
     r.close()
 
@@ -619,3 +631,119 @@ def test_ambient_occlusion_changes_terminated_rays(vr):
     np.testing.assert_array_equal(ao[..., 3], plain[..., 3])
     changed = np.any(ao[ert][:, :3] != plain[ert][:, :3], axis=1)
     assert changed.mean() > 0.1 and np.all(ao[ert][:, :3] <= plain[ert][:, :3] + 1e-7)
+
+
+def _sparse_volume(res=(48, 48, 48)):
+    vol = np.zeros(res[::-1], np.uint8)
+    c = common.noise_volume((16, 16, 16), UCHAR, seed=3, smooth=False)
+    vol[14:30, 20:36, 10:26] = np.maximum(c, 60)
+    return vol
+
+
+@pytest.mark.parametrize("kw", [{}, {"show_ess": True}, {"ess": False, "illum": 0}])
+def test_image_order_ess_sequence_matches_oracle(vr, kw):
+    """imgEss (:659-670, :912-925): four frames from the reference's initial hit images; every
+    frame and both hit images equal the oracle's, with the ping-pong swap in between."""
+    vol = _sparse_volume()
+    tff = frontend.tff_from_stops()
+    W, H = 136, 104
+    _setup(vr, vol, UCHAR, tff, common.views()["rot30"], img_ess=True, **kw)
+    vr.updateOutputImg(W, H)
+    hin, hout = vro.hit_image_init(W, H)
+    g_in, g_out = vr.getImageEss(W, H)
+    assert np.array_equal(g_in, hin) and np.array_equal(g_out, hout)
+    cam, rp, rc, pt = common.to_oracle_params(*vr.params())
+    skipped = []
+    for frame in range(4):
+        got = vr.runRaycastNoGL(W, H)
+        vr.setIteration(0)
+        ref, _, _ = vro.render_tile(vol, UCHAR, tff, cam, rp, rc, pt, use_ess=kw.get("ess", True),
+                                    W=W, H=H, hit_in=hin, hit_out=hout)
+        assert np.abs(got - ref).max() <= TOL
+        hin, hout = hout, hin
+        g_in, g_out = vr.getImageEss(W, H)
+        assert np.array_equal(g_in, hin), "frame %d: hit image differs" % frame
+        assert np.array_equal(g_out, hout)
+        skipped.append(int((hin == 0).sum()))
+    assert 0 < skipped[-1] and hin.sum() > 0        # something is skipped, something is hit
+    # updateOutputImg starts the hit images over (volumerendercl.cpp:482-488)
+    vr.updateOutputImg(W, H)
+    g_in, _ = vr.getImageEss(W, H)
+    assert np.array_equal(g_in, vro.hit_image_init(W, H)[0])
+    vr.setImgEss(False)
+
+
+def test_image_order_ess_tiles(vr):
+    """A tile render reads the whole hit image and updates the texels of its own groups only."""
+    import torch
+    vol = _sparse_volume()
+    tff = frontend.tff_from_stops()
+    W, H, TW, TH = 136, 104, 32, 48
+    _setup(vr, vol, UCHAR, tff, common.views()["rot30"], img_ess=True)
+    vr.updateOutputImg(W, H)
+    full = vr.runRaycastNoGL(W, H)
+    vr.setIteration(0)
+    hit_full, _ = vr.getImageEss(W, H)              # after the swap: what the frame wrote
+    vr.updateOutputImg(W, H)
+    tiles_x, tiles_y = (W + TW - 1) // TW, (H + TH - 1) // TH
+    ids = np.array([t for t in range(tiles_x * tiles_y) if t % 2 == 0], dtype=np.uint32)
+    out = torch.zeros((len(ids), TH, TW, 4), dtype=torch.float32, device="cuda")
+    vr.render_tiles(W, H, TW, TH, ids, out.data_ptr())
+    torch.cuda.synchronize()
+    hit_tiles, _ = vr.getImageEss(W, H)
+    o = out.cpu().numpy()
+    own = np.zeros_like(hit_full, dtype=bool)
+    for k, t in enumerate(ids):
+        tx, ty = int(t) % tiles_x, int(t) // tiles_x
+        x0, y0 = tx * TW, ty * TH
+        w, h = min(TW, W - x0), min(TH, H - y0)
+        np.testing.assert_array_equal(o[k, :h, :w], full[y0:y0 + h, x0:x0 + w])
+        own[y0 // 8:(y0 + h + 7) // 8, x0 // 8:(x0 + w + 7) // 8] = True
+    assert np.array_equal(hit_tiles[own], hit_full[own])
+    assert not hit_tiles[~own].any()                # untouched texels of the zeroed output image
+    vr.setImgEss(False)
+
+
+def test_cpp_host_cli_image_order_ess(tmp_path):
+    """vrhip_render --img-ess --show-ess --frames 3: the C++ host carries the hit images (and
+    the accumulate image) from frame to frame like runRaycast does."""
+    import os
+    import subprocess
+    from volumerenderercl_amd import datraw
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "volumerenderercl_amd", "vrhip_render")
+    dat = os.path.join(root, "tests", "golden", "loader", "c1.dat")
+    out = str(tmp_path / "frame")
+    W, H = 104, 72
+    cmd = [exe, "--dat", dat, "--size", str(W), str(H), "--translate", "0.3", "-0.2", "3.5",
+           "--seed", str(SEED), "--img-ess", "--show-ess", "--frames", "3", "--out", out]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    got = np.fromfile(out + ".rgba.f32", dtype=np.float32).reshape(H, W, 4)
+    rd = datraw.DatRawReader()
+    rd.read_files(datraw.Properties(dat))
+    p = rd.properties()
+    vol = rd.data()[0].reshape(p.volume_res[2], p.volume_res[1], p.volume_res[0])
+    tff = frontend.tff_from_stops()
+    cam = vro.CameraParams()
+    cam.viewMat[:] = frontend.view_matrix(translation=(0.3, -0.2, 3.5))
+    cam.bbox_bl[:] = [-1, -1, -1, 0]
+    cam.bbox_tr[:] = [1, 1, 1, 0]
+    rp = vro.RenderingParams()
+    rp.backgroundColor[:] = [1, 1, 1, 0]
+    rp.modelScale[:] = vro.calc_scaling(p.volume_res[:3], p.slice_thickness) + [0]
+    rp.illumType, rp.useLinear, rp.seed = 1, 1, SEED
+    rp.imgEss, rp.showEss = 1, 1
+    rc = vro.RaycastParams()
+    rc.samplingRate = 1.5
+    _, brf, _ = vro.brick_layout(p.volume_res[:3])
+    rc.brickRes[:] = brf + [0]
+    hin, hout = vro.hit_image_init(W, H)
+    acc = None
+    for it in range(3):
+        rp.iteration = it
+        acc, _, _ = vro.render_tile(vol, vro.UCHAR, tff, cam, rp, rc, W=W, H=H, in_accum=acc,
+                                    hit_in=hin, hit_out=hout)
+        hin, hout = hout, hin
+    assert (hin == 0).sum() > 0
+    assert np.abs(got - acc).max() <= TOL

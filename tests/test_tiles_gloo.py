@@ -92,6 +92,77 @@ def test_gloo_tile_gather_matches_single_rank(world, W, H, T):
     np.testing.assert_array_equal(got, ref)
 
 
+def _worker_img_ess(rank, world, port, W, H, T, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    vol, tff, cam, rp, rc = _scene()
+    vol = np.zeros_like(vol)
+    vol[10:20, 12:22, 8:18] = 200          # small object: most groups end up skipped
+    rp.imgEss = 1
+    split = tiles.TileSplit(W, H, T, T, world, rank)
+    state = {"hin": None, "hout": None}
+    state["hin"], state["hout"] = vro.hit_image_init(W, H)
+
+    def render_tiles(ids, out):
+        for k, t in enumerate(ids):
+            x0, y0, w, h = split.tile_rect(t)
+            img, _, _ = vro.render_tile(vol, vro.UCHAR, tff, cam, rp, rc, W=W, H=H,
+                                        tile=(x0, y0, w, h), threads=1, hit_in=state["hin"],
+                                        hit_out=state["hout"])
+            out[k, :h, :w] = torch.from_numpy(img)
+        state["hin"], state["hout"] = state["hout"], state["hin"]   # the per-frame swap
+
+    def put(h):
+        state["hin"] = np.ascontiguousarray(h)
+
+    drv = tiles.TileDriver(None, split, torch.device("cpu"), render_tiles_fn=render_tiles, dist=dist,
+                           hit_io=(lambda: state["hin"], put))
+    frame = torch.zeros((H, W, 4)) if rank == 0 else None
+    frames, hits = [], []
+    for _ in range(4):
+        out = drv.render_frame(frame)
+        if rank == 0:
+            frames.append(out.numpy().copy())
+            hits.append(state["hin"].copy())
+    if rank == 0:
+        q.put((frames, hits))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_image_order_ess_matches_single_rank():
+    """imgEss across ranks: the hit image merged after every frame makes the 2-rank sequence
+    equal to the single-rank one, frame by frame and texel by texel."""
+    W, H, T = 112, 80, 16
+    vol, tff, cam, rp, rc = _scene()
+    vol = np.zeros_like(vol)
+    vol[10:20, 12:22, 8:18] = 200
+    rp.imgEss = 1
+    hin, hout = vro.hit_image_init(W, H)
+    want_frames, want_hits = [], []
+    for _ in range(4):
+        img, _, _ = vro.render_tile(vol, vro.UCHAR, tff, cam, rp, rc, W=W, H=H, hit_in=hin,
+                                    hit_out=hout)
+        hin, hout = hout, hin
+        want_frames.append(img)
+        want_hits.append(hin.copy())
+    assert (want_hits[-1] == 0).sum() > want_hits[-1].size // 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_img_ess, args=(r, 2, port, W, H, T, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    frames, hits = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for k in range(4):
+        assert np.array_equal(frames[k], want_frames[k]), "frame %d" % k
+        assert np.array_equal(hits[k], want_hits[k]), "hit image %d" % k
+
+
 def test_tile_split_is_a_partition():
     for world in (1, 2, 3, 4, 8):
         s0 = tiles.TileSplit(1024, 1000, 64, 48, world, 0)

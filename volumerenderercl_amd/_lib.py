@@ -85,6 +85,9 @@ SYMBOLS = {
     "vrhip_render_frame": (C.c_int, [_H, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int]),
     "vrhip_render_tiles": (C.c_int, [_H, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                      C.c_void_p, C.c_uint32, C.c_void_p]),
+    "vrhip_reset_image_ess": (C.c_int, [_H]),
+    "vrhip_get_image_ess": (C.c_int, [_H, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "vrhip_set_image_ess": (C.c_int, [_H, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "vrhip_last_kernel_seconds": (C.c_double, [_H]),
     "vrhip_last_phase_seconds": (C.c_int, [_H, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vrhip_set_stats_enabled": (C.c_int, [_H, C.c_int]),

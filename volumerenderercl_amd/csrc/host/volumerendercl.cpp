@@ -94,7 +94,9 @@ void VolumeRenderCL::updateSamplingRate(const double samplingRate)   // :397-401
 
 void VolumeRenderCL::updateOutputImg(const size_t, const size_t, cl_GLuint)
 {
-    // output / accumulate buffers are sized by the render call itself (:465-499)
+    // output / accumulate buffers are sized by the render call itself (:465-499); the hit images of
+    // image-order ESS start over with their initial contents (:482-488)
+    if (_r) check("updateOutputImg", vrhip_reset_image_ess(_r));
 }
 
 void VolumeRenderCL::pushParams()

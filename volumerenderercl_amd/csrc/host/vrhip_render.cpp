@@ -178,6 +178,7 @@ void write_ppm(const std::string &path, const std::vector<float> &rgba, size_t w
         "         [--pathtrace] [--extinction E]   (technique 1; --frames = samples per pixel)\n"
         "         [--downsample FACTOR]            (volumeDownsampling: writes <dat>_<N>.raw/.dat, no frame)\n"
         "         [--state FILE.json] [--tf-stops FILE.tff]   (files saved by the reference GUI)\n"
+        "         [--contours] [--aerial] [--ao] [--show-ess] [--img-ess]   (--img-ess: state carried over --frames)\n"
         "writes PREFIX.rgba.f32 (W*H*4 float32, row 0 = top), PREFIX.ppm and prints one JSON line\n";
     std::exit(2);
 }
@@ -195,7 +196,7 @@ int main(int argc, char **argv)
     double extinction = 100.0;
     int downsample = 0;
     std::string state_file, tf_stops;
-    bool contours = false, aerial = false, use_ao_flag = false;
+    bool contours = false, aerial = false, use_ao_flag = false, show_ess_flag = false, img_ess = false;
     std::array<float, 16> view{};
     unsigned illum = 1, seed = 0;
     int frames = 1, device = 0;
@@ -233,6 +234,8 @@ int main(int argc, char **argv)
         else if (a == "--contours") contours = true;
         else if (a == "--aerial") aerial = true;
         else if (a == "--ao") use_ao_flag = true;
+        else if (a == "--show-ess") show_ess_flag = true;
+        else if (a == "--img-ess") img_ess = true;
         else if (a == "--extinction") { need(i, 1); extinction = std::atof(argv[++i]); }
         else if (a == "--device") { need(i, 1); device = std::atoi(argv[++i]); }
         else if (a == "--out") { need(i, 1); out = argv[++i]; }
@@ -257,7 +260,7 @@ int main(int argc, char **argv)
             std::printf("{\"downsampled\": \"%s\"}\n", base.c_str());
             return 0;
         }
-        bool use_ao = use_ao_flag, show_box = false;
+        bool use_ao = use_ao_flag, show_box = show_ess_flag;
         if (!state_file.empty()) {   // what the GUI's widgets would forward after loadCamState
             const CamState st = read_cam_state(state_file);
             if (st.has_rot) for (int k = 0; k < 4; ++k) q[k] = st.q[k];
@@ -288,6 +291,7 @@ int main(int argc, char **argv)
         vr.setAerial(aerial);
         vr.setAmbientOcclusion(use_ao);
         if (show_box) vr.setShowESS(true);
+        if (img_ess) vr.setImgEss(true);   // state carried from frame to frame (--frames N)
         vr.setBackground(bg);
         vr.updateSamplingRate(rate);
         if (pathtrace) {

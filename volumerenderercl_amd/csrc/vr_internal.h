@@ -100,6 +100,13 @@ struct FrameView {
     uint16_t *cost;        // W*H, or nullptr
     uint32_t *order;       // permutation of the suspended rays, or nullptr (append order)
     uint32_t *sort_ws;     // kSortBins counts + kSortBins cursors, zeroed before each launch
+    // Image-order ESS (rendering_params.imgEss, volumeraycast.cl:659-670, :912-925): one texel per
+    // 8x8 work-group, (W/8 + 1) x (H/8 + 1) of them (volumerendercl.cpp:482-488).
+    const uint8_t *hit_in; // last frame's hit image
+    uint8_t *hit_status;   // this frame: what each group's work-items did (HIT_*, vr_raycast.hip)
+    uint8_t *hit_any;      // this frame: 1 = a work-item that reached the end changed its pixel;
+                           // zeroed before each launch
+    uint32_t hit_w, hit_h;
 };
 constexpr uint32_t kSortBins = 256;
 constexpr uint32_t kControlWords = 4 + 2 * kSortBins;   // queue head, cont count, cont head, pad, sort_ws
@@ -144,6 +151,7 @@ struct RaycastLaunch {
     uint32_t *touched;
     int num_cus;
     hipEvent_t mid_event;  // optional: recorded between the phase-1 and phase-2 launches
+    uint8_t *hit_out;      // imgEss: this frame's hit image (resolved after the march), or nullptr
 };
 
 hipError_t vr_launch_raycast(const RaycastLaunch &a, hipStream_t stream);

@@ -47,6 +47,7 @@ struct RayCtx {   // per-ray invariants, recomputable from the pixel
     int stepv0, stepv1, stepv2, exit0, exit1, exit2;
     float dT0, dT1, dT2;
     bool valid;       // hits the clip box with sampleDist > 0
+    bool miss;        // inside the image, misses the clip box (image-order ESS bookkeeping)
     float nominal;    // ceil(sampleDist / stepSize)
 };
 
@@ -56,6 +57,7 @@ struct RayDyn {   // marching state
     int c0, c1, c2;
     float tv0, tv1, tv2;
     uint32_t cidx, skw;   // linear index of the current brick cell and its bitmap word
+    float t_last;         // XS variants: ray parameter of the last sample taken, < 0 = none (showEss)
     float t_ert;          // ray parameter of the sample that triggered early ray termination
     bool ert;             // (ambient occlusion is applied there, :870-876)
 #ifdef VR_RAYLEN          // diagnostic build: samples taken by the ray, written to the alpha channel
@@ -88,6 +90,7 @@ VR_DEV void setup_ray(uint32_t gx, uint32_t gy, bool inside, const FrameView &fr
     c.tfar = ray.tfar;
     c.sampleDist = ray.tfar - ray.tnear;
     c.valid = inside && ray.hit && c.sampleDist > 0.f;
+    c.miss = inside && !ray.hit;
     c.tnear = ray.tnear;
     c.stepSize = 0.f; c.offset = 0.f; c.nominal = 0.f;
     c.stepv0 = c.stepv1 = c.stepv2 = 0;
@@ -106,6 +109,7 @@ VR_DEV void setup_ray(uint32_t gx, uint32_t gy, bool inside, const FrameView &fr
     d.tv0 = d.tv1 = d.tv2 = 0.f;
     d.cidx = 0; d.skw = 0;
     d.t_ert = 0.f; d.ert = false;
+    d.t_last = -1.f;
 #ifdef VR_RAYLEN
     d.nsmp = 0;
 #endif
@@ -574,12 +578,77 @@ VR_DEV void apply_ao(const Vol<VT, INSTR> &vol, const float4 *s_tff, int tffn, c
     d.r0 *= f; d.r1 *= f; d.r2 *= f;
 }
 
-// Running mean over iterations (:898-909, fp32 accumulate buffer) and the two writes.
+// ---- image-order ESS (volumeraycast.cl:659-670, :912-925) and showEss (:888-896)
+
+// what the work-items of an 8x8 work-group (= patch) did, for vr_hit_resolve_kernel
+enum { HIT_SKIPPED = 0, HIT_FIRST_ENDS = 1, HIT_FIRST_MISSES = 2 };
+
+// volumeraycast.cl:323-343 with bound = (0, 1)
+VR_DEV bool check_bounding_box(f3 pos, f3 voxLen)
+{
+    const bool xl = pos.x < voxLen.x, xh = pos.x > 1.f - voxLen.x;
+    const bool yl = pos.y < voxLen.y, yh = pos.y > 1.f - voxLen.y;
+    const bool zl = pos.z < 0.f + voxLen.z, zh = pos.z > 1.f - voxLen.z;
+    return (xl && zl) || (xl && yl) || (yl && zl) || (xh && zl) || (yh && zl) || (xh && zh) ||
+           (yh && zh) || (xl && zh) || (yl && zh) || (xh && yl) || (xh && yh) || (xl && yh);
+}
+
+// getLastHit (:513-526): true when nothing was hit in or around this work-group last frame.
+// Lanes 0..8 read one texel each; texels outside the hit image count as 0.
+VR_DEV bool group_unhit(const FrameView &fr, uint32_t tx8, uint32_t ty8, uint32_t lane)
+{
+    uint32_t v = 0;
+    if (lane < 9u) {
+        const int x = (int)tx8 + (int)(lane % 3u) - 1, y = (int)ty8 + (int)(lane / 3u) - 1;
+        if (x >= 0 && y >= 0 && x < (int)fr.hit_w && y < (int)fr.hit_h)
+            v = fr.hit_in[(size_t)y * fr.hit_w + (size_t)x];
+    }
+    return __ballot(v != 0u) == 0ull;
+}
+
+// Runs once per patch, after its rays are set up.  Records what the group's first work-item
+// will do (it has the last word on the hit texel, :918-924) and, for a group that is skipped,
+// writes the background (:664-668).  Returns true for a skipped group.
+VR_DEV bool image_ess_patch(const FrameView &fr, const vrhip_rendering_params &rp, const RayCtx &c,
+                            const WaveTile &wt, uint32_t lane, bool inside, uint32_t gx, uint32_t gy,
+                            size_t out_index)
+{
+    const bool unhit = group_unhit(fr, wt.tx8, wt.ty8, lane);
+    const unsigned long long valid = __ballot(c.valid);
+    if (lane == 0)
+        fr.hit_status[(size_t)wt.ty8 * fr.hit_w + wt.tx8] =
+            (uint8_t)(unhit ? HIT_SKIPPED : ((valid & 1ull) ? HIT_FIRST_ENDS : HIT_FIRST_MISSES));
+    if (unhit && inside) {
+        float4 o = make_float4(c.env0, c.env1, c.env2, c.env3);
+        if (rp.showEss) o = make_float4(1.f - o.x, 1.f - o.y, 1.f - o.z, 1.f - o.w);
+        fr.fb[(size_t)gy * fr.W + gx] = o;
+        if (fr.out) fr.out[out_index] = o;
+    }
+    return unhit;
+}
+
+// showEss (:888-896), running mean over iterations (:898-909, fp32 accumulate buffer), the two
+// writes, and the image-order ESS hit flag (:912-917).  EXTRAS = false: the default kernels,
+// which are never launched with showEss / imgEss set.
+template <bool EXTRAS>
 VR_DEV void write_pixel(const FrameView &fr, const vrhip_rendering_params &rp, const RayCtx &c,
-                        const RayDyn &d, uint32_t gx, uint32_t gy, size_t out_index)
+                        const RayDyn &d, f3 voxLen, uint32_t gx, uint32_t gy, size_t out_index)
 {
     const size_t fi = (size_t)gy * fr.W + gx;
-    float r0 = d.r0, r1 = d.r1, r2 = d.r2;
+    float r0 = d.r0, r1 = d.r1, r2 = d.r2, alpha = d.alpha;
+    if (EXTRAS && rp.showEss && c.valid) {
+        f3 pk = mk3(0.f, 0.f, 0.f);   // :722: the position of a ray that never sampled
+        if (d.t_last >= 0.f) {
+            const f3 pos = add3(c.cam, scale3(c.dir, d.t_last - c.offset));
+            pk = mk3(pos.x * 0.5f + 0.5f, pos.y * 0.5f + 0.5f, pos.z * 0.5f + 0.5f);
+        }
+        if (check_bounding_box(pk, voxLen)) {
+            r0 = fabsf(1.f - rp.backgroundColor[0]);
+            r1 = fabsf(1.f - rp.backgroundColor[1]);
+            r2 = fabsf(1.f - rp.backgroundColor[2]);
+            alpha = 1.f;
+        }
+    }
     if (rp.iteration != 0 && c.valid) {
         float4 prev = fr.fb[fi];
         float it1 = (float)(rp.iteration + 1u);
@@ -587,12 +656,14 @@ VR_DEV void write_pixel(const FrameView &fr, const vrhip_rendering_params &rp, c
         r1 = prev.y + (r1 - prev.y) / it1;
         r2 = prev.z + (r2 - prev.z) / it1;
     }
-    float4 o = make_float4(r0, r1, r2, c.valid ? d.alpha : c.env3);
+    float4 o = make_float4(r0, r1, r2, c.valid ? alpha : c.env3);
 #ifdef VR_RAYLEN
     o.w = c.valid ? (float)d.nsmp : 0.f;
 #endif
     fr.fb[fi] = o;
     if (fr.out) fr.out[out_index] = o;
+    if (EXTRAS && rp.imgEss && c.valid && (r0 != c.env0 || r1 != c.env1 || r2 != c.env2))
+        fr.hit_any[(size_t)(gy >> 3) * fr.hit_w + (gx >> 3)] = 1;
 }
 
 template <typename VT, int INSTR>
@@ -660,6 +731,8 @@ __global__ __launch_bounds__(kBlockDim) void vr_dda_prepass_kernel(
     RayCtx c;
     RayDyn d;
     setup_ray<true>(gx, gy, inside, fr, cam, rp, rc, resf, voxLen, grid, c, d);
+    const size_t out_index = (size_t)wt.out_base + (size_t)ly * fr.out_stride + lx;
+    if (rp.imgEss && image_ess_patch(fr, rp, c, wt, lane, inside, gx, gy, out_index)) return;
     fetch_skip_word(skip.bits, grid, d);
     unsigned long long n0 = 0, n1 = 0;
     while (__ballot(d.state == S_BRICK)) dda_step<0>(skip.bits, grid, c, d, n0, n1);
@@ -667,7 +740,7 @@ __global__ __launch_bounds__(kBlockDim) void vr_dda_prepass_kernel(
     const unsigned long long m = __ballot(live);
     if (inside && !live) {
         // what the march would leave for a ray without samples: background colour, alpha 0
-        write_pixel(fr, rp, c, d, gx, gy, (size_t)wt.out_base + (size_t)ly * fr.out_stride + lx);
+        write_pixel<true>(fr, rp, c, d, voxLen, gx, gy, out_index);
     }
     if (m && lane == 0) {
         const uint32_t slot = atomicAdd(fr.live_count, 1u);
@@ -712,7 +785,7 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_kernel(
     // empty-run skipping needs the linear sampler's footprint; the traffic-instrumented variant
     // reproduces the reference's fetch set instead
     const bool skip_empty = INSTR != 2 && cells.empty != nullptr && rp.useLinear != 0 &&
-                            !(XS && rp.illumType == 4);
+                            !(XS && (rp.illumType == 4 || rp.showEss));   // showEss tracks every sample
 
     // every wave pulls 8x8 patches until the queue is drained (exit condition reached by every
     // wave: the head only grows).  The next ticket is drawn while the current patch is marched,
@@ -743,6 +816,10 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_kernel(
         RayCtx c;
         RayDyn d;
         setup_ray<ESS>(gx, gy, inside, fr, cam, rp, rc, resf, voxLen, grid, c, d);
+        if (XS && rp.imgEss && !use_live &&   // (with a live list the pre-pass has done this)
+            image_ess_patch(fr, rp, c, wt, lane, inside, gx, gy,
+                            (size_t)wt.out_base + (size_t)ly * fr.out_stride + lx))
+            continue;
         // rays the pre-pass has finished (their pixel is written) stay out of the march
         const bool prepass_done = !((live_mask >> lane) & 1ull);
         if (prepass_done) d.state = S_DONE;
@@ -801,6 +878,7 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_kernel(
                 for (int k = 0; k < kBatch; ++k) {
                     if (vk[k] && d.state == S_SAMPLE) {
                         if (INSTR) { c_taken++; if (litk[k]) c_shaded++; }
+                        if (XS) d.t_last = tk[k];
                         composite(c, d, p0[k], p1[k], p2[k], opk[k], tk[k]);
                     }
                 }
@@ -838,7 +916,8 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_kernel(
         if (XS && rc.useAO && inside && !cont && !prepass_done && d.ert)
             apply_ao<VT, INSTR>(vol, s_tff, tffn, c, d, rp, gx, gy);
         if (inside && !cont && !prepass_done)
-            write_pixel(fr, rp, c, d, gx, gy, (size_t)wt.out_base + (size_t)ly * fr.out_stride + lx);
+            write_pixel<XS>(fr, rp, c, d, voxLen, gx, gy,
+                            (size_t)wt.out_base + (size_t)ly * fr.out_stride + lx);
         VR_STAMP(7);
     }
     VR_STAMP_FLUSH_AT(0);
@@ -1054,7 +1133,7 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
         if (XS && rc.useAO && have && slot == 0 && d.ert)
             apply_ao<VT, INSTR>(vol, s_tff, tffn, c, d, rp, gx, gy);
         if (have && slot == 0) {
-            write_pixel(fr, rp, c, d, gx, gy, (size_t)rec.out_index);
+            write_pixel<XS>(fr, rp, c, d, voxLen, gx, gy, (size_t)rec.out_index);
             if (fr.cost) fr.cost[(size_t)gy * fr.W + gx] = (uint16_t)(my_rounds < 65535u ? my_rounds : 65535u);
         }
         VR_STAMP(7);
@@ -1130,6 +1209,18 @@ __global__ __launch_bounds__(kBlockDim) void vr_cont_scatter_kernel(const ContRe
             if (i < n) order[s_off[key[j]] + s_base[key[j]] + rank[j]] = i;
         }
     }
+}
+
+// Image-order ESS, end of the frame (:918-924): the hit texel of every group of this launch.
+// A skipped group and a group whose first work-item missed the box leave 0; otherwise the first
+// work-item reports whether any work-item that reached the end changed its pixel.
+__global__ __launch_bounds__(kBlockDim) void vr_hit_resolve_kernel(FrameView fr, uint8_t *hit_out)
+{
+    const uint32_t i = blockIdx.x * kBlockDim + threadIdx.x;
+    if (i >= fr.n_wave_tiles) return;
+    const WaveTile wt = fr.queue[i];
+    const size_t g = (size_t)wt.ty8 * fr.hit_w + wt.tx8;
+    hit_out[g] = fr.hit_status[g] == HIT_FIRST_ENDS ? fr.hit_any[g] : (uint8_t)0;
 }
 
 template <typename K>
@@ -1217,7 +1308,8 @@ hipError_t launch_typed(const RaycastLaunch &a, hipStream_t stream)
     const bool lds = a.skip.in_lds != 0;
     // the rarely used shading modes 2-5 live in kernel variants of their own (XS), so that their
     // code and registers do not tax the default ones
-    const bool xs = a.render.illumType >= 2 || a.raycast.useAO != 0;
+    const bool xs = a.render.illumType >= 2 || a.raycast.useAO != 0 || a.render.showEss != 0 ||
+                    a.render.imgEss != 0;
     if (a.use_ess) {
         if (lds) {
             if (a.instr == 0) return xs ? launch_variant<VT, true, 0, true, true>(a, stream) : launch_variant<VT, true, 0, true, false>(a, stream);
@@ -1264,12 +1356,19 @@ extern "C" int vrhip_debug_stamps(unsigned long long out[32], int reset)
 
 hipError_t vr_launch_raycast(const RaycastLaunch &a, hipStream_t stream)
 {
+    hipError_t e;
     switch (a.format) {
-    case VRHIP_UCHAR: return launch_typed<uint8_t>(a, stream);
-    case VRHIP_USHORT: return launch_typed<uint16_t>(a, stream);
-    case VRHIP_FLOAT: return launch_typed<float>(a, stream);
+    case VRHIP_UCHAR: e = launch_typed<uint8_t>(a, stream); break;
+    case VRHIP_USHORT: e = launch_typed<uint16_t>(a, stream); break;
+    case VRHIP_FLOAT: e = launch_typed<float>(a, stream); break;
     default: return hipErrorInvalidValue;
     }
+    if (e == hipSuccess && a.render.imgEss && a.hit_out && a.frame.n_wave_tiles) {
+        hipLaunchKernelGGL(vr_hit_resolve_kernel, dim3((a.frame.n_wave_tiles + kBlockDim - 1) / kBlockDim),
+                           dim3(kBlockDim), 0, stream, a.frame, a.hit_out);
+        e = hipGetLastError();
+    }
+    return e;
 }
 
 hipError_t vr_launch_skipmap(const BrickView &bricks, int format, float inv_max, const TfView &tf,

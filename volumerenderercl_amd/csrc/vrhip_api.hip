@@ -94,6 +94,9 @@ struct vrhip_renderer {
     size_t cont_cap = 0;
     uint32_t round_budget = 10;       // phase-1 sample rounds per patch (0 = single phase)
     std::vector<uint32_t> queue_key;   // W, H, tile_w, tile_h, tile ids...
+    // image-order ESS: ping-pong hit images (volumerendercl.cpp:482-488, :524-530) + per-frame scratch
+    uint8_t *hit_in = nullptr, *hit_out = nullptr, *hit_status = nullptr, *hit_any = nullptr;
+    uint32_t hit_w = 0, hit_h = 0;
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr, evb0 = nullptr, evb1 = nullptr;
     bool timed = false, bricks_timed = false;
@@ -326,8 +329,37 @@ int check_renderable(vrhip_renderer *r, uint32_t width, uint32_t height)
                "Unknown illumination type.");
     VR_REQUIRE(r, r->render.technique == 0 || r->pathtrace.max_extinction > 0.f, VRHIP_ERR_INVALID,
                "max_extinction must be positive.");
-    VR_REQUIRE(r, !r->render.imgEss && !r->render.showEss, VRHIP_ERR_UNSUPPORTED,
-               "image-order ESS / showEss are outside the hot path (SURVEY 8f).");
+    // the path-tracing branch returns before the hit image is written (:686-706): its state
+    // would never change
+    VR_REQUIRE(r, !(r->render.imgEss && r->render.technique == 1), VRHIP_ERR_UNSUPPORTED,
+               "image-order ESS is not supported with the path tracer.");
+    return VRHIP_OK;
+}
+
+// The two hit images of image-order ESS, (W/8 + 1) x (H/8 + 1) texels, as updateOutputImg
+// creates them (volumerendercl.cpp:482-488): the input image is initialised from a vector of
+// 32-bit ones read as one byte per texel (bytes 1,0,0,0,1,...); the output image is left
+// uninitialised there, zero here.
+int ensure_hit_images(vrhip_renderer *r, uint32_t w, uint32_t h)
+{
+    const uint32_t hw = w / 8u + 1u, hh = h / 8u + 1u;
+    if (r->hit_in && r->hit_w == hw && r->hit_h == hh) return VRHIP_OK;
+    VR_HIP(r, hipStreamSynchronize(r->stream));
+    for (uint8_t **p : {&r->hit_in, &r->hit_out, &r->hit_status, &r->hit_any}) {
+        if (*p) VR_HIP(r, hipFree(*p));
+        *p = nullptr;
+    }
+    r->hit_w = r->hit_h = 0;
+    const size_t n = (size_t)hw * hh;
+    for (uint8_t **p : {&r->hit_in, &r->hit_out, &r->hit_status, &r->hit_any}) {
+        VR_HIP(r, hipMalloc((void **)p, n));
+        VR_HIP(r, hipMemset(*p, 0, n));
+    }
+    std::vector<uint8_t> init(n, 0);
+    for (size_t i = 0; i < n; i += 4) init[i] = 1;
+    VR_HIP(r, hipMemcpy(r->hit_in, init.data(), n, hipMemcpyHostToDevice));
+    r->hit_w = hw;
+    r->hit_h = hh;
     return VRHIP_OK;
 }
 
@@ -494,6 +526,16 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
     a->frame.order = r->sort_cont && r->cost ? r->order : nullptr;
     a->frame.sort_ws = r->queue_head + 4;
     a->frame.fb = r->fb;
+    if (r->render.imgEss && r->render.technique == 0) {
+        a->frame.hit_in = r->hit_in;
+        a->frame.hit_status = r->hit_status;
+        a->frame.hit_any = r->hit_any;
+        a->frame.hit_w = r->hit_w;
+        a->frame.hit_h = r->hit_h;
+    }
+    // showEss needs the position of every ray's last sample: it is kept in registers, not in the
+    // continuation records, so the march runs in a single phase
+    if (r->render.showEss) a->frame.round_budget = 0;
     a->cam = r->cam;
     a->render = r->render;
     a->raycast = r->raycast;
@@ -515,9 +557,14 @@ int launch_timed(vrhip_renderer *r, const RaycastLaunch &a)
     VR_HIP(r, hipEventRecord(r->ev0, r->stream));
     RaycastLaunch b = a;
     b.mid_event = r->evm;
+    if (b.frame.hit_in) {
+        VR_HIP(r, hipMemsetAsync(r->hit_any, 0, (size_t)r->hit_w * r->hit_h, r->stream));
+        b.hit_out = r->hit_out;
+    }
     VR_HIP(r, vr_launch_frame(b, r->stream));
     VR_HIP(r, hipEventRecord(r->ev1, r->stream));
     r->timed = true;
+    if (b.frame.hit_in) std::swap(r->hit_in, r->hit_out);   // runRaycast, volumerendercl.cpp:524-530
     return VRHIP_OK;
 }
 
@@ -535,6 +582,10 @@ int prepare_render(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t 
     }
     rc = ensure_fb(r, width, height);
     if (rc) return rc;
+    if (r->render.imgEss) {
+        rc = ensure_hit_images(r, width, height);
+        if (rc) return rc;
+    }
     if (r->render.technique == 0) {
         rc = ensure_skipmap(r);
         if (rc) return rc;
@@ -574,6 +625,9 @@ int count_touched_impl(vrhip_renderer *r, uint32_t width, uint32_t height, uint3
     a.frame.fb = scratch;
     if (e == hipSuccess) e = hipMemsetAsync(r->stats_dev, 0, sizeof(DevStats), r->stream);
     a.frame.round_budget = 0;   // the traffic pass runs single-phase (no speculative touches)
+    // image-order ESS: the pass skips what the next frame will skip, and leaves the hit images alone
+    if (a.frame.hit_in && e == hipSuccess)
+        e = hipMemsetAsync(r->hit_any, 0, (size_t)r->hit_w * r->hit_h, r->stream);
     if (e == hipSuccess) e = hipMemsetAsync(r->queue_head, 0, kControlWords * sizeof(uint32_t), r->stream);
     if (e == hipSuccess) e = vr_launch_frame(a, r->stream);
     std::vector<uint32_t> host(words);
@@ -652,6 +706,8 @@ void vrhip_destroy(vrhip_renderer *r)
     if (r->queue_head) (void)hipFree(r->queue_head);
     if (r->cont) (void)hipFree(r->cont);
     if (r->cost) (void)hipFree(r->cost);
+    for (uint8_t *p : {r->hit_in, r->hit_out, r->hit_status, r->hit_any})
+        if (p) (void)hipFree(p);
     if (r->live) (void)hipFree(r->live);
     if (r->order) (void)hipFree(r->order);
     if (r->skip_bits) (void)hipFree(r->skip_bits);
@@ -1044,6 +1100,45 @@ int vrhip_get_stats(const vrhip_renderer *r, vrhip_stats *out)
     out->bricks_visited = s.v[3];
     out->bricks_skipped = s.v[4];
     out->rays_hit = s.v[5];
+    return VRHIP_OK;
+}
+
+int vrhip_reset_image_ess(vrhip_renderer *r)
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    r->hit_w = r->hit_h = 0;   // re-created (and re-initialised) by the next imgEss frame
+    return VRHIP_OK;
+}
+
+int vrhip_get_image_ess(vrhip_renderer *r, uint32_t width, uint32_t height, uint8_t *hit_in,
+                        uint8_t *hit_out)
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    if (set_device(r)) return VRHIP_ERR_HIP;
+    VR_REQUIRE(r, width > 0 && height > 0 && width <= 16384 && height <= 16384, VRHIP_ERR_INVALID,
+               "Invalid output image size.");
+    int rc = ensure_hit_images(r, width, height);
+    if (rc) return rc;
+    const size_t n = (size_t)r->hit_w * r->hit_h;
+    VR_HIP(r, hipStreamSynchronize(r->stream));
+    if (hit_in) VR_HIP(r, hipMemcpy(hit_in, r->hit_in, n, hipMemcpyDeviceToHost));
+    if (hit_out) VR_HIP(r, hipMemcpy(hit_out, r->hit_out, n, hipMemcpyDeviceToHost));
+    return VRHIP_OK;
+}
+
+int vrhip_set_image_ess(vrhip_renderer *r, uint32_t width, uint32_t height, const uint8_t *hit_in,
+                        const uint8_t *hit_out)
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    if (set_device(r)) return VRHIP_ERR_HIP;
+    VR_REQUIRE(r, width > 0 && height > 0 && width <= 16384 && height <= 16384, VRHIP_ERR_INVALID,
+               "Invalid output image size.");
+    int rc = ensure_hit_images(r, width, height);
+    if (rc) return rc;
+    const size_t n = (size_t)r->hit_w * r->hit_h;
+    VR_HIP(r, hipStreamSynchronize(r->stream));
+    if (hit_in) VR_HIP(r, hipMemcpy(r->hit_in, hit_in, n, hipMemcpyHostToDevice));
+    if (hit_out) VR_HIP(r, hipMemcpy(r->hit_out, hit_out, n, hipMemcpyHostToDevice));
     return VRHIP_OK;
 }
 

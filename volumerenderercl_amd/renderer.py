@@ -126,7 +126,35 @@ class VolumeRenderCL:
         self._raycast.samplingRate = float(samplingRate)
 
     def updateOutputImg(self, width, height, texId=0):
+        """volumerendercl.cpp:465-499: output buffers are sized by the render call; the hit images
+        of image-order ESS are re-created with their initial contents (:482-488)."""
         self._out_size = (int(width), int(height))
+        if self._h:
+            self._check(self._lib.vrhip_reset_image_ess(self._h))
+
+    def getImageEss(self, width, height):
+        """(hit_in, hit_out) of image-order ESS for a width x height frame: uint8
+        [(height/8+1), (width/8+1)]; hit_in is what the next imgEss frame reads."""
+        shape = (int(height) // 8 + 1, int(width) // 8 + 1)
+        a, b = np.zeros(shape, np.uint8), np.zeros(shape, np.uint8)
+        self._check(self._lib.vrhip_get_image_ess(self._h, int(width), int(height),
+                                                  a.ctypes.data, b.ctypes.data))
+        return a, b
+
+    def setImageEss(self, width, height, hit_in=None, hit_out=None):
+        shape = (int(height) // 8 + 1, int(width) // 8 + 1)
+        ptrs = []
+        keep = []
+        for h in (hit_in, hit_out):
+            if h is None:
+                ptrs.append(None)
+                continue
+            h = np.ascontiguousarray(h, dtype=np.uint8)
+            if h.shape != shape:
+                raise ValueError("hit image must have shape %r" % (shape,))
+            keep.append(h)
+            ptrs.append(h.ctypes.data)
+        self._check(self._lib.vrhip_set_image_ess(self._h, int(width), int(height), *ptrs))
 
     def _begin_frame(self):
         # setMemObjectsRaycast: fresh seed per frame (volumerendercl.cpp:212)

@@ -6,6 +6,11 @@ ESS/ERT: neighbouring tiles -- similar cost -- go to different ranks), every ran
 whole volume, renders its tiles into a compact buffer and rank 0 gathers them over
 RCCL/xGMI (torch.distributed `gather`, backend "nccl" == RCCL; "gloo" in the CPU tests).
 One collective per frame, 16*W*H/N bytes per peer.
+
+Image-order ESS (rendering_params.imgEss) is the one piece of inter-frame state that crosses
+tile borders: a work-group looks at last frame's hit texels of its 3x3 neighbourhood.  Every
+rank updates the texels of its own tiles; with `image_ess=True` the driver merges them after
+each frame with one small all-reduce ((W/8+1)*(H/8+1) bytes) before the next frame reads them.
 """
 import numpy as np
 
@@ -46,12 +51,28 @@ class TileDriver:
         rendering of frame k + 1, so the frame rate is set by the slower of the two, not their sum.
     """
 
-    def __init__(self, vr, split, device, render_tiles_fn=None, dist=None):
+    def __init__(self, vr, split, device, render_tiles_fn=None, dist=None, image_ess=False,
+                 hit_io=None):
         import torch
         self.torch = torch
         self.vr, self.split, self.device = vr, split, device
         self.render_tiles_fn = render_tiles_fn
         s = split
+        # image-order ESS: (get, set) of the hit image the next frame reads
+        self.hit_io = hit_io
+        if image_ess and hit_io is None:
+            self.hit_io = (lambda: vr.getImageEss(s.W, s.H)[0],
+                           lambda h: vr.setImageEss(s.W, s.H, hit_in=h))
+        if self.hit_io is not None:
+            own = np.zeros((s.H // 8 + 1, s.W // 8 + 1), dtype=bool)
+            owned_by_any = np.zeros_like(own)
+            for t in range(s.n_tiles):
+                x0, y0, w, h = s.tile_rect(t)
+                rect = (slice(y0 // 8, (y0 + h + 7) // 8), slice(x0 // 8, (x0 + w + 7) // 8))
+                owned_by_any[rect] = True
+                if s.owner[t] == s.rank:
+                    own[rect] = True
+            self.hit_own, self.hit_owned_by_any = own, owned_by_any
         if dist is None and s.world > 1:
             import torch.distributed as dist
         self.dist = dist
@@ -92,6 +113,19 @@ class TileDriver:
         glist = [self.staging[b][r] for r in range(s.world)] if s.rank == 0 else None
         work = self.dist.gather(self.local[b], glist, dst=0, async_op=True)
         self.pending.append((b, work))
+        if self.hit_io is not None:
+            self.merge_hit_image()
+
+    def merge_hit_image(self):
+        """Image-order ESS: give every rank the hit texels the tile owners produced this frame.
+        Texels outside all tiles (the padded last row / column of groups) keep their value."""
+        get, put = self.hit_io
+        hit = np.ascontiguousarray(get(), dtype=np.uint8)
+        mine = self.torch.from_numpy(np.where(self.hit_own, hit, 0).astype(np.int32)).to(self.device)
+        self.dist.all_reduce(mine)      # sum: exactly one owner per texel
+        merged = np.where(self.hit_owned_by_any, mine.cpu().numpy().astype(np.uint8), hit)
+        put(merged)
+        return merged
 
     def collect(self, frame):
         """Finish the oldest frame in flight; returns the assembled frame on rank 0."""
