@@ -9,8 +9,7 @@
 //  * runRaycastNoGL fills width*height*4 fp32 RGBA, row 0 = top, as documented there (:173)
 //    (the reference reads an UNORM8 image into that vector);
 //  * frames accumulate in fp32 and `iteration` advances in both run paths (C9, C10);
-//  * createEnvironmentMap(file) / image-order ESS / showESS are outside the hot path and throw
-//    std::runtime_error;
+//  * RGBA / RG volumes are outside the hot path and throw std::runtime_error;
 //  * `buildScaledVol` (declared but never defined in the reference, :221) is dropped.
 #pragma once
 

@@ -160,6 +160,13 @@ int vrhip_render_frame(vrhip_renderer *r, uint32_t width, uint32_t height, float
 int vrhip_render_tiles(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t tile_w,
                        uint32_t tile_h, const uint32_t *tile_ids, uint32_t n_tiles,
                        float *out_tiles_dev);
+/* createEnvironmentMap (volumerendercl.cpp:1121-1150): float RGBA texels, row-major, width*height*4
+ * floats (the host layer decodes the Radiance .hdr file).  The kernel samples it in place of the
+ * background colour when it is wider than one texel (volumeraycast.cl:506-510, :655-656);
+ * rgba == NULL or width <= 1 removes it. */
+int vrhip_set_environment_map(vrhip_renderer *r, const float *rgba, uint32_t width,
+                              uint32_t height);
+
 /* ---- image-order ESS (rendering_params.imgEss; volumeraycast.cl:659-670, :912-925) --------
  * The renderer keeps the reference's two hit images, (width/8 + 1) x (height/8 + 1) texels of one
  * byte, creates them on the first imgEss frame of a size with updateOutputImg's initial contents

@@ -37,6 +37,13 @@ const void *vrdr_data(vrdr *h, uint64_t t);
 /* DatRawReader::getHistogram(t) */
 int vrdr_histogram(vrdr *h, uint64_t t, double out[256]);
 
+
+/* Radiance .hdr decoder behind createEnvironmentMap (reference: inc/hdr_loader.h:255-277,
+ * load_hdr_float4): *pixels receives width*height*4 floats (RGB + alpha 0), to be released with
+ * vrhost_free_pixels.  Returns 0, 1 (bad arguments) or 2 (file cannot be loaded). */
+int vrhost_load_hdr(const char *file, float **pixels, uint32_t *width, uint32_t *height);
+void vrhost_free_pixels(float *pixels);
+
 #ifdef __cplusplus
 }
 #endif

@@ -641,6 +641,70 @@ static void vro_sincosf(float x, float *s, float *c)
     }
 }
 
+/* atan2 and acos of get_environment_coords (:506-510) as fixed fp32 sequences (Cephes atanf /
+ * asinf kernels); vr_device_math.h executes the same ones. */
+static float atan_pos(float x) /* x >= 0, +inf allowed */
+{
+    float y0 = 0.0f, t = x;
+    if (x > 2.414213562373095f) { y0 = 1.5707963267948966f; t = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y0 = 0.7853981633974483f; t = (x - 1.0f) / (x + 1.0f); }
+    float z = t * t;
+    float p = 8.05374449538e-2f;
+    p = fmaf(p, z, -1.38776856032e-1f);
+    p = fmaf(p, z, 1.99777106478e-1f);
+    p = fmaf(p, z, -3.33329491539e-1f);
+    return y0 + fmaf(p * z, t, t);
+}
+
+float vro_atan2f(float y, float x)
+{
+    float ax = fabsf(x), ay = fabsf(y);
+    float a = (ax == 0.0f && ay == 0.0f) ? 0.0f : atan_pos(ay / ax);
+    if (x < 0.0f) a = 3.14159265358979323846f - a;
+    return y < 0.0f ? -a : a;
+}
+
+static float asin_kernel(float z, float s) /* asin(s) for z = s*s <= 0.25 */
+{
+    float p = 4.2163199048e-2f;
+    p = fmaf(p, z, 2.4181311049e-2f);
+    p = fmaf(p, z, 4.5470025998e-2f);
+    p = fmaf(p, z, 7.4953002686e-2f);
+    p = fmaf(p, z, 1.6666752422e-1f);
+    return fmaf(p * z, s, s);
+}
+
+float vro_acosf(float x) /* x in [-1, 1] */
+{
+    float a = fabsf(x);
+    if (a > 0.5f) {
+        float z = 0.5f * (1.0f - a);
+        float r = 2.0f * asin_kernel(z, sqrtf(z));
+        return x > 0.0f ? r : 3.14159265358979323846f - r;
+    }
+    return 1.5707963267948966f - asin_kernel(x * x, x);
+}
+
+/* read_imagef(environment, linearSmp, get_environment_coords(rayDir)) (:506-510, :655-656):
+ * float RGBA image, normalised coordinates, CLAMP_TO_EDGE, LINEAR (OpenCL 1.2 spec 8.2) */
+static void env_lookup(const vro_frame_extras *ex, f3 dir, float out[4])
+{
+    float s = vro_atan2f(dir.z, dir.x) * (float)(0.5 / 3.14159265358979323846) + 0.5f;
+    float t = vro_acosf(vmax(vmin(dir.y, 1.0f), -1.0f)) * (float)(1.0 / 3.14159265358979323846);
+    int w = (int)ex->env_w, h = (int)ex->env_h;
+    float ub = s * (float)w - 0.5f, vb = t * (float)h - 0.5f;
+    float fx = floorf(ub), fy = floorf(vb);
+    float a = ub - fx, b = vb - fy;
+    int x0 = iclamp((int)fx, 0, w - 1), x1 = iclamp((int)fx + 1, 0, w - 1);
+    int y0 = iclamp((int)fy, 0, h - 1), y1 = iclamp((int)fy + 1, 0, h - 1);
+    const float *p = ex->env_rgba;
+    for (int c = 0; c < 4; ++c) {
+        float t0 = lerpf(p[4 * ((size_t)y0 * w + x0) + c], p[4 * ((size_t)y0 * w + x1) + c], a);
+        float t1 = lerpf(p[4 * ((size_t)y1 * w + x0) + c], p[4 * ((size_t)y1 * w + x1) + c], a);
+        out[c] = lerpf(t0, t1, b);
+    }
+}
+
 /* volumeraycast.cl:181-206: returns the un-negated float4 (normal, |s2-s1|) */
 static void gradient_central_diff_tff(const vol_t *v, f3 pos, float out[4])
 {
@@ -880,10 +944,11 @@ static int render_pixel(const vol_t *v, const kargs_t *k, uint32_t gx, uint32_t 
     }
     rayDir = normalize3(mul3(rayDir, ms));
 
-    /* :653-656 (environment map out of scope: width 1) */
+    /* :653-656; the environment map replaces the background when it is wider than one texel */
     float bgf = rp->useGradient ? (0.7f + 0.5f * rayDir.y) : 1.f;
     float env[4];
     for (int i = 0; i < 4; ++i) env[i] = rp->backgroundColor[i] * bgf;
+    if (k->ex && k->ex->env_rgba && k->ex->env_w > 1) env_lookup(k->ex, rayDir, env);
 
     /* :658-670 image-order ESS: nothing was hit in or around this work-group last frame */
     if (rp->imgEss) {
@@ -1126,7 +1191,7 @@ int vro_render_tile_ex(const vro_scene *scene, const vro_camera_params *cam,
         if (x0 % 8u || y0 % 8u || (w % 8u && x0 + w != W) || (h % 8u && y0 + h != H)) return -1;
         if (render->technique == 1) return -2;
     }
-    if (ex && ex->env_rgba) return -2;
+    if (ex && ex->env_rgba && (ex->env_w == 0 || ex->env_h == 0)) return -1;
 
     vol_t v;
     memset(&v, 0, sizeof v);

@@ -103,6 +103,11 @@ int vro_intersect_bbox(const float orig[3], const float dir[3], const float lowe
  * IEEE fp32 operations, reproduced verbatim by the HIP kernel. */
 float vro_powr(float x, float y);
 
+/* atan2 / acos as used by get_environment_coords (volumeraycast.cl:506-510): fixed fp32
+ * sequences shared with the HIP kernel. */
+float vro_atan2f(float y, float x);
+float vro_acosf(float x);
+
 /* volumerendercl.cpp:39-54 */
 uint32_t vro_round_pow2(uint32_t n);
 /* volumerendercl.cpp:620-636: brick edge (voxels), raycast.brickRes, brick image dims */

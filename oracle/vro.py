@@ -63,7 +63,7 @@ def build(force=False):
             os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "vr_oracle.c"))):
         subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference/src") and not os.path.exists(
-            os.path.join(_HERE, "_ref", "libref_rng.so")):
+            os.path.join(_HERE, "_ref", "libref_hdr.so")):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
 
 
@@ -106,6 +106,10 @@ def lib():
         L.vro_synth_volume.restype = C.c_int
         L.vro_synth_volume.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.c_int, C.c_void_p]
         L.vro_num_threads.restype = C.c_int
+        L.vro_atan2f.restype = C.c_float
+        L.vro_atan2f.argtypes = [C.c_float, C.c_float]
+        L.vro_acosf.restype = C.c_float
+        L.vro_acosf.argtypes = [C.c_float]
         _lib = L
     return _lib
 

@@ -59,7 +59,7 @@ def tffs():
 
 
 def oracle_frame(vr, vol, fmt, tff, W, H, use_ess=True, tile=None, in_accum=None,
-                 want_touched=False, prefix=None):
+                 want_touched=False, prefix=None, env=None):
     cam, rp, rc, pt = to_oracle_params(*vr.params())
     return vro.render_tile(vol, fmt, tff, cam, rp, rc, pt, use_ess=use_ess, W=W, H=H, tile=tile,
-                           in_accum=in_accum, want_touched=want_touched, prefix=prefix)
+                           in_accum=in_accum, want_touched=want_touched, prefix=prefix, env=env)

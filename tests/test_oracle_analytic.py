@@ -217,3 +217,32 @@ def test_image_order_ess_sequence():
                                  hit_in=hin, hit_out=hout2)
     assert np.array_equal(part, full[16:64, 32:72])
     assert np.array_equal(hout2[2:8, 4:9], hout[2:8, 4:9]) and hout2.sum() == hout[2:8, 4:9].sum()
+
+
+def test_environment_map_replaces_background():
+    """:506-510, :655-656: a map wider than one texel is sampled (linear, clamp to edge) in the
+    ray's direction and used wherever the background colour was; a constant map equals a
+    constant background; a 1-texel-wide map is ignored."""
+    vol = vro.synth_volume("sphere", [24, 24, 24], vro.UCHAR)
+    cam, rp, rc = _params(illum=1, res=(24, 24, 24))
+    tff = frontend.tff_from_stops()
+    rp.backgroundColor[:] = [0.2, 0.4, 0.6, 0.5]
+    plain, _, _ = vro.render_tile(vol, vro.UCHAR, tff, cam, rp, rc, W=56, H=40)
+    const = np.tile(np.float32([0.2, 0.4, 0.6, 0.5]), (4, 8, 1))
+    rp.backgroundColor[:] = [1, 1, 1, 1]
+    img, _, _ = vro.render_tile(vol, vro.UCHAR, tff, cam, rp, rc, W=56, H=40, env=const)
+    assert np.array_equal(img, plain)
+    one, _, _ = vro.render_tile(vol, vro.UCHAR, tff, cam, rp, rc, W=56, H=40, env=const[:, :1])
+    white, _, _ = vro.render_tile(vol, vro.UCHAR, tff, cam, rp, rc, W=56, H=40)
+    assert np.array_equal(one, white)
+    # a map that encodes its own texture coordinates: missed rays return (s, t) of their direction
+    h, w = 64, 128
+    env = np.zeros((h, w, 4), np.float32)
+    env[..., 0] = (np.arange(w, dtype=np.float32) + 0.5) / w
+    env[..., 1] = ((np.arange(h, dtype=np.float32) + 0.5) / h)[:, None]
+    vol0 = np.zeros_like(vol)
+    img, _, _ = vro.render_tile(vol0, vro.UCHAR, tff, cam, rp, rc, W=56, H=40, env=env)
+    # default camera looks down -z: atan2(z, x) in (-pi, 0) -> s in (0, 0.5); centre ray s = 0.25
+    assert abs(img[20, 28, 0] - 0.25) < 0.06 and abs(img[20, 28, 1] - 0.5) < 0.06
+    assert np.all(np.diff(img[20, :, 0]) > 0)       # s grows with x, t with y (image row 0 = top)
+    assert np.all(np.diff(img[:, 28, 1]) > 0)

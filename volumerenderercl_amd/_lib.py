@@ -85,6 +85,7 @@ SYMBOLS = {
     "vrhip_render_frame": (C.c_int, [_H, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int]),
     "vrhip_render_tiles": (C.c_int, [_H, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                      C.c_void_p, C.c_uint32, C.c_void_p]),
+    "vrhip_set_environment_map": (C.c_int, [_H, C.c_void_p, C.c_uint32, C.c_uint32]),
     "vrhip_reset_image_ess": (C.c_int, [_H]),
     "vrhip_get_image_ess": (C.c_int, [_H, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "vrhip_set_image_ess": (C.c_int, [_H, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),

@@ -1,6 +1,7 @@
 // volumerendercl.cpp -- VolumeRenderCL on libvrhip (see include/volumerendercl.h).  Each
 // method cites the reference behaviour it reproduces
 // (/root/reference/src/core/volumerendercl.cpp).
+#include "hdrloader.h"
 #include "volumerendercl.h"
 
 #include <cstring>
@@ -367,8 +368,17 @@ const std::string VolumeRenderCL::volumeDownsampling(const size_t t, const int f
 
 void VolumeRenderCL::createEnvironmentMap(const std::string &file_name)
 {
-    if (file_name.empty()) return;   // 1x1 white map == no environment map (:1130-1134)
-    throw std::runtime_error("ERROR: environment maps are outside the hot path (SURVEY 8f3)");
+    // an empty name installs the 1x1 white map, which the kernel never samples (:1130-1134, :655)
+    if (file_name.empty()) {
+        check("createEnvironmentMap", vrhip_set_environment_map(_r, nullptr, 0, 0));
+        return;
+    }
+    vrhost::HdrImage img;
+    if (!vrhost::load_hdr_float4(file_name, img))
+        throw std::runtime_error("Error loading environment map file.");   // :1138
+    check("createEnvironmentMap",
+          vrhip_set_environment_map(_r, img.rgba.data(), img.width, img.height));
+    std::cout << "Loaded environment map " << file_name << std::endl;
 }
 
 void VolumeRenderCL::setSeed(unsigned int seed) { _seedPinned = true; _pinnedSeed = seed; }

@@ -179,6 +179,7 @@ void write_ppm(const std::string &path, const std::vector<float> &rgba, size_t w
         "         [--downsample FACTOR]            (volumeDownsampling: writes <dat>_<N>.raw/.dat, no frame)\n"
         "         [--state FILE.json] [--tf-stops FILE.tff]   (files saved by the reference GUI)\n"
         "         [--contours] [--aerial] [--ao] [--show-ess] [--img-ess]   (--img-ess: state carried over --frames)\n"
+        "         [--env FILE.hdr]                 (createEnvironmentMap: Radiance RGBE environment map)\n"
         "writes PREFIX.rgba.f32 (W*H*4 float32, row 0 = top), PREFIX.ppm and prints one JSON line\n";
     std::exit(2);
 }
@@ -187,7 +188,7 @@ void write_ppm(const std::string &path, const std::vector<float> &rgba, size_t w
 
 int main(int argc, char **argv)
 {
-    std::string dat, synth_kind, synth_fmt = "UCHAR", tf = "default", out;
+    std::string dat, synth_kind, synth_fmt = "UCHAR", tf = "default", out, env_file;
     unsigned synth_n = 0;
     size_t W = 1024, H = 1024;
     double q[4] = {1, 0, 0, 0}, tr[3] = {0, 0, 2};
@@ -236,6 +237,7 @@ int main(int argc, char **argv)
         else if (a == "--ao") use_ao_flag = true;
         else if (a == "--show-ess") show_ess_flag = true;
         else if (a == "--img-ess") img_ess = true;
+        else if (a == "--env") { need(i, 1); env_file = argv[++i]; }
         else if (a == "--extinction") { need(i, 1); extinction = std::atof(argv[++i]); }
         else if (a == "--device") { need(i, 1); device = std::atoi(argv[++i]); }
         else if (a == "--out") { need(i, 1); out = argv[++i]; }
@@ -291,6 +293,7 @@ int main(int argc, char **argv)
         vr.setAerial(aerial);
         vr.setAmbientOcclusion(use_ao);
         if (show_box) vr.setShowESS(true);
+        if (!env_file.empty()) vr.createEnvironmentMap(env_file);
         if (img_ess) vr.setImgEss(true);   // state carried from frame to frame (--frames N)
         vr.setBackground(bg);
         vr.updateSamplingRate(rate);

@@ -1,5 +1,8 @@
 // vrhost_capi.cpp -- plain-C access to the host-side DatRawReader (libvrhost.so), used by the
 // Python package (volumerenderercl_amd/datraw.py) and its tests.  Declared in include/vrhost.h.
+#include "hdrloader.h"
+#include <cstdlib>
+#include <cstring>
 #include "vrhost.h"
 
 #include <cstring>
@@ -65,6 +68,22 @@ const void *vrdr_data(vrdr *h, uint64_t t)
     if (!h || !h->reader.has_data() || t >= h->reader.data().size()) return nullptr;
     return h->reader.data()[t].data();
 }
+
+int vrhost_load_hdr(const char *file, float **pixels, uint32_t *width, uint32_t *height)
+{
+    if (!file || !pixels || !width || !height) return 1;
+    vrhost::HdrImage img;
+    if (!vrhost::load_hdr_float4(file, img)) return 2;
+    float *p = static_cast<float *>(std::malloc(img.rgba.size() * sizeof(float)));
+    if (!p) return 2;
+    std::memcpy(p, img.rgba.data(), img.rgba.size() * sizeof(float));
+    *pixels = p;
+    *width = img.width;
+    *height = img.height;
+    return 0;
+}
+
+void vrhost_free_pixels(float *pixels) { std::free(pixels); }
 
 int vrdr_histogram(vrdr *h, uint64_t t, double out[256])
 {

@@ -124,6 +124,50 @@ VR_DEV float vr_powr(float x, float y)
     return r * __uint_as_float((uint32_t)(ni + 127) << 23);
 }
 
+// atan2 / acos of get_environment_coords (volumeraycast.cl:506-510): the oracle's fixed fp32
+// sequences (vro_atan2f / vro_acosf, Cephes atanf / asinf kernels)
+VR_DEV float vr_atan_pos(float x)   // x >= 0, +inf allowed
+{
+    float y0 = 0.0f, t = x;
+    if (x > 2.414213562373095f) { y0 = 1.5707963267948966f; t = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y0 = 0.7853981633974483f; t = (x - 1.0f) / (x + 1.0f); }
+    float z = t * t;
+    float p = 8.05374449538e-2f;
+    p = __builtin_fmaf(p, z, -1.38776856032e-1f);
+    p = __builtin_fmaf(p, z, 1.99777106478e-1f);
+    p = __builtin_fmaf(p, z, -3.33329491539e-1f);
+    return y0 + __builtin_fmaf(p * z, t, t);
+}
+
+VR_DEV float vr_atan2f(float y, float x)
+{
+    float ax = fabsf(x), ay = fabsf(y);
+    float a = (ax == 0.0f && ay == 0.0f) ? 0.0f : vr_atan_pos(ay / ax);
+    if (x < 0.0f) a = 3.14159265358979323846f - a;
+    return y < 0.0f ? -a : a;
+}
+
+VR_DEV float vr_asin_kernel(float z, float s)   // asin(s) for z = s*s <= 0.25
+{
+    float p = 4.2163199048e-2f;
+    p = __builtin_fmaf(p, z, 2.4181311049e-2f);
+    p = __builtin_fmaf(p, z, 4.5470025998e-2f);
+    p = __builtin_fmaf(p, z, 7.4953002686e-2f);
+    p = __builtin_fmaf(p, z, 1.6666752422e-1f);
+    return __builtin_fmaf(p * z, s, s);
+}
+
+VR_DEV float vr_acosf(float x)   // x in [-1, 1]
+{
+    float a = fabsf(x);
+    if (a > 0.5f) {
+        float z = 0.5f * (1.0f - a);
+        float r = 2.0f * vr_asin_kernel(z, sqrtf(z));
+        return x > 0.0f ? r : 3.14159265358979323846f - r;
+    }
+    return 1.5707963267948966f - vr_asin_kernel(x * x, x);
+}
+
 // sin/cos of x in [0, 2*pi] (path tracer phase function, volumeraycast.cl:456-459)
 VR_DEV void vr_sincosf(float x, float *s, float *c)
 {

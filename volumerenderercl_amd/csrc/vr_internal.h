@@ -107,6 +107,10 @@ struct FrameView {
     uint8_t *hit_any;      // this frame: 1 = a work-item that reached the end changed its pixel;
                            // zeroed before each launch
     uint32_t hit_w, hit_h;
+    // Environment map (createEnvironmentMap, volumerendercl.cpp:1121-1150): float RGBA texels,
+    // nullptr when none is set (the reference's 1x1 white map is never sampled, :655)
+    const float4 *env;
+    uint32_t env_w, env_h;
 };
 constexpr uint32_t kSortBins = 256;
 constexpr uint32_t kControlWords = 4 + 2 * kSortBins;   // queue head, cont count, cont head, pad, sort_ws

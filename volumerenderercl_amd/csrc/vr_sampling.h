@@ -390,6 +390,24 @@ VR_DEV Ray make_ray(uint32_t gx, uint32_t gy, const FrameView &fr, const vrhip_c
 
     float bgf = rp.useGradient ? (0.7f + 0.5f * rayDir.y) : 1.f;
     for (int i = 0; i < 4; ++i) r.env[i] = rp.backgroundColor[i] * bgf;
+    if (fr.env) {
+        // environment map (:506-510, :655-656): float RGBA image, linearSmp = normalised
+        // coordinates, CLAMP_TO_EDGE, LINEAR; replaces the background colour, alpha included
+        const float es = vr_atan2f(rayDir.z, rayDir.x) * (float)(0.5 / 3.14159265358979323846) + 0.5f;
+        const float et = vr_acosf(vmax(vmin(rayDir.y, 1.0f), -1.0f)) * (float)(1.0 / 3.14159265358979323846);
+        const int ew = (int)fr.env_w, eh = (int)fr.env_h;
+        const float ub = es * (float)ew - 0.5f, vb = et * (float)eh - 0.5f;
+        const float fx = floorf(ub), fy = floorf(vb);
+        const float ea = ub - fx, eb = vb - fy;
+        const int x0 = iclamp((int)fx, 0, ew - 1), x1 = iclamp((int)fx + 1, 0, ew - 1);
+        const int y0 = iclamp((int)fy, 0, eh - 1), y1 = iclamp((int)fy + 1, 0, eh - 1);
+        const float4 t00 = fr.env[(size_t)y0 * ew + x0], t10 = fr.env[(size_t)y0 * ew + x1];
+        const float4 t01 = fr.env[(size_t)y1 * ew + x0], t11 = fr.env[(size_t)y1 * ew + x1];
+        r.env[0] = lerpf(lerpf(t00.x, t10.x, ea), lerpf(t01.x, t11.x, ea), eb);
+        r.env[1] = lerpf(lerpf(t00.y, t10.y, ea), lerpf(t01.y, t11.y, ea), eb);
+        r.env[2] = lerpf(lerpf(t00.z, t10.z, ea), lerpf(t01.z, t11.z, ea), eb);
+        r.env[3] = lerpf(lerpf(t00.w, t10.w, ea), lerpf(t01.w, t11.w, ea), eb);
+    }
 
     // intersectBBox, volumeraycast.cl:122-142
     float o[3] = {camPos.x, camPos.y, camPos.z}, d[3] = {rayDir.x, rayDir.y, rayDir.z};

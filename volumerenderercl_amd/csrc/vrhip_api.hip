@@ -97,6 +97,8 @@ struct vrhip_renderer {
     // image-order ESS: ping-pong hit images (volumerendercl.cpp:482-488, :524-530) + per-frame scratch
     uint8_t *hit_in = nullptr, *hit_out = nullptr, *hit_status = nullptr, *hit_any = nullptr;
     uint32_t hit_w = 0, hit_h = 0;
+    float4 *env = nullptr;            // environment map (float RGBA), or nullptr
+    uint32_t env_w = 0, env_h = 0;
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr, evb0 = nullptr, evb1 = nullptr;
     bool timed = false, bricks_timed = false;
@@ -533,6 +535,9 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
         a->frame.hit_w = r->hit_w;
         a->frame.hit_h = r->hit_h;
     }
+    a->frame.env = r->env;
+    a->frame.env_w = r->env_w;
+    a->frame.env_h = r->env_h;
     // showEss needs the position of every ray's last sample: it is kept in registers, not in the
     // continuation records, so the march runs in a single phase
     if (r->render.showEss) a->frame.round_budget = 0;
@@ -708,6 +713,7 @@ void vrhip_destroy(vrhip_renderer *r)
     if (r->cost) (void)hipFree(r->cost);
     for (uint8_t *p : {r->hit_in, r->hit_out, r->hit_status, r->hit_any})
         if (p) (void)hipFree(p);
+    if (r->env) (void)hipFree(r->env);
     if (r->live) (void)hipFree(r->live);
     if (r->order) (void)hipFree(r->order);
     if (r->skip_bits) (void)hipFree(r->skip_bits);
@@ -1100,6 +1106,28 @@ int vrhip_get_stats(const vrhip_renderer *r, vrhip_stats *out)
     out->bricks_visited = s.v[3];
     out->bricks_skipped = s.v[4];
     out->rays_hit = s.v[5];
+    return VRHIP_OK;
+}
+
+int vrhip_set_environment_map(vrhip_renderer *r, const float *rgba, uint32_t width,
+                              uint32_t height)
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    if (set_device(r)) return VRHIP_ERR_HIP;
+    VR_HIP(r, hipStreamSynchronize(r->stream));
+    if (r->env) VR_HIP(r, hipFree(r->env));
+    r->env = nullptr;
+    r->env_w = r->env_h = 0;
+    // the kernel only samples maps wider than one texel (:655); createEnvironmentMap("")
+    // installs a 1x1 white one, i.e. none
+    if (!rgba || width <= 1 || height == 0) return VRHIP_OK;
+    VR_REQUIRE(r, width <= 16384 && height <= 16384, VRHIP_ERR_INVALID,
+               "Environment map too large.");
+    const size_t bytes = (size_t)width * height * sizeof(float4);
+    VR_HIP(r, hipMalloc((void **)&r->env, bytes));
+    VR_HIP(r, hipMemcpy(r->env, rgba, bytes, hipMemcpyHostToDevice));
+    r->env_w = width;
+    r->env_h = height;
     return VRHIP_OK;
 }
 

@@ -39,6 +39,10 @@ def _load():
         lib.vrdr_data.restype = C.c_void_p
         lib.vrdr_data.argtypes = [C.c_void_p, C.c_uint64]
         lib.vrdr_histogram.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_double)]
+        lib.vrhost_load_hdr.restype = C.c_int
+        lib.vrhost_load_hdr.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_float)),
+                                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        lib.vrhost_free_pixels.argtypes = [C.POINTER(C.c_float)]
         _lib = lib
     return _lib
 
@@ -111,3 +115,18 @@ class DatRawReader:
 
     def histograms(self):
         return self._hist
+
+
+def load_hdr(file_name):
+    """Radiance .hdr -> float32 [height, width, 4] (RGB, alpha 0), through the host layer's decoder
+    (reference: inc/hdr_loader.h load_hdr_float4).  Raises RuntimeError like createEnvironmentMap
+    (volumerendercl.cpp:1137-1138)."""
+    lib = _load()
+    p = C.POINTER(C.c_float)()
+    w, h = C.c_uint32(0), C.c_uint32(0)
+    if lib.vrhost_load_hdr(os.fsencode(file_name), C.byref(p), C.byref(w), C.byref(h)) != 0:
+        raise RuntimeError("Error loading environment map file.")
+    try:
+        return np.ctypeslib.as_array(p, shape=(h.value, w.value, 4)).copy()
+    finally:
+        lib.vrhost_free_pixels(p)

@@ -278,6 +278,26 @@ class VolumeRenderCL:
             return [0, 0, 0, 1]
         return list(self._res)
 
+    def createEnvironmentMap(self, file_name):
+        """volumerendercl.cpp:1121-1150: Radiance .hdr file -> float RGBA environment map; an
+        empty name installs the reference's 1x1 white map, which the kernel never samples."""
+        if not file_name:
+            self.setEnvironmentMap(None)
+            return
+        from . import datraw
+        self.setEnvironmentMap(datraw.load_hdr(file_name))
+
+    def setEnvironmentMap(self, rgba):
+        """float32 [height, width, 4] texels, or None to remove the map."""
+        if rgba is None:
+            self._check(self._lib.vrhip_set_environment_map(self._h, None, 0, 0))
+            return
+        rgba = np.ascontiguousarray(rgba, dtype=np.float32)
+        if rgba.ndim != 3 or rgba.shape[2] != 4:
+            raise ValueError("environment map must be [height, width, 4]")
+        self._check(self._lib.vrhip_set_environment_map(self._h, rgba.ctypes.data,
+                                                        rgba.shape[1], rgba.shape[0]))
+
     def getHistogram(self, timestep=0):
         if not self._vol_loaded:
             raise ValueError("Invalid timestep for histogram data.")
