@@ -9,7 +9,8 @@
 //  * runRaycastNoGL fills width*height*4 fp32 RGBA, row 0 = top, as documented there (:173)
 //    (the reference reads an UNORM8 image into that vector);
 //  * frames accumulate in fp32 and `iteration` advances in both run paths (C9, C10);
-//  * RGBA / RG volumes are outside the hot path and throw std::runtime_error;
+//  * ARGB / BGRA volumes (uploaded by the reference, never handled by its kernel) throw
+//    std::runtime_error;
 //  * `buildScaledVol` (declared but never defined in the reference, :221) is dropped.
 #pragma once
 
@@ -119,5 +120,6 @@ private:
     pathtrace_params _pathtrace_params;
     DatRawReader _dr;
     bool _synthetic = false;
+    int _channels = 1;          // 1 = R, 2 = RG, 4 = RGBA (volDataToCLmem, :697-705)
     std::array<unsigned int, 4> _synthRes = {{0, 0, 0, 1}};
 };

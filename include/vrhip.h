@@ -104,6 +104,13 @@ int vrhip_set_stream(vrhip_renderer *r, void *hip_stream, int use_own);
 /* Dense x-fastest scalar field (CL_R image) of `format`, host memory. */
 int vrhip_upload_volume(vrhip_renderer *r, const void *host_voxels, const uint32_t res[3],
                         int format, uint32_t timestep);
+/* CL_RG / CL_RGBA volumes (volumerendercl.cpp:697-705; kernel volumeraycast.cl:838-855):
+ * `channels` interleaved values of `format` per voxel, 2 = RG (colour (r,0,0), opacity TF(|g|)),
+ * 4 = RGBA (the voxel is the sample's colour and opacity), 1 = vrhip_upload_volume.  Everything
+ * that reads `.x` in the reference -- bricks, gradients, the path tracer, down-sampling -- sees
+ * channel 0.  Other counts: VRHIP_ERR_INVALID ("Unknown or invalid volume color format."). */
+int vrhip_upload_volume_channels(vrhip_renderer *r, const void *host_voxels, const uint32_t res[3],
+                                 int format, int channels, uint32_t timestep);
 /* Same, source already in device memory (HBM). */
 int vrhip_upload_volume_device(vrhip_renderer *r, const void *dev_voxels, const uint32_t res[3],
                                int format, uint32_t timestep);

@@ -219,11 +219,12 @@ typedef struct {
     int bw, bh, bd;         /* brick image dims */
     uint8_t *touched;       /* micro-brick bitmap or NULL */
     int mbx, mby;
+    int nch;                /* channels per voxel: 1 (CL_R), 2 (CL_RG), 4 (CL_RGBA) */
 } vol_t;
 
-static inline float vox_raw(const vol_t *v, int x, int y, int z)
+static inline float vox_raw_c(const vol_t *v, int x, int y, int z, int ch)
 {
-    size_t i = (size_t)z * v->slice + (size_t)y * v->row + (size_t)x;
+    size_t i = ((size_t)z * v->slice + (size_t)y * v->row + (size_t)x) * (size_t)v->nch + (size_t)ch;
     if (v->touched) {
         size_t b = ((size_t)(z >> 2) * (size_t)v->mby + (size_t)(y >> 2)) * (size_t)v->mbx +
                    (size_t)(x >> 2);
@@ -238,9 +239,12 @@ static inline float vox_raw(const vol_t *v, int x, int y, int z)
     }
 }
 
+/* the .x component every single-channel reader of the kernel looks at */
+static inline float vox_raw(const vol_t *v, int x, int y, int z) { return vox_raw_c(v, x, y, z, 0); }
+
 /* linearSmp (volumeraycast.cl:30-31) on the CL_R volume: OpenCL 1.2 spec 8.2,
  * normalised coords, CLAMP_TO_EDGE, LINEAR. */
-static float vol_linear(const vol_t *v, float px, float py, float pz)
+static float vol_linear_c(const vol_t *v, float px, float py, float pz, int ch)
 {
     float u = px * v->fw, vv = py * v->fh, ww = pz * v->fd;
     float ub = u - 0.5f, vb = vv - 0.5f, wb = ww - 0.5f;
@@ -250,23 +254,33 @@ static float vol_linear(const vol_t *v, float px, float py, float pz)
     int x0 = iclamp(ix, 0, v->w - 1), x1 = iclamp(ix + 1, 0, v->w - 1);
     int y0 = iclamp(iy, 0, v->h - 1), y1 = iclamp(iy + 1, 0, v->h - 1);
     int z0 = iclamp(iz, 0, v->d - 1), z1 = iclamp(iz + 1, 0, v->d - 1);
-    float c00 = lerpf(vox_raw(v, x0, y0, z0), vox_raw(v, x1, y0, z0), a);
-    float c10 = lerpf(vox_raw(v, x0, y1, z0), vox_raw(v, x1, y1, z0), a);
-    float c01 = lerpf(vox_raw(v, x0, y0, z1), vox_raw(v, x1, y0, z1), a);
-    float c11 = lerpf(vox_raw(v, x0, y1, z1), vox_raw(v, x1, y1, z1), a);
+    float c00 = lerpf(vox_raw_c(v, x0, y0, z0, ch), vox_raw_c(v, x1, y0, z0, ch), a);
+    float c10 = lerpf(vox_raw_c(v, x0, y1, z0, ch), vox_raw_c(v, x1, y1, z0, ch), a);
+    float c01 = lerpf(vox_raw_c(v, x0, y0, z1, ch), vox_raw_c(v, x1, y0, z1, ch), a);
+    float c11 = lerpf(vox_raw_c(v, x0, y1, z1, ch), vox_raw_c(v, x1, y1, z1, ch), a);
     float c0 = lerpf(c00, c10, b);
     float c1 = lerpf(c01, c11, b);
     return lerpf(c0, c1, c) * v->inv_max;
 }
 
+static float vol_linear(const vol_t *v, float px, float py, float pz)
+{
+    return vol_linear_c(v, px, py, pz, 0);
+}
+
 /* nearestSmp (volumeraycast.cl:32-33): normalised, CLAMP (border 0 for CL_R), NEAREST */
-static float vol_nearest(const vol_t *v, float px, float py, float pz)
+static float vol_nearest_c(const vol_t *v, float px, float py, float pz, int ch)
 {
     float fx = floorf(px * v->fw), fy = floorf(py * v->fh), fz = floorf(pz * v->fd);
     if (!(fx >= 0.0f && fx <= (float)(v->w - 1) && fy >= 0.0f && fy <= (float)(v->h - 1) &&
           fz >= 0.0f && fz <= (float)(v->d - 1)))
         return 0.0f;
-    return vox_raw(v, (int)fx, (int)fy, (int)fz) * v->inv_max;
+    return vox_raw_c(v, (int)fx, (int)fy, (int)fz, ch) * v->inv_max;
+}
+
+static float vol_nearest(const vol_t *v, float px, float py, float pz)
+{
+    return vol_nearest_c(v, px, py, pz, 0);
 }
 
 /* TF read: read_imagef(tffData, linearSmp, x) on the RGBA8 1-D image
@@ -1072,6 +1086,18 @@ static int render_pixel(const vol_t *v, const kargs_t *k, uint32_t gx, uint32_t 
             f3 grad = mk3(0.f, 0.f, 0.f);
             if (rp->illumType == 4) { /* :796-799 gradient magnitude through the TF */
                 tff_linear(v->s, gradient_central_diff_len(v, pos), tfc);
+            } else if (v->nch == 4) { /* :840-845 CL_RGBA: the voxel is the colour, no shading */
+                for (int c = 0; c < 4; ++c)
+                    tfc[c] = rp->useLinear ? vol_linear_c(v, pos.x, pos.y, pos.z, c)
+                                           : vol_nearest_c(v, pos.x, pos.y, pos.z, c);
+            } else if (v->nch == 2) { /* :846-855 CL_RG: (r, g, 0, 1) -> colour (r, 0, 0), opacity TF(|g|) */
+                float r = rp->useLinear ? vol_linear_c(v, pos.x, pos.y, pos.z, 0)
+                                        : vol_nearest_c(v, pos.x, pos.y, pos.z, 0);
+                float g = rp->useLinear ? vol_linear_c(v, pos.x, pos.y, pos.z, 1)
+                                        : vol_nearest_c(v, pos.x, pos.y, pos.z, 1);
+                float t4[4];
+                tff_linear(v->s, fabsf(g / 1.f), t4);
+                tfc[0] = r; tfc[1] = 0.f; tfc[2] = 0.f; tfc[3] = t4[3];
             } else {
                 float density = rp->useLinear ? vol_linear(v, pos.x, pos.y, pos.z)
                                               : vol_nearest(v, pos.x, pos.y, pos.z);
@@ -1206,6 +1232,8 @@ int vro_render_tile_ex(const vro_scene *scene, const vro_camera_params *cam,
     v.touched = touched;
     v.mbx = (v.w + 3) / 4;
     v.mby = (v.h + 3) / 4;
+    v.nch = scene->channels > 1 ? (int)scene->channels : 1;
+    if (v.nch != 1 && v.nch != 2 && v.nch != 4) return -1;
 
     vro_pathtrace_params pt_default = {100.f};
     kargs_t k = {cam, render, raycast, pathtrace ? pathtrace : &pt_default, use_ess,

@@ -79,6 +79,8 @@ typedef struct {
     uint32_t tff_n;          /* entries (reference: 1024)                             */
     const uint32_t *prefix;  /* inclusive prefix sum of the alpha bytes               */
     uint32_t prefix_n;
+    uint32_t channels;       /* 0/1 = CL_R; 2 = CL_RG, 4 = CL_RGBA: interleaved voxels, the
+                              * bricks are those of channel 0 (generateBricks reads .x)      */
 } vro_scene;
 
 typedef struct {

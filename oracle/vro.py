@@ -41,7 +41,7 @@ class Scene(C.Structure):
     _fields_ = [("voxels", C.c_void_p), ("res", C.c_uint32 * 3), ("format", C.c_int32),
                 ("bricks", C.c_void_p), ("bricks_res", C.c_uint32 * 3),
                 ("tff", C.c_void_p), ("tff_n", C.c_uint32),
-                ("prefix", C.c_void_p), ("prefix_n", C.c_uint32)]
+                ("prefix", C.c_void_p), ("prefix_n", C.c_uint32), ("channels", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -201,17 +201,20 @@ def render_tile(vol, fmt, tff, cam, rp, rc, pt=None, use_ess=True, W=64, H=64, t
     """
     vol = np.ascontiguousarray(vol, dtype=_NP_DTYPE[fmt])
     res = [vol.shape[2], vol.shape[1], vol.shape[0]]
+    channels = vol.shape[3] if vol.ndim == 4 else 1    # [z, y, x, c]: CL_RG / CL_RGBA volumes
     tff = np.ascontiguousarray(tff, dtype=np.uint8).reshape(-1)
     if prefix is None:
         prefix = prefix_sum(tff)
     prefix = np.ascontiguousarray(prefix, dtype=np.uint32)
     if bricks is None and use_ess:
-        bricks = generate_bricks(vol, fmt)
+        # generateBricks reads the .x component (volumeraycast.cl:947-957)
+        bricks = generate_bricks(vol[..., 0] if vol.ndim == 4 else vol, fmt)
     x0, y0, w, h = tile if tile is not None else (0, 0, W, H)
     sc = Scene()
     sc.voxels = vol.ctypes.data
     sc.res = _u3(res)
     sc.format = fmt
+    sc.channels = channels
     if bricks is not None:
         bricks = np.ascontiguousarray(bricks, dtype=_NP_DTYPE[fmt])
         sc.bricks = bricks.ctypes.data

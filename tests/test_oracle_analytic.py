@@ -246,3 +246,44 @@ def test_environment_map_replaces_background():
     assert abs(img[20, 28, 0] - 0.25) < 0.06 and abs(img[20, 28, 1] - 0.5) < 0.06
     assert np.all(np.diff(img[20, :, 0]) > 0)       # s grows with x, t with y (image row 0 = top)
     assert np.all(np.diff(img[:, 28, 1]) > 0)
+
+
+def test_rgba_and_rg_volumes_closed_form():
+    """CL_RGBA volumes (:840-845): the voxel is the sample's colour and opacity, the TF is not
+    used; CL_RG (:846-855): colour (r, 0, 0), opacity TF(|g|).alpha.  Constant volumes give the
+    same closed form as test_constant_density_closed_form."""
+    rgba = np.zeros((20, 20, 20, 4), np.uint8)
+    rgba[...] = [255, 0, 51, 5]
+    cam, rp, rc = _params(rate=1.5, res=(20, 20, 20))
+    tff = np.zeros((1024, 4), np.uint8)          # TF with alpha 0 everywhere: must not matter
+    img, st, _ = vro.render_tile(rgba, vro.UCHAR, tff, cam, rp, rc, use_ess=False, W=40, H=40)
+    hit = img[..., 3] > 0
+    assert hit.sum() == st["rays_hit"] > 0
+    alpha = img[..., 3][hit].astype(np.float64)
+    a = np.float64(np.float32(5) / np.float32(255))
+    n_ray = np.log1p(-alpha) / np.log1p(-a) * 1.5
+    assert np.all(np.abs(n_ray - np.round(n_ray)) < 2e-3)
+    np.testing.assert_allclose(img[..., 0][hit], 1.0, atol=1e-6)                 # c = 1
+    np.testing.assert_allclose(img[..., 1][hit], 1.0 - alpha, atol=2e-6)         # c = 0
+    np.testing.assert_allclose(img[..., 2][hit], 1.0 - 0.8 * alpha, atol=2e-6)   # c = 0.2
+    # RG: opacity comes from the TF at |g|, colour is (r, 0, 0)
+    rg = np.zeros((20, 20, 20, 2), np.uint8)
+    rg[...] = [128, 255]
+    tff[:, 3] = np.arange(1024) // 128           # alpha byte 7 at the top of the table
+    img2, _, _ = vro.render_tile(rg, vro.UCHAR, tff, cam, rp, rc, use_ess=False, W=40, H=40)
+    hit2 = img2[..., 3] > 0
+    assert np.array_equal(hit2, hit)
+    alpha2 = img2[..., 3][hit2].astype(np.float64)
+    a2 = np.float64(np.float32(7) / np.float32(255))
+    n2 = np.log1p(-alpha2) / np.log1p(-a2) * 1.5
+    assert np.all(np.abs(n2 - np.round(n2)) < 2e-3)
+    r = np.float64(np.float32(128) / np.float32(255))
+    np.testing.assert_allclose(img2[..., 0][hit2], 1.0 - (1.0 - r) * alpha2, atol=2e-6)
+    np.testing.assert_allclose(img2[..., 1][hit2], 1.0 - alpha2, atol=2e-6)
+    # ESS decisions come from channel 0 through the TF (generateBricks reads .x): where the TF is
+    # empty at channel 0's value every brick is skipped, whatever the opacity from |g| would be
+    tff[:, 3] = np.where(np.arange(1024) < 900, 0, 7)
+    on, st_on, _ = vro.render_tile(rg, vro.UCHAR, tff, cam, rp, rc, use_ess=True, W=40, H=40)
+    off, _, _ = vro.render_tile(rg, vro.UCHAR, tff, cam, rp, rc, use_ess=False, W=40, H=40)
+    assert st_on["samples_taken"] == 0 and np.all(on[..., :3] == 1.0)
+    assert np.array_equal(off, img2)

@@ -76,8 +76,9 @@ void VolumeRenderCL::initialize(bool useGL, bool useCPU, cl_vendor, const std::s
     if (_dr.has_data()) {
         const auto &p = _dr.properties();
         for (size_t t = 0; t < _dr.data().size(); ++t)
-            check("volDataToCLmem", vrhip_upload_volume(_r, _dr.data()[t].data(), p.volume_res.data(),
-                                                        int(p.format), uint32_t(t)));
+            check("volDataToCLmem",
+                  vrhip_upload_volume_channels(_r, _dr.data()[t].data(), p.volume_res.data(),
+                                               int(p.format), _channels, uint32_t(t)));
     }
 }
 
@@ -161,23 +162,31 @@ size_t VolumeRenderCL::loadVolumeData(const DatRawReader::Properties volumeFileP
         std::cout << p.to_string() << std::endl;
         // volDataToCLmem (:690-759)
         const std::string &co = p.image_channel_order;
-        if (!(co == "R" || co == "" || co == "I" || co == "LUMINANCE")) {
-            if (co == "RG" || co == "RGBA" || co == "ARGB" || co == "BGRA")
-                throw std::invalid_argument("Multi-channel volumes are outside the hot path.");
+        int channels = 1;
+        if (co == "RG") channels = 2;
+        else if (co == "RGBA") channels = 4;
+        else if (co == "ARGB" || co == "BGRA")
+            // accepted by the reference's upload (:706-709), but its kernel has no branch for these
+            // orders and composites an unset colour (volumeraycast.cl:800-855)
+            throw std::invalid_argument("ARGB / BGRA volumes are not supported.");
+        else if (!(co == "R" || co == "" || co == "I" || co == "LUMINANCE"))
             throw std::invalid_argument("Unknown or invalid volume color format.");
-        }
+        _channels = channels;
         if (p.format != DatRawReader::UCHAR && p.format != DatRawReader::USHORT &&
             p.format != DatRawReader::FLOAT)
             throw std::invalid_argument("Unknown or invalid volume data format.");
         const size_t bpv = p.format == DatRawReader::UCHAR ? 1 : p.format == DatRawReader::USHORT ? 2 : 4;
         check("clearVolumes", vrhip_clear_volumes(_r));
         for (size_t t = 0; t < _dr.data().size(); ++t) {
-            if (size_t(p.volume_res[0]) * p.volume_res[1] * p.volume_res[2] * bpv > _dr.data()[t].size()) {
+            // (the reference checks one channel's worth, :740-742, and lets the image read beyond)
+            if (size_t(p.volume_res[0]) * p.volume_res[1] * p.volume_res[2] * bpv * size_t(channels) >
+                _dr.data()[t].size()) {
                 _dr.clearData();
                 throw std::runtime_error("Volume size does not match size specified in dat file.");
             }
-            check("volDataToCLmem", vrhip_upload_volume(_r, _dr.data()[t].data(), p.volume_res.data(),
-                                                        int(p.format), uint32_t(t)));
+            check("volDataToCLmem",
+                  vrhip_upload_volume_channels(_r, _dr.data()[t].data(), p.volume_res.data(),
+                                               int(p.format), _channels, uint32_t(t)));
         }
         calcScaling();
     } catch (std::invalid_argument &e) {

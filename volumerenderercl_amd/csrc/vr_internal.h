@@ -18,6 +18,11 @@ struct VolView {
     uint32_t nbx, nby, nbz;     // micro-brick grid = ceil(res / 4)
     uint32_t ystride;           // elements per brick row:   nbx * 64
     unsigned long long zstride; // elements per brick slice: nbx * nby * 64
+    // CL_RG / CL_RGBA volumes (volumerendercl.cpp:697-705): one planar micro-bricked array per
+    // channel.  `data` is channel 0 -- the .x every single-channel reader of the kernel looks at
+    // (bricks, gradients, path tracer); chan[0..2] are channels 1..3.
+    const void *chan[3];
+    int channels;               // 1, 2 or 4
 };
 
 __host__ __device__ inline unsigned long long vr_voxel_index(const VolView &v, int x, int y, int z)

@@ -262,6 +262,24 @@ VR_DEV void eval_batch(const Vol<VT, INSTR> &vol, const float4 *s_tff, int tffn,
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) tfc[k] = tff_linear(s_tff, tffn, dens[k]);
 
+    // CL_RGBA / CL_RG volumes (:838-855): the voxel is the colour (RGBA) or (r, g) -> colour
+    // (r, 0, 0) with opacity TF(|g|); neither is shaded.  dens[] holds channel 0 already.
+    const bool multi = XS && vol.channels > 1 && rp.illumType != 4;
+    if (multi) {
+#pragma unroll 1
+        for (int k = 0; k < kBatch; ++k) {
+            if (INSTR == 2 && !vk[k]) continue;
+            float ch[3] = {0.f, 0.f, 0.f};
+            for (int j = 1; j < vol.channels; ++j) {
+                const Vol<VT, INSTR> vc = vol.channel(j);
+                ch[j - 1] = rp.useLinear ? vc.linear(pk[k].x, pk[k].y, pk[k].z)
+                                         : vc.nearest(pk[k].x, pk[k].y, pk[k].z);
+            }
+            if (vol.channels == 4) tfc[k] = make_float4(dens[k], ch[0], ch[1], ch[2]);
+            else tfc[k] = make_float4(dens[k], 0.f, 0.f, tff_linear(s_tff, tffn, fabsf(ch[0] / 1.f)).w);
+        }
+    }
+
     // ---- which samples need the expensive part, and their slots
     const bool shade_mode = XS ? (rp.illumType != 0 && rp.illumType != 4) : rp.illumType == 1;   // :809
     const bool want_grad = shade_mode || (rcp.contours && !rp.illumType);
@@ -271,7 +289,7 @@ VR_DEV void eval_batch(const Vol<VT, INSTR> &vol, const float4 *s_tff, int tffn,
     uint32_t n_slots = 0;
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
-        lit[k] = vk[k] && tfc[k].w > 0.1f && !(XS && rp.illumType == 4);   // :809/:832, before the depth cue
+        lit[k] = vk[k] && tfc[k].w > 0.1f && !(XS && rp.illumType == 4) && !multi;   // :809/:832, before the depth cue
         shaded[k] = lit[k] && shade_mode;
         if (rcp.aerial) {                                     // :858-862
             float depthCue = 1.f - (tk[k] - c.tnear) / c.sampleDist;
@@ -677,6 +695,9 @@ VR_DEV Vol<VT, INSTR> make_vol(const VolView &vv, uint32_t *touched)
     vol.nbx = vv.nbx; vol.nby = vv.nby;
     vol.ystride = vv.ystride; vol.zstride = (uint32_t)vv.zstride;
     vol.touched = touched;
+    vol.pc[0] = (const VT *)vv.chan[0]; vol.pc[1] = (const VT *)vv.chan[1];
+    vol.pc[2] = (const VT *)vv.chan[2];
+    vol.channels = vv.channels;
     return vol;
 }
 
@@ -1309,7 +1330,7 @@ hipError_t launch_typed(const RaycastLaunch &a, hipStream_t stream)
     // the rarely used shading modes 2-5 live in kernel variants of their own (XS), so that their
     // code and registers do not tax the default ones
     const bool xs = a.render.illumType >= 2 || a.raycast.useAO != 0 || a.render.showEss != 0 ||
-                    a.render.imgEss != 0;
+                    a.render.imgEss != 0 || a.vol.channels > 1;
     if (a.use_ess) {
         if (lds) {
             if (a.instr == 0) return xs ? launch_variant<VT, true, 0, true, true>(a, stream) : launch_variant<VT, true, 0, true, false>(a, stream);

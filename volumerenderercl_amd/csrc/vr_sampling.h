@@ -57,6 +57,16 @@ struct Vol {
     uint32_t nbx, nby, ystride;     // micro-brick layout (vr_internal.h)
     uint32_t zstride;               // fits 32 bits (<= 2048 * 2048 * 64): one 32x32->64 multiply per z
     uint32_t *touched;
+    const VT *pc[3];                // channels 1..3 of CL_RG / CL_RGBA volumes (XS variants only)
+    int channels;
+
+    // this volume's channel ch >= 1 as a single-channel volume
+    VR_DEV Vol channel(int ch) const
+    {
+        Vol v = *this;
+        v.p = pc[ch - 1];
+        return v;
+    }
 
     // per-axis parts of the element index of voxel (x, y, z) in the 4x4x4 micro-brick layout
     VR_DEV uint32_t xoff(int x) const { return ((uint32_t)(x >> 2) << 6) + (uint32_t)(x & 3); }

@@ -16,7 +16,8 @@
 namespace {
 
 struct VolumeSlot {
-    void *dev = nullptr;      // dense x-fastest voxels
+    void *dev = nullptr;      // micro-bricked voxels (channel 0 of a multi-channel volume)
+    void *chan[3] = {nullptr, nullptr, nullptr};   // channels 1..3 of CL_RG / CL_RGBA volumes
     void *bricks = nullptr;   // (min,max) grid
     float2 *pt_minmax = nullptr;   // path tracer: per-cell (min,max) incl. halo, built on demand
     bool pt_minmax_valid = false;
@@ -38,6 +39,7 @@ struct vrhip_renderer {
 
     uint32_t res[3] = {0, 0, 0};
     int format = -1;
+    int channels = 1;                 // 1 = CL_R, 2 = CL_RG, 4 = CL_RGBA
     // HBM layout of a time step: 4x4x4-voxel micro-bricks (vr_internal.h, DESIGN.md "Data
     // layout"); nb = ceil(res / 4)
     uint32_t nb[3] = {0, 0, 0};
@@ -234,6 +236,17 @@ VolView make_vol_view(const vrhip_renderer *r, const void *data)
     v.nbz = r->nb[2];
     v.ystride = r->nb[0] * 64u;
     v.zstride = (unsigned long long)r->nb[0] * r->nb[1] * 64ull;
+    v.chan[0] = v.chan[1] = v.chan[2] = nullptr;
+    v.channels = 1;
+    return v;
+}
+
+// the render view of a time step: all channels
+VolView make_render_view(const vrhip_renderer *r, const VolumeSlot &s)
+{
+    VolView v = make_vol_view(r, s.dev);
+    for (int i = 0; i < 3; ++i) v.chan[i] = s.chan[i];
+    v.channels = r->channels;
     return v;
 }
 
@@ -265,7 +278,7 @@ int set_device(const vrhip_renderer *r)
 
 // (re)allocate a slot for `timestep`, checking that res/format agree with other timesteps
 int prepare_slot(vrhip_renderer *r, const uint32_t res[3], int format, uint32_t timestep,
-                 VolumeSlot **slot)
+                 VolumeSlot **slot, int channels = 1)
 {
     VR_REQUIRE(r, res && res[0] && res[1] && res[2], VRHIP_ERR_INVALID,
                "Volume resolution must be non-zero.");
@@ -274,7 +287,7 @@ int prepare_slot(vrhip_renderer *r, const uint32_t res[3], int format, uint32_t 
     VR_REQUIRE(r, res[0] <= 8192 && res[1] <= 8192 && res[2] <= 8192, VRHIP_ERR_INVALID,
                "Volume resolution above 8192 per axis is not supported.");
     bool same = r->format == format && r->res[0] == res[0] && r->res[1] == res[1] &&
-                r->res[2] == res[2];
+                r->res[2] == res[2] && r->channels == channels;
     if (!same) {
         VR_REQUIRE(r, timestep == 0 || r->vols.empty(), VRHIP_ERR_INVALID,
                    "Volume size does not match size of the other time steps.");
@@ -282,11 +295,14 @@ int prepare_slot(vrhip_renderer *r, const uint32_t res[3], int format, uint32_t 
         if (rc) return rc;
         std::memcpy(r->res, res, sizeof r->res);
         r->format = format;
+        r->channels = channels;
         set_layout(r);
     }
     if (r->vols.size() <= timestep) r->vols.resize(timestep + 1);
     VolumeSlot &s = r->vols[timestep];
     if (!s.dev) VR_HIP(r, hipMalloc(&s.dev, volume_alloc_bytes(r)));
+    for (int c = 1; c < channels; ++c)
+        if (!s.chan[c - 1]) VR_HIP(r, hipMalloc(&s.chan[c - 1], volume_alloc_bytes(r)));
     r->bricks_valid = false;
     r->skip_dirty = true;
     r->pt_dirty = true;
@@ -331,6 +347,8 @@ int check_renderable(vrhip_renderer *r, uint32_t width, uint32_t height)
                "Unknown illumination type.");
     VR_REQUIRE(r, r->render.technique == 0 || r->pathtrace.max_extinction > 0.f, VRHIP_ERR_INVALID,
                "max_extinction must be positive.");
+    // technique 1 and the traffic / downsampling helpers read channel 0 only, like the kernel's
+    // .x readers; nothing else to check for CL_RG / CL_RGBA volumes
     // the path-tracing branch returns before the hit image is written (:686-706): its state
     // would never change
     VR_REQUIRE(r, !(r->render.imgEss && r->render.technique == 1), VRHIP_ERR_UNSUPPORTED,
@@ -501,7 +519,7 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
 {
     std::memset(a, 0, sizeof *a);
     const VolumeSlot &s = r->vols[r->timestep];
-    a->vol = make_vol_view(r, s.dev);
+    a->vol = make_render_view(r, s);
     a->bricks = make_brick_view(r, s.bricks);
     a->tf = make_tf_view(r);
     a->skip.bits = r->skip_bits;
@@ -547,7 +565,8 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
     a->pathtrace = r->pathtrace;
     a->cells = r->cells;
     if (!r->pt_cull) a->cells.bound = nullptr;
-    if (!r->skip_empty) a->cells.empty = nullptr;
+    // the empty bits are those of TF(channel 0): not what a CL_RG / CL_RGBA sample's opacity is
+    if (!r->skip_empty || r->channels > 1) a->cells.empty = nullptr;
     a->format = r->format;
     a->use_ess = r->use_ess ? 1 : 0;
     a->instr = r->stats_enabled ? 1 : 0;
@@ -763,6 +782,31 @@ int vrhip_upload_volume(vrhip_renderer *r, const void *host_voxels, const uint32
     return VRHIP_OK;
 }
 
+int vrhip_upload_volume_channels(vrhip_renderer *r, const void *host_voxels, const uint32_t res[3],
+                                 int format, int channels, uint32_t timestep)
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    if (channels == 1) return vrhip_upload_volume(r, host_voxels, res, format, timestep);
+    VR_REQUIRE(r, host_voxels, VRHIP_ERR_INVALID, "vrhip_upload_volume: NULL voxel pointer");
+    VR_REQUIRE(r, channels == 2 || channels == 4, VRHIP_ERR_INVALID,
+               "Unknown or invalid volume color format.");   // volumerendercl.cpp:711
+    if (set_device(r)) return VRHIP_ERR_HIP;
+    VolumeSlot *s;
+    int rc = prepare_slot(r, res, format, timestep, &s, channels);
+    if (rc) return rc;
+    // interleaved texels -> one planar array per channel, each re-tiled like a CL_R volume
+    const size_t n = (size_t)res[0] * res[1] * res[2], bpv = fmt_bytes(format);
+    std::vector<unsigned char> plane(n * bpv);
+    const unsigned char *src = static_cast<const unsigned char *>(host_voxels);
+    for (int c = 0; c < channels; ++c) {
+        for (size_t i = 0; i < n; ++i)
+            std::memcpy(&plane[i * bpv], src + (i * (size_t)channels + (size_t)c) * bpv, bpv);
+        VR_HIP(r, copy_volume(r, c == 0 ? s->dev : s->chan[c - 1], plane.data(), true, false,
+                              r->stream));
+    }
+    return VRHIP_OK;
+}
+
 int vrhip_upload_volume_device(vrhip_renderer *r, const void *dev_voxels, const uint32_t res[3],
                                int format, uint32_t timestep)
 {
@@ -842,6 +886,8 @@ int vrhip_clear_volumes(vrhip_renderer *r)
     (void)hipStreamSynchronize(r->stream);
     for (VolumeSlot &s : r->vols) {
         if (s.dev) (void)hipFree(s.dev);
+        for (void *c : s.chan)
+            if (c) (void)hipFree(c);
         if (s.bricks) (void)hipFree(s.bricks);
         if (s.pt_minmax) (void)hipFree(s.pt_minmax);
     }
@@ -850,6 +896,7 @@ int vrhip_clear_volumes(vrhip_renderer *r)
     r->skip_dirty = true;
     r->pt_dirty = true;
     r->format = -1;
+    r->channels = 1;
     r->res[0] = r->res[1] = r->res[2] = 0;
     r->timestep = 0;
     return VRHIP_OK;

@@ -211,20 +211,34 @@ class VolumeRenderCL:
         p = reader.properties()
         vols = reader.data()
         self._histograms = reader.histograms()
-        return self.loadVolumeArrays(vols, p.format, p.slice_thickness, p.volume_res[:3])
+        co = p.image_channel_order
+        if co in ("R", "", "I", "LUMINANCE"):
+            channels = 1
+        elif co == "RG":
+            channels = 2
+        elif co == "RGBA":
+            channels = 4
+        elif co in ("ARGB", "BGRA"):   # uploaded by the reference, but its kernel has no branch for them
+            raise RuntimeError("ARGB / BGRA volumes are not supported.")
+        else:
+            raise RuntimeError("Unknown or invalid volume color format.")   # :711
+        return self.loadVolumeArrays(vols, p.format, p.slice_thickness, p.volume_res[:3],
+                                     channels=channels)
 
-    def loadVolumeArrays(self, volumes, fmt, thickness=(1.0, 1.0, 1.0), res=None):
-        """Upload already-decoded time steps (ndarray [z, y, x] or flat) -- the
-        volDataToCLmem + calcScaling + default prefix-sum part of loadVolumeData."""
+    def loadVolumeArrays(self, volumes, fmt, thickness=(1.0, 1.0, 1.0), res=None, channels=None):
+        """Upload already-decoded time steps (ndarray [z, y, x], [z, y, x, c] for CL_RG / CL_RGBA
+        volumes, or flat with `res` and `channels`) -- the volDataToCLmem + calcScaling + default
+        prefix-sum part of loadVolumeData."""
         self._vol_loaded = False
         self._check(self._lib.vrhip_clear_volumes(self._h))
         for t, v in enumerate(volumes):
             v = np.ascontiguousarray(v, dtype=NP_DTYPE[fmt])
             r = res if res is not None else (v.shape[2], v.shape[1], v.shape[0])
-            if v.size < int(r[0]) * int(r[1]) * int(r[2]):
+            nch = channels if channels is not None else (v.shape[3] if v.ndim == 4 else 1)
+            if v.size < int(r[0]) * int(r[1]) * int(r[2]) * nch:
                 raise RuntimeError("Volume size does not match size specified in dat file.")
-            self._check(self._lib.vrhip_upload_volume(self._h, v.ctypes.data_as(C.c_void_p),
-                                                      _u3(r), fmt, t))
+            self._check(self._lib.vrhip_upload_volume_channels(
+                self._h, v.ctypes.data_as(C.c_void_p), _u3(r), fmt, int(nch), t))
         self._res = [int(r[0]), int(r[1]), int(r[2]), len(volumes)]
         self._format = fmt
         self._thickness = [float(x) for x in thickness]
