@@ -35,6 +35,8 @@ WORKLOADS = {
     "sphere2048": ("sphere", 2048, "UCHAR", 1, "default", True),
     "haze2048": ("sphere", 2048, "UCHAR", 1, "haze", True),     # dense regime: no ERT
     "shells1024u16": ("shells", 1024, "USHORT", 1, "default", True),
+    "haze1024": ("sphere", 1024, "UCHAR", 1, "haze", True),     # mid-sized dense volumes
+    "sphere512f": ("sphere", 512, "FLOAT", 1, "default", True),
     "sphere256": ("sphere", 256, "UCHAR", 1, "default", True),
     "sphere256_plain": ("sphere", 256, "UCHAR", 0, "default", False),
     "sphere64": ("sphere", 64, "UCHAR", 1, "default", True),    # CI-sized

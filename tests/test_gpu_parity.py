@@ -914,3 +914,84 @@ def test_cpp_host_cli_rgba_dat(tmp_path):
     bad = subprocess.run([exe, "--dat", str(tmp_path / "bgra.dat"), "--out", out],
                          capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and "not supported" in bad.stderr
+
+
+FP_CASES = [
+    # fmt, res, (W, H), view, tff, kwargs -- frames the default kernels render from the footprint
+    # volume (un-instrumented, volume not much wider than the viewport)
+    (UCHAR, (48, 48, 48), (96, 80), "rot30", "default", {}),
+    (UCHAR, (33, 47, 29), (64, 64), "close", "haze", {"illum": 0}),
+    (UCHAR, (48, 48, 48), (64, 64), "inside", "default", {}),        # edge-clamped fetches
+    (USHORT, (40, 56, 36), (64, 64), "close", "opaque", {"ess": False}),
+    (USHORT, (45, 45, 45), (80, 64), "rot30", "default", {"contours": True}),
+    (FLOAT, (48, 48, 48), (80, 64), "rot30", "default", {}),
+    (FLOAT, (37, 37, 37), (64, 64), "inside", "haze", {"ess": False}),
+]
+
+
+@pytest.mark.parametrize("fmt,res,size,view,tff,kw", FP_CASES)
+def test_footprint_volume_frames_match_oracle(vr, monkeypatch, fmt, res, size, view, tff, kw):
+    """The footprint volume (one load per trilinear fetch) only changes where the
+    eight voxels come from: the un-instrumented frame equals the oracle's, and the frame of a
+    renderer with the footprint volume disabled, bit for bit."""
+    vol = common.noise_volume(res, fmt, seed=12, smooth=False)
+    table = common.tffs()[tff]
+    W, H = size
+    _setup(vr, vol, fmt, table, common.views()[view], **kw)
+    vr.setStatsEnabled(False)
+    got = vr.runRaycastNoGL(W, H)
+    vr.setIteration(0)
+    ref, _, _ = common.oracle_frame(vr, vol, fmt, table, W, H, use_ess=kw.get("ess", True))
+    assert np.abs(got - ref).max() <= TOL
+    monkeypatch.setenv("VRHIP_NO_FOOTPRINT", "1")
+    r2 = VolumeRenderCL()
+    r2.initialize()
+    try:
+        _setup(r2, vol, fmt, table, common.views()[view], **kw)
+        r2.setStatsEnabled(False)
+        plain = r2.runRaycastNoGL(W, H)
+    finally:
+        r2.close()
+    assert np.array_equal(got, plain)
+    # another viewport (other rays, other fetches): same agreement
+    small = vr.runRaycastNoGL(24, 16)
+    vr.setIteration(0)
+    ref_small, _, _ = common.oracle_frame(vr, vol, fmt, table, 24, 16, use_ess=kw.get("ess", True))
+    assert np.abs(small - ref_small).max() <= TOL
+
+
+def test_time_series_steps_match_oracle(vr):
+    """One volume per time step (volumerendercl.cpp:736-752), setTimestep (:1167-1174): bricks,
+    skip bitmap, cell grid and footprint volume follow the selected step; an out-of-range step is
+    ignored like in the reference."""
+    steps = [common.noise_volume((40, 44, 36), UCHAR, seed=40 + t, smooth=False) for t in range(3)]
+    tff = common.tffs()["default"]
+    W, H = 72, 56
+    vr.loadVolumeArrays(steps, UCHAR)
+    vr.setTransferFunction(tff)
+    vr.setSeed(SEED)
+    vr.setIllumination(1)
+    vr.setObjEss(True)
+    vr.setTechnique(0)
+    vr.setAmbientOcclusion(False)
+    vr.setShowESS(False)
+    vr.setImgEss(False)
+    vr.updateView(common.views()["rot30"])
+    assert vr.getResolution()[3] == 3
+    frames = {}
+    for t in (0, 2, 1, 2):
+        vr.setTimestep(t)
+        for stats in (True, False):      # instrumented (plain layout) and default kernels
+            vr.setStatsEnabled(stats)
+            got = vr.runRaycastNoGL(W, H)
+            vr.setIteration(0)
+            ref, _, _ = common.oracle_frame(vr, steps[t], UCHAR, tff, W, H)
+            assert np.abs(got - ref).max() <= TOL, "time step %d" % t
+        frames.setdefault(t, got)
+        assert np.array_equal(frames[t], got)
+    assert np.abs(frames[0] - frames[1]).max() > 1e-3
+    vr.setTimestep(7)                    # ignored
+    vr.setStatsEnabled(False)
+    again = vr.runRaycastNoGL(W, H)
+    vr.setIteration(0)
+    assert np.array_equal(again, frames[2])

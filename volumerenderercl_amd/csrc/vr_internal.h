@@ -23,7 +23,20 @@ struct VolView {
     // (bricks, gradients, path tracer); chan[0..2] are channels 1..3.
     const void *chan[3];
     int channels;               // 1, 2 or 4
+    // Footprint volume (optional, nullptr = absent): entry (ex, ey, ez), ex in [0, w] etc., holds
+    // the 8 voxels a trilinear fetch with low-corner texel ix = ex - 1 reads, edge clamping
+    // applied: value j = dx + 2 dy + 4 dz is voxel (clamp(ix + dx), clamp(iy + dy), clamp(iz + dz)).
+    // One 8 / 16 / 32-byte load per fetch instead of eight voxel loads; 8x the volume's bytes, laid
+    // out in 4x4x4 micro-bricks of entries like the volume itself.
+    const void *fp;
+    uint32_t fp_nbx, fp_nby;    // micro-brick grid of the (w+1) x (h+1) x (d+1) entries
 };
+
+__host__ __device__ inline unsigned long long vr_fp_index(const VolView &v, int ex, int ey, int ez)
+{
+    return ((unsigned long long)(ez >> 2) * v.fp_nby + (unsigned long long)(ey >> 2)) * v.fp_nbx * 64ull +
+           (unsigned long long)(((ex >> 2) << 6) + ((ez & 3) << 4) + ((ey & 3) << 2) + (ex & 3));
+}
 
 __host__ __device__ inline unsigned long long vr_voxel_index(const VolView &v, int x, int y, int z)
 {
@@ -164,6 +177,9 @@ struct RaycastLaunch {
 };
 
 hipError_t vr_launch_raycast(const RaycastLaunch &a, hipStream_t stream);
+// fills the footprint volume vol.fp of `vol`: (w+1)(h+1)(d+1) entries rounded up to
+// whole micro-bricks, 8 values of the volume's type each; vr_bricks.hip
+hipError_t vr_launch_build_footprint(const VolView &vol, int format, hipStream_t stream);
 // technique 1 (Woodcock-tracking path tracer), one sample per pixel; vr_pathtrace.hip
 hipError_t vr_launch_pathtrace(const RaycastLaunch &a, hipStream_t stream);
 // cell grid (vr_cells.hip): per-cell (min,max) of the raw voxel values incl. halo; then opacity

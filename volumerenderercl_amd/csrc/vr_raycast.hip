@@ -225,8 +225,10 @@ constexpr int kStageF4 = (kBlockDim / 64) * kStageFloatsPerWave / 4;   // float4
 // over the dense slot list (usually one pass over the active lanes; per-ray constants come from
 // the owner lane by ds_bpermute) and hands four scalars per sample back.  Every sample sees the
 // same fp32 operations as before, in another lane.
-template <typename VT, int INSTR, bool XS>
-VR_DEV void eval_batch(const Vol<VT, INSTR> &vol, const float4 *s_tff, int tffn, float *s_stage,
+// FP: the kernel variant that reads the footprint volume (VolView::fp) instead of the plain
+// layout -- default kernels only (no instrumentation, no XS extras); see launch_typed.
+template <typename VT, int INSTR, bool XS, bool FP>
+VR_DEV void eval_batch(const Vol<VT, INSTR, FP> &vol, const float4 *s_tff, int tffn, float *s_stage,
                        const RayCtx &c, const vrhip_rendering_params &rp,
                        const vrhip_raycast_params &rcp, float refInterval,
                        const float (&tk)[kBatch], const bool (&vk)[kBatch], float (&p0)[kBatch],
@@ -271,7 +273,7 @@ VR_DEV void eval_batch(const Vol<VT, INSTR> &vol, const float4 *s_tff, int tffn,
             if (INSTR == 2 && !vk[k]) continue;
             float ch[3] = {0.f, 0.f, 0.f};
             for (int j = 1; j < vol.channels; ++j) {
-                const Vol<VT, INSTR> vc = vol.channel(j);
+                const auto vc = vol.channel(j);
                 ch[j - 1] = rp.useLinear ? vc.linear(pk[k].x, pk[k].y, pk[k].z)
                                          : vc.nearest(pk[k].x, pk[k].y, pk[k].z);
             }
@@ -417,8 +419,8 @@ constexpr int kLook1 = VR_LOOK1, kLook2 = VR_LOOK2;
 // The cell is found from a linearised texel position (u0 + k * du): the cell extents carry a
 // one-texel halo for exactly this purpose, so the lookahead costs a few instructions per sample
 // and no voxel access.
-template <typename VT, int INSTR, int kLook>
-VR_DEV uint32_t empty_mask(const CellView &cv, const Vol<VT, INSTR> &vol, const RayCtx &c, float t0)
+template <typename VT, int INSTR, int kLook, typename V>
+VR_DEV uint32_t empty_mask(const CellView &cv, const V &vol, const RayCtx &c, float t0)
 {
     const f3 p0 = add3(c.cam, scale3(c.dir, t0 - c.offset));
     const float u0 = (p0.x * 0.5f + 0.5f) * vol.fw - 0.5f;
@@ -558,8 +560,8 @@ VR_DEV float hybrid_rand(uint32_t (&st)[4])
 // calcAO (:368-392) at the sample that triggered early ray termination, with
 // getUniformRandomSampleDirectionUpper (:353-364); scales the ray's colour by 1 - ao / 2 (:875).
 // Rare mode, rolled loops.
-template <typename VT, int INSTR>
-VR_DEV void apply_ao(const Vol<VT, INSTR> &vol, const float4 *s_tff, int tffn, const RayCtx &c,
+template <typename VT, int INSTR, typename V>
+VR_DEV void apply_ao(const V &vol, const float4 *s_tff, int tffn, const RayCtx &c,
                      RayDyn &d, const vrhip_rendering_params &rp, uint32_t gx, uint32_t gy)
 {
     const f3 p0 = add3(c.cam, scale3(c.dir, d.t_ert - c.offset));
@@ -684,10 +686,10 @@ VR_DEV void write_pixel(const FrameView &fr, const vrhip_rendering_params &rp, c
         fr.hit_any[(size_t)(gy >> 3) * fr.hit_w + (gx >> 3)] = 1;
 }
 
-template <typename VT, int INSTR>
-VR_DEV Vol<VT, INSTR> make_vol(const VolView &vv, uint32_t *touched)
+template <typename VT, int INSTR, bool FP>
+VR_DEV Vol<VT, INSTR, FP> make_vol(const VolView &vv, uint32_t *touched)
 {
-    Vol<VT, INSTR> vol;
+    Vol<VT, INSTR, FP> vol;
     vol.p = (const VT *)vv.data;
     vol.w1 = vv.w - 1; vol.h1 = vv.h - 1; vol.d1 = vv.d - 1;
     vol.fw = vv.fw; vol.fh = vv.fh; vol.fd = vv.fd;
@@ -698,6 +700,9 @@ VR_DEV Vol<VT, INSTR> make_vol(const VolView &vv, uint32_t *touched)
     vol.pc[0] = (const VT *)vv.chan[0]; vol.pc[1] = (const VT *)vv.chan[1];
     vol.pc[2] = (const VT *)vv.chan[2];
     vol.channels = vv.channels;
+    vol.fp = (const FpEntry<VT> *)vv.fp;
+    vol.fp_ystride = vv.fp_nbx * 64u;
+    vol.fp_zstride = vv.fp_nbx * vv.fp_nby * 64u;
     return vol;
 }
 
@@ -775,7 +780,7 @@ __global__ __launch_bounds__(kBlockDim) void vr_dda_prepass_kernel(
 
 // ------------------------------------------------------------------ phase 1
 
-template <typename VT, bool ESS, int INSTR, bool SKIP_LDS, bool XS>
+template <typename VT, bool ESS, int INSTR, bool SKIP_LDS, bool XS, bool FP>
 __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_kernel(
     VolView vv, BrickView bricks, TfView tf, SkipView skip, CellView cells, FrameView fr,
     vrhip_camera_params cam, vrhip_rendering_params rp, vrhip_raycast_params rc, DevStats *stats,
@@ -797,7 +802,7 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_kernel(
     const int tffn = (int)tf.tff_n;
     unsigned long long c_taken = 0, c_nominal = 0, c_shaded = 0, c_bricks = 0, c_skipped = 0,
                        c_hit = 0;
-    const Vol<VT, INSTR> vol = make_vol<VT, INSTR>(vv, touched);
+    const Vol<VT, INSTR, FP> vol = make_vol<VT, INSTR, FP>(vv, touched);
     const f3 resf = mk3(vol.fw, vol.fh, vol.fd);
     const f3 voxLen = mk3(1.f / vol.fw, 1.f / vol.fh, 1.f / vol.fd);
     const float refInterval = 1.f / rc.samplingRate;
@@ -891,7 +896,7 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_kernel(
                     if (INSTR == 2) vk[k] = false;
                 }
                 float p0[kBatch], p1[kBatch], p2[kBatch], opk[kBatch];
-                eval_batch<VT, INSTR, XS>(vol, s_tff, tffn, s_stage, c, rp, rc, refInterval, tk, vk, p0, p1, p2,
+                eval_batch<VT, INSTR, XS, FP>(vol, s_tff, tffn, s_stage, c, rp, rc, refInterval, tk, vk, p0, p1, p2,
                                       opk, litk);
                 VR_STAMP(3);
                 // sequential front-to-back compositing (:865-879)
@@ -977,7 +982,7 @@ VR_DEV void composite_from(const RayCtx &c, RayDyn &d, const float (&p0)[kBatch]
 // lane replays the compositing of all 16 in ray order, fetching the other lanes' results with
 // in-quad DPP broadcasts -- the fp32 operation sequence per ray is exactly phase 1's (and the
 // reference's), the serial chain of a long ray is 4x shorter.
-template <typename VT, bool ESS, int INSTR, bool SKIP_LDS, bool XS>
+template <typename VT, bool ESS, int INSTR, bool SKIP_LDS, bool XS, bool FP>
 __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
     VolView vv, BrickView bricks, TfView tf, SkipView skip, CellView cells, FrameView fr,
     vrhip_camera_params cam, vrhip_rendering_params rp, vrhip_raycast_params rc, DevStats *stats,
@@ -1001,7 +1006,7 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
     constexpr uint32_t kRaysPerWave = 64 / kSplit;
     const int tffn = (int)tf.tff_n;
     unsigned long long c_taken = 0, c_shaded = 0, c_bricks = 0, c_skipped = 0;
-    const Vol<VT, INSTR> vol = make_vol<VT, INSTR>(vv, touched);
+    const Vol<VT, INSTR, FP> vol = make_vol<VT, INSTR, FP>(vv, touched);
     const f3 resf = mk3(vol.fw, vol.fh, vol.fd);
     const f3 voxLen = mk3(1.f / vol.fw, 1.f / vol.fh, 1.f / vol.fd);
     const float refInterval = 1.f / rc.samplingRate;
@@ -1114,14 +1119,14 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
                     float tk2[kBatch];
 #pragma unroll
                     for (int k = 0; k < kBatch; ++k) tk2[k] = tk[k] + 1e-7f;
-                    eval_batch<VT, INSTR, XS>(vol, s_tff, tffn, s_stage, c, rp, rc, refInterval, tk2, vk, p0, p1,
+                    eval_batch<VT, INSTR, XS, FP>(vol, s_tff, tffn, s_stage, c, rp, rc, refInterval, tk2, vk, p0, p1,
                                           p2, opk, litk);
                     asm volatile("" ::"v"(p0[0]), "v"(p0[1]), "v"(p0[2]), "v"(p0[3]), "v"(p1[0]), "v"(p1[1]),
                                  "v"(p1[2]), "v"(p1[3]), "v"(p2[0]), "v"(p2[1]), "v"(p2[2]), "v"(p2[3]),
                                  "v"(opk[0]), "v"(opk[1]), "v"(opk[2]), "v"(opk[3]));
                 }
 #endif
-                eval_batch<VT, INSTR, XS>(vol, s_tff, tffn, s_stage, c, rp, rc, refInterval, tk, vk, p0, p1, p2,
+                eval_batch<VT, INSTR, XS, FP>(vol, s_tff, tffn, s_stage, c, rp, rc, refInterval, tk, vk, p0, p1, p2,
                                       opk, litk);
                 VR_STAMP(3);
                 int fl[kBatch];
@@ -1273,11 +1278,11 @@ hipError_t prepare_variant(K kernel, size_t lds, int *nb_out, const char *what, 
     return hipSuccess;
 }
 
-template <typename VT, bool ESS, int INSTR, bool SKIP_LDS, bool XS>
+template <typename VT, bool ESS, int INSTR, bool SKIP_LDS, bool XS, bool FP = false>
 hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
 {
-    auto k1 = vr_raycast_kernel<VT, ESS, INSTR, SKIP_LDS, XS>;
-    auto k2 = vr_raycast_split_kernel<VT, ESS, INSTR, SKIP_LDS, XS>;
+    auto k1 = vr_raycast_kernel<VT, ESS, INSTR, SKIP_LDS, XS, FP>;
+    auto k2 = vr_raycast_split_kernel<VT, ESS, INSTR, SKIP_LDS, XS, FP>;
     size_t lds = (size_t)kStageF4 * sizeof(float4) + (size_t)a.tf.tff_n * sizeof(float4);
     if (ESS && SKIP_LDS) lds += ((size_t)a.skip.n_words + 1) * sizeof(uint32_t);
     static int nb1 = 0, nb2 = 0;
@@ -1331,6 +1336,12 @@ hipError_t launch_typed(const RaycastLaunch &a, hipStream_t stream)
     // code and registers do not tax the default ones
     const bool xs = a.render.illumType >= 2 || a.raycast.useAO != 0 || a.render.showEss != 0 ||
                     a.render.imgEss != 0 || a.vol.channels > 1;
+    // the default kernels read the footprint volume when the host has provided one for this frame
+    if (!xs && a.instr == 0 && a.vol.fp) {
+        if (!a.use_ess) return launch_variant<VT, false, 0, false, false, true>(a, stream);
+        return lds ? launch_variant<VT, true, 0, true, false, true>(a, stream)
+                   : launch_variant<VT, true, 0, false, false, true>(a, stream);
+    }
     if (a.use_ess) {
         if (lds) {
             if (a.instr == 0) return xs ? launch_variant<VT, true, 0, true, true>(a, stream) : launch_variant<VT, true, 0, true, false>(a, stream);

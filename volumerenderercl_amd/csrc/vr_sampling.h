@@ -48,7 +48,31 @@ __device__ __forceinline__ unsigned long long vr_stamp()
 
 // ------------------------------------------------------------------ volume reads
 
-template <typename VT, int INSTR>
+// One entry of the footprint volume (VolView::fp): the 2x2x2 voxels of a trilinear fetch, value
+// j = dx + 2 dy + 4 dz, loaded with one 8 / 16 / 2x16-byte access.
+template <typename VT> struct FpEntry;
+template <> struct FpEntry<uint8_t> {
+    uint2 r;
+    template <int J> VR_DEV float v() const { return (float)(((J < 4 ? r.x : r.y) >> (8 * (J & 3))) & 0xffu); }
+};
+template <> struct FpEntry<uint16_t> {
+    uint4 r;
+    template <int J> VR_DEV float v() const
+    {
+        const uint32_t w = (J >> 1) == 0 ? r.x : (J >> 1) == 1 ? r.y : (J >> 1) == 2 ? r.z : r.w;
+        return (float)((J & 1) ? (w >> 16) : (w & 0xffffu));
+    }
+};
+template <> struct FpEntry<float> {
+    float4 a, b;
+    template <int J> VR_DEV float v() const
+    {
+        return J == 0 ? a.x : J == 1 ? a.y : J == 2 ? a.z : J == 3 ? a.w
+             : J == 4 ? b.x : J == 5 ? b.y : J == 6 ? b.z : b.w;
+    }
+};
+
+template <typename VT, int INSTR, bool FP = false>
 struct Vol {
     const VT *p;
     int w1, h1, d1;   // res - 1
@@ -59,6 +83,19 @@ struct Vol {
     uint32_t *touched;
     const VT *pc[3];                // channels 1..3 of CL_RG / CL_RGBA volumes (XS variants only)
     int channels;
+    const FpEntry<VT> *fp;          // FP: footprint volume (VolView::fp)
+    uint32_t fp_ystride, fp_zstride;   // entries per brick row / brick slice of it
+
+    // FP: the entry for low-corner texel (ix, iy, iz) -- any integers; what lies outside
+    // [-1, res - 1] reads the same (edge-clamped) voxels as the nearest entry inside
+    VR_DEV FpEntry<VT> entry(int ix, int iy, int iz) const
+    {
+        const uint32_t ex = (uint32_t)(iclamp(ix, -1, w1) + 1), ey = (uint32_t)(iclamp(iy, -1, h1) + 1);
+        const uint32_t ez = (uint32_t)(iclamp(iz, -1, d1) + 1);
+        const uint32_t in = __umul24(ey >> 2, fp_ystride) + ((ex >> 2) << 6) + ((ez & 3u) << 4) +
+                            ((ey & 3u) << 2) + (ex & 3u);
+        return fp[(unsigned long long)(ez >> 2) * (unsigned long long)fp_zstride + (unsigned long long)in];
+    }
 
     // this volume's channel ch >= 1 as a single-channel volume
     VR_DEV Vol channel(int ch) const
@@ -106,6 +143,16 @@ struct Vol {
         float fx = floorf(ub), fy = floorf(vb), fz = floorf(sb);
         float a = ub - fx, b = vb - fy, c = sb - fz;
         int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+        if (FP) {   // the same eight voxels and the same blend, from one load
+            const FpEntry<VT> e = entry(ix, iy, iz);
+            float c00 = lerpf(e.template v<0>(), e.template v<1>(), a);
+            float c10 = lerpf(e.template v<2>(), e.template v<3>(), a);
+            float c01 = lerpf(e.template v<4>(), e.template v<5>(), a);
+            float c11 = lerpf(e.template v<6>(), e.template v<7>(), a);
+            float c0 = lerpf(c00, c10, b);
+            float c1 = lerpf(c01, c11, b);
+            return lerpf(c0, c1, c) * inv_max;
+        }
         int x0 = iclamp(ix, 0, w1), x1 = iclamp(ix + 1, 0, w1);
         int y0 = iclamp(iy, 0, h1), y1 = iclamp(iy + 1, 0, h1);
         int z0 = iclamp(iz, 0, d1), z1 = iclamp(iz + 1, 0, d1);
@@ -156,6 +203,7 @@ struct Vol {
         float fx = floorf(ub), fy = floorf(vb), fz = floorf(sb);
         float a = ub - fx, b = vb - fy, c = sb - fz;
         int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+        if (FP) return neg_gradient_fp(ix, iy, iz, a, b, c);
         int X[4], Y[4], Z[4];
         uint32_t xo[4], yo[4];
         unsigned long long zo[4];
@@ -182,6 +230,45 @@ struct Vol {
         s2.y = lerpf(lerpf(r21, r31, b), lerpf(r22, r32, b), c) * inv_max;
         s1.z = lerpf(lerpf(r10, r20, b), lerpf(r11, r21, b), c) * inv_max;
         s2.z = lerpf(lerpf(r12, r22, b), lerpf(r13, r23, b), c) * inv_max;
+#undef VR_L
+#undef VR_R
+#undef VR_M
+#undef VR_P
+        f3 g = sub3(s2, s1);
+        f3 n = normalize3(g);
+        if (dot3(g, g) == 0.0f) n = mk3(0.57735f, 0.57735f, 0.57735f);
+        return neg3(n);
+    }
+
+    // neg_gradient() on the footprint volume: the 4x4x4 neighbourhood is the eight entries at
+    // (ix - 1 + 2i, iy - 1 + 2j, iz - 1 + 2k); texel (xi, yi, zi) of it is value
+    // (xi & 1) + 2 (yi & 1) + 4 (zi & 1) of entry (xi >> 1, yi >> 1, zi >> 1).  Same taps, same blends.
+    VR_DEV f3 neg_gradient_fp(int ix, int iy, int iz, float a, float b, float c) const
+    {
+        const FpEntry<VT> e000 = entry(ix - 1, iy - 1, iz - 1), e100 = entry(ix + 1, iy - 1, iz - 1);
+        const FpEntry<VT> e010 = entry(ix - 1, iy + 1, iz - 1), e110 = entry(ix + 1, iy + 1, iz - 1);
+        const FpEntry<VT> e001 = entry(ix - 1, iy - 1, iz + 1), e101 = entry(ix + 1, iy - 1, iz + 1);
+        const FpEntry<VT> e011 = entry(ix - 1, iy + 1, iz + 1), e111 = entry(ix + 1, iy + 1, iz + 1);
+#define VR_E(xi, yi, zi)                                                                             \
+    (((zi) >> 1) == 0 ? (((yi) >> 1) == 0 ? (((xi) >> 1) == 0 ? e000 : e100)                        \
+                                          : (((xi) >> 1) == 0 ? e010 : e110))                        \
+                      : (((yi) >> 1) == 0 ? (((xi) >> 1) == 0 ? e001 : e101)                        \
+                                          : (((xi) >> 1) == 0 ? e011 : e111)))
+#define VR_L(xi, yi, zi) VR_E(xi, yi, zi).template v<((xi) & 1) + 2 * ((yi) & 1) + 4 * ((zi) & 1)>()
+#define VR_R(yi, zi) lerpf(VR_L(1, yi, zi), VR_L(2, yi, zi), a)   /* texels (x0, x1)   */
+#define VR_M(yi, zi) lerpf(VR_L(0, yi, zi), VR_L(1, yi, zi), a)   /* texels (x0-1, x0) */
+#define VR_P(yi, zi) lerpf(VR_L(2, yi, zi), VR_L(3, yi, zi), a)   /* texels (x1, x1+1) */
+        const float r01 = VR_R(0, 1), r11 = VR_R(1, 1), r21 = VR_R(2, 1), r31 = VR_R(3, 1);
+        const float r02 = VR_R(0, 2), r12 = VR_R(1, 2), r22 = VR_R(2, 2), r32 = VR_R(3, 2);
+        const float r10 = VR_R(1, 0), r20 = VR_R(2, 0), r13 = VR_R(1, 3), r23 = VR_R(2, 3);
+        f3 s1, s2;
+        s1.x = lerpf(lerpf(VR_M(1, 1), VR_M(2, 1), b), lerpf(VR_M(1, 2), VR_M(2, 2), b), c) * inv_max;
+        s2.x = lerpf(lerpf(VR_P(1, 1), VR_P(2, 1), b), lerpf(VR_P(1, 2), VR_P(2, 2), b), c) * inv_max;
+        s1.y = lerpf(lerpf(r01, r11, b), lerpf(r02, r12, b), c) * inv_max;
+        s2.y = lerpf(lerpf(r21, r31, b), lerpf(r22, r32, b), c) * inv_max;
+        s1.z = lerpf(lerpf(r10, r20, b), lerpf(r11, r21, b), c) * inv_max;
+        s2.z = lerpf(lerpf(r12, r22, b), lerpf(r13, r23, b), c) * inv_max;
+#undef VR_E
 #undef VR_L
 #undef VR_R
 #undef VR_M
@@ -291,8 +378,8 @@ VR_DEV float tff_linear_alpha(const float4 *tff, int n, float x)
 
 // gradientCentralDiffTff (:181-206), un-negated: xyz = normalised difference of the TF opacities
 // one texel either side, w = its length.  (illumType 2 and the path tracer.)
-template <typename VT, int INSTR>
-VR_DEV float4 gradient_tff(const Vol<VT, INSTR> &vol, const float4 *s_tff, int tffn, f3 p)
+template <typename VT, int INSTR, typename V>
+VR_DEV float4 gradient_tff(const V &vol, const float4 *s_tff, int tffn, f3 p)
 {
     const f3 off = mk3(1.0f / vol.fw, 1.0f / vol.fh, 1.0f / vol.fd);
     f3 s1, s2;
