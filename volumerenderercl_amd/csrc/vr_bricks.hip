@@ -233,39 +233,41 @@ __global__ __launch_bounds__(kThreads) void vr_downsample_kernel(VolView vol, in
     }
 }
 
-// Footprint volume: one thread per entry, in memory order (coalesced 8/16/32-byte stores); the
-// eight source voxels come from at most eight micro-bricks of the volume (cached gathers).
+// Footprint volume: entries in memory order (coalesced 8/16/32-byte stores), grid-stride (a launch
+// is limited to 2^32 threads; 2048^3 has 8.6e9 entries); the eight source voxels come from at
+// most eight micro-bricks of the volume (cached gathers).
 template <typename VT>
 __global__ __launch_bounds__(kThreads) void vr_build_footprint_kernel(VolView vv)
 {
     const unsigned long long n = (unsigned long long)vv.fp_nbx * vv.fp_nby *
                                  (unsigned long long)((vv.d + 4) >> 2) * 64ull;
-    const unsigned long long i = (unsigned long long)blockIdx.x * kThreads + threadIdx.x;
-    if (i >= n) return;
-    const unsigned long long brick = i >> 6;
-    const int in = (int)(i & 63ull);
-    const int bx = (int)(brick % vv.fp_nbx), by = (int)((brick / vv.fp_nbx) % vv.fp_nby);
-    const int bz = (int)(brick / ((unsigned long long)vv.fp_nbx * vv.fp_nby));
-    const int ex = bx * 4 + (in & 3), ey = by * 4 + ((in >> 2) & 3), ez = bz * 4 + (in >> 4);
+    const unsigned long long stride = (unsigned long long)gridDim.x * kThreads;
     const VT *p = (const VT *)vv.data;
-    VT e[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int x = min(max(ex - 1 + (j & 1), 0), vv.w - 1);
-        const int y = min(max(ey - 1 + ((j >> 1) & 1), 0), vv.h - 1);
-        const int z = min(max(ez - 1 + (j >> 2), 0), vv.d - 1);
-        e[j] = p[vr_voxel_index(vv, x, y, z)];
-    }
     VT *out = (VT *)const_cast<void *>(vv.fp);
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+        const unsigned long long brick = i >> 6;
+        const int in = (int)(i & 63ull);
+        const int bx = (int)(brick % vv.fp_nbx), by = (int)((brick / vv.fp_nbx) % vv.fp_nby);
+        const int bz = (int)(brick / ((unsigned long long)vv.fp_nbx * vv.fp_nby));
+        const int ex = bx * 4 + (in & 3), ey = by * 4 + ((in >> 2) & 3), ez = bz * 4 + (in >> 4);
+        VT e[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) out[i * 8ull + j] = e[j];
+        for (int j = 0; j < 8; ++j) {
+            const int x = min(max(ex - 1 + (j & 1), 0), vv.w - 1);
+            const int y = min(max(ey - 1 + ((j >> 1) & 1), 0), vv.h - 1);
+            const int z = min(max(ez - 1 + (j >> 2), 0), vv.d - 1);
+            e[j] = p[vr_voxel_index(vv, x, y, z)];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[i * 8ull + j] = e[j];
+    }
 }
 
 hipError_t vr_launch_build_footprint(const VolView &vol, int format, hipStream_t stream)
 {
     const unsigned long long n = (unsigned long long)vol.fp_nbx * vol.fp_nby *
                                  (unsigned long long)((vol.d + 4) >> 2) * 64ull;
-    dim3 grid((unsigned)((n + kThreads - 1) / kThreads)), block(kThreads);
+    dim3 grid((unsigned)std::min<unsigned long long>((n + kThreads - 1) / kThreads, 1ull << 22)), block(kThreads);
     switch (format) {
     case VRHIP_UCHAR:
         hipLaunchKernelGGL(vr_build_footprint_kernel<uint8_t>, grid, block, 0, stream, vol);

@@ -395,10 +395,9 @@ int ensure_hit_images(vrhip_renderer *r, uint32_t w, uint32_t h)
 }
 
 // Footprint volume of the current time step (VolView::fp, DESIGN.md "Footprint volume"): 8x the
-// volume's bytes, so that a trilinear fetch is one load.  Measured: -3..-8 % frame time for every
-// footprint volume up to 32 GiB (1536^3 UCHAR, 1024^3 FLOAT), at any viewport; from 34 GiB on
-// (1664^3 UCHAR) the pass is 7x SLOWER -- a cliff, same pixels -- so larger volumes keep the plain
-// layout.  Built on first use, kept until the volume or the time step changes.
+// volume's bytes, so that a trilinear fetch is one load.  Measured: -8 % frame time at 256^3,
+// -5 % at 1024^3 UCHAR, -3 % around 30 GB (1536^3 UCHAR, 1024^3 FLOAT), nothing at 2048^3 (69 GB),
+// hence the cap.  Built on first use, kept until the volume or the time step changes.
 int ensure_footprint(vrhip_renderer *r)
 {
     r->fp_active = false;
