@@ -212,8 +212,8 @@ __global__ __launch_bounds__(kThreads) void vr_downsample_kernel(VolView vol, in
                                                                  int vx, int vy, int vz, VT *out)
 {
     const size_t n = (size_t)lx * ly * lz;
-    const size_t o = (size_t)blockIdx.x * kThreads + threadIdx.x;
-    if (o >= n) return;
+    // grid-stride: a launch cannot have more than 2^32 threads
+    for (size_t o = (size_t)blockIdx.x * kThreads + threadIdx.x; o < n; o += (size_t)gridDim.x * kThreads) {
     const int cx = (int)(o % (size_t)lx), cy = (int)((o / (size_t)lx) % (size_t)ly);
     const int cz = (int)(o / ((size_t)lx * ly));
     const int x0 = vx * cx, y0 = vy * cy, z0 = vz * cz;
@@ -230,6 +230,7 @@ __global__ __launch_bounds__(kThreads) void vr_downsample_kernel(VolView vol, in
         const float top = sizeof(VT) == 1 ? 255.0f : 65535.0f;
         const float q = rintf(fminf(fmaxf(value * top, 0.f), top));   // convert_*_sat_rte
         out[o] = (VT)q;
+    }
     }
 }
 
@@ -287,7 +288,7 @@ hipError_t vr_launch_downsample(const VolView &vol, int format, const int lo[3],
                                 void *out, hipStream_t stream)
 {
     const size_t n = (size_t)lo[0] * lo[1] * lo[2];
-    dim3 grid((unsigned)((n + kThreads - 1) / kThreads)), block(kThreads);
+    dim3 grid((unsigned)std::min<size_t>((n + kThreads - 1) / kThreads, (size_t)1 << 22)), block(kThreads);
     switch (format) {
     case VRHIP_UCHAR:
         hipLaunchKernelGGL(vr_downsample_kernel<uint8_t>, grid, block, 0, stream, vol, lo[0], lo[1], lo[2],
