@@ -64,3 +64,15 @@ def test_product_never_touches_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "vr_oracle" not in text and "from oracle" not in text and \
                     "import oracle" not in text and "libvroracle" not in text, os.path.join(dirpath, f)
+
+
+def test_host_library_exports_every_declared_symbol():
+    """libvrhost.so (loader, .hdr decoder) exports what include/vrhost.h declares."""
+    text = open(os.path.join(ROOT, "include", "vrhost.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(vr(?:dr|host)_[a-z_0-9]+)\s*\(", text)))
+    assert "vrhost_load_hdr" in names and "vrdr_load" in names
+    _lib.load()   # libvrhost links against libvrhip
+    host = C.CDLL(os.path.join(ROOT, "volumerenderercl_amd", "libvrhost.so"))
+    for name in names:
+        assert hasattr(host, name), name
