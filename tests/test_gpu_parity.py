@@ -571,6 +571,22 @@ def test_cpp_host_downsampling_writes_dat_raw(tmp_path):
     rd = datraw.DatRawReader()
     rd.read_files(datraw.Properties(base + ".dat"))
     np.testing.assert_array_equal(rd.data()[0].reshape(-1), ref.reshape(-1))
+    # the Python twin of the class writes the same two files, byte for byte
+    cpp_dat, cpp_raw = open(base + ".dat", "rb").read(), open(base + ".raw", "rb").read()
+    os.remove(base + ".dat")
+    os.remove(base + ".raw")
+    r = VolumeRenderCL()
+    r.initialize()
+    try:
+        r.loadVolumeData(datraw.Properties(str(tmp_path / "v.dat")))
+        assert r.volumeDownsampling(0, 2) == base
+        with pytest.raises(ValueError):
+            r.volumeDownsampling(0, 1)
+        assert r.getPlatformNames() == ["AMD HIP (ROCm)"]
+        assert r.getDeviceNames(0, "GPU") == [r.getCurrentDeviceName()] and r.getDeviceNames(0, "CPU") == []
+    finally:
+        r.close()
+    assert open(base + ".dat", "rb").read() == cpp_dat and open(base + ".raw", "rb").read() == cpp_raw
 
 
 def test_cpp_host_cli_reads_gui_state_and_tff(tmp_path):

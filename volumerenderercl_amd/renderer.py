@@ -110,6 +110,14 @@ class VolumeRenderCL:
         self._check(self._lib.vrhip_set_stream(self._h, C.c_void_p(stream_ptr),
                                                1 if use_own else 0))
 
+    def getPlatformNames(self):
+        """volumerendercl.cpp:1062-1079 (OpenCL platforms): there is one, the HIP runtime."""
+        return ["AMD HIP (ROCm)"]
+
+    def getDeviceNames(self, platformId=0, type="GPU"):
+        """volumerendercl.cpp:1087-1108: the devices of a platform by type; no CPU device here."""
+        return [] if type == "CPU" else [self.getCurrentDeviceName()]
+
     def getCurrentDeviceName(self):
         buf = C.create_string_buffer(256)
         self._check(self._lib.vrhip_device_name(self._h, buf, 256))
@@ -211,6 +219,7 @@ class VolumeRenderCL:
         p = reader.properties()
         vols = reader.data()
         self._histograms = reader.histograms()
+        self._props = p
         co = p.image_channel_order
         if co in ("R", "", "I", "LUMINANCE"):
             channels = 1
@@ -270,6 +279,31 @@ class VolumeRenderCL:
         self._check(self._lib.vrhip_downsample_volume(self._h, int(t), int(factor),
                                                       out.ctypes.data_as(C.c_void_p), out.nbytes, lo))
         return out
+
+    def volumeDownsampling(self, t, factor):
+        """volumerendercl.cpp:238-341: down-sample time step t on the GPU and write
+        <dat name>_<N>.raw / .dat next to the loaded .dat (the reference's text, quirks included:
+        `Format:` carries the enum's integer, `ObjectFileName:` is cut with substr(first + 1,
+        lastindex)).  Returns the path without extension."""
+        props = getattr(self, "_props", None)
+        if not self._vol_loaded or props is None or not props.dat_file_name:
+            raise RuntimeError("No volume data is loaded.")
+        if factor < 2:
+            raise ValueError("Factor must be greater or equal 2.")
+        low = self.downsampleVolume(t, factor)
+        name = props.dat_file_name
+        dot = name.rfind(".")
+        rawname = (name[:dot] if dot >= 0 else name) + "_" + str(low.shape[2])
+        low.tofile(rawname + ".raw")
+        last = rawname.rfind(".")
+        first = max(rawname.rfind("/"), rawname.rfind("\\"))
+        short = rawname[first + 1:] if last < 0 else rawname[first + 1:first + 1 + last]
+        with open(rawname + ".dat", "w") as f:
+            f.write("ObjectFileName: \t%s.raw\n" % short)
+            f.write("Resolution: \t\t%d %d %d\n" % (low.shape[2], low.shape[1], low.shape[0]))
+            f.write("SliceThickness: \t%g %g %g\n" % tuple(props.slice_thickness[:3]))
+            f.write("Format: \t\t\t%d\n" % int(props.format))
+        return rawname
 
     def downloadVolume(self, t=0):
         out = np.empty((self._res[2], self._res[1], self._res[0]), dtype=NP_DTYPE[self._format])
