@@ -1011,3 +1011,34 @@ def test_time_series_steps_match_oracle(vr):
     again = vr.runRaycastNoGL(W, H)
     vr.setIteration(0)
     assert np.array_equal(again, frames[2])
+
+
+@pytest.mark.parametrize("kind,fmt", [("shells", UCHAR), ("sphere", USHORT)])
+def test_midsize_synthetic_volume_matches_oracle(vr, kind, fmt):
+    """256^3 synthetic fields (SURVEY 8d formulas, generated on the GPU and by the oracle): brick
+    edge 4, many micro-brick rows, the cell grid at 32^3 cells, the footprint volume with 65^3
+    micro-bricks of entries -- instrumented and default kernels against the oracle."""
+    res = (256, 256, 256)
+    vol = vro.synth_volume(kind, list(res), fmt)
+    tff = common.tffs()["default"]
+    W, H = 176, 144
+    vr.synthVolume(kind, res, fmt)
+    np.testing.assert_array_equal(vr.downloadVolume(0), vol)
+    vr.setTransferFunction(tff)
+    vr.setSeed(SEED)
+    for name, val in (("setIllumination", 1), ("setLinearInterpolation", True), ("setCamOrtho", False),
+                      ("setUseGradient", False), ("setContours", False), ("setAerial", False),
+                      ("setObjEss", True), ("setAmbientOcclusion", False), ("setTechnique", 0),
+                      ("setShowESS", False), ("setImgEss", False)):
+        getattr(vr, name)(val)
+    vr.updateSamplingRate(1.5)
+    vr.setBBox(-1, -1, -1, 1, 1, 1)
+    vr.params()[1].backgroundColor[:] = [1.0, 1.0, 1.0, 1.0]
+    vr.updateView(common.views()["rot30"])
+    vr.setIteration(0)
+    got, ref, stats = _compare(vr, vol, fmt, tff, W, H)
+    assert stats["bricks_skipped"] > 0 and stats["samples_shaded"] > 0
+    vr.setStatsEnabled(False)
+    plain = vr.runRaycastNoGL(W, H)
+    vr.setIteration(0)
+    assert np.array_equal(plain, got)
