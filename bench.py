@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--workload", default="shells2048", choices=sorted(WORKLOADS))
     ap.add_argument("--viewport", type=int, default=1024)
     ap.add_argument("--tile", type=int, default=64, help="tile edge for the multi-GPU split")
+    ap.add_argument("--frames-per-gather", type=int, default=4,
+                    help="multi-GPU: independent frames per RCCL gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="target CPU work for the bounded cpu_baseline sample")
@@ -184,17 +186,17 @@ def main():
 
     split = vtiles.TileSplit(W, H, args.tile, args.tile, world, rank)
     frame = torch.empty((H, W, 4), dtype=torch.float32, device=dev) if rank == 0 else None
-    driver = vtiles.TileDriver(vr, split, dev)
+    # world > 1: `--frames-per-gather` independent frames share one collective (fewer, larger
+    # gathers: the host-side cost of a collective is comparable to a rank's rendering time)
+    fpg = max(1, min(args.frames_per_gather, args.steps))
+    driver = vtiles.TileDriver(vr, split, dev, batch=fpg)
+    frames = (torch.empty((fpg, H, W, 4), dtype=torch.float32, device=dev)
+              if rank == 0 and world > 1 else None)
 
     def render(seed, k=0):
         vr.setSeed(seed)
         vr.setIteration(k if technique == 1 else 0)   # path tracer: progressive running mean
         return driver.render_frame(frame)
-
-    def submit(seed, k=0):   # world > 1: render my tiles of the frame and start its gather
-        vr.setSeed(seed)
-        vr.setIteration(k if technique == 1 else 0)
-        driver.submit()
 
     for k in range(args.warmup):
         render(seeds[k])
@@ -209,12 +211,21 @@ def main():
         for k in range(args.steps):
             render(seeds[args.warmup + k], k)
     else:
-        # one frame in flight: the gather + assembly of frame k overlap the rendering of k + 1
-        submit(seeds[args.warmup], 0)
-        for k in range(1, args.steps):
-            submit(seeds[args.warmup + k], k)
-            driver.collect(frame)
-        driver.collect(frame)
+        # one gather in flight: the gather + assembly of a batch of frames overlap the rendering
+        # of the next batch
+        chunks = [list(range(c0, min(c0 + fpg, args.steps))) for c0 in range(0, args.steps, fpg)]
+
+        def submit_chunk(chunk):
+            def before(i):
+                vr.setSeed(seeds[args.warmup + chunk[i]])
+                vr.setIteration(chunk[i] if technique == 1 else 0)
+            driver.submit_batch(len(chunk), before)
+
+        submit_chunk(chunks[0])
+        for chunk in chunks[1:]:
+            submit_chunk(chunk)
+            driver.collect_batch(frames)
+        driver.collect_batch(frames)
     ev1.record(stream)
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -325,8 +336,9 @@ def main():
                                H + (8 - H % 8), args.view, tff_name, illum, "on" if ess else "off")
                             + (" -- technique 1 (path tracer, max_extinction 100): illumType/ESS/ERT/"
                                "samplingRate unused" if technique == 1 else ""),
-                "parallelism": "tiles%dx%d/%d ranks, volume replicated, RCCL gather (one frame in flight)" % (
-                    args.tile, args.tile, world) if world > 1 else "single GPU, full frame",
+                "parallelism": "tiles%dx%d/%d ranks, volume replicated, one RCCL gather per %d frames "
+                               "(one gather in flight)" % (args.tile, args.tile, world, fpg)
+                               if world > 1 else "single GPU, full frame",
             },
             "msamples_nominal_per_s": work["samples_nominal"] / wall / 1e6,
             "work_per_frame": {k: v // args.steps for k, v in work.items()},

@@ -31,6 +31,9 @@ def _scene():
     return vol, frontend.tff_from_stops(), cam, rp, rc
 
 
+BATCH_SEEDS = [11, 22222, 3333333, 44, 555]
+
+
 def _worker(rank, world, port, W, H, T, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -59,10 +62,27 @@ def _worker(rank, world, port, W, H, T, q):
         o = drv.collect(frame)
         if rank == 0:
             outs.append(o.numpy().copy())
+    # batched: up to 3 independent frames (their own jitter seeds) per gather, one gather in flight
+    drvb = tiles.TileDriver(None, split, torch.device("cpu"), render_tiles_fn=render_tiles, dist=dist,
+                            batch=3)
+    frames = torch.zeros((3, H, W, 4)) if rank == 0 else None
+    batched = []
+
+    def before(chunk):
+        def set_seed(i):
+            rp.seed = BATCH_SEEDS[chunk[i]]
+        return set_seed
+
+    drvb.submit_batch(3, before([0, 1, 2]))
+    drvb.submit_batch(2, before([3, 4]))
+    for n in (3, 2):
+        o = drvb.collect_batch(frames)
+        if rank == 0:
+            batched += [o[i].numpy().copy() for i in range(n)]
     if rank == 0:
         for o in outs:
             np.testing.assert_array_equal(o, first)
-        q.put(first)
+        q.put((first, batched))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -85,11 +105,16 @@ def test_gloo_tile_gather_matches_single_rank(world, W, H, T):
     procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, T, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get(timeout=240)
+    got, batched = q.get(timeout=240)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
     np.testing.assert_array_equal(got, ref)
+    assert len(batched) == len(BATCH_SEEDS)
+    for seed, frame in zip(BATCH_SEEDS, batched):
+        rp.seed = seed
+        want, _, _ = vro.render_tile(vol, vro.UCHAR, tff, cam, rp, rc, W=W, H=H)
+        np.testing.assert_array_equal(frame, want)
 
 
 def _worker_img_ess(rank, world, port, W, H, T, q):

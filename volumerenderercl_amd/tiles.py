@@ -48,11 +48,15 @@ class TileDriver:
         frame into one of two buffers and starts the gather asynchronously (RCCL runs it on its
         own stream), collect() waits for the oldest gather in flight and assembles that frame
         on rank 0.  With one frame in flight the gather + assembly of frame k overlap the
-        rendering of frame k + 1, so the frame rate is set by the slower of the two, not their sum.
+        rendering of frame k + 1, so the frame rate is set by the slower of the two, not their sum;
+      * submit_batch(n, before_frame) / collect_batch(frames): the same with `n` <= `batch`
+        independent frames per collective (one gather and one assembly for all of them): at a few
+        hundred microseconds of GPU work per rank and frame the host-side cost of a collective is
+        as long as the rendering, so fewer, larger collectives keep the GPUs busy.
     """
 
     def __init__(self, vr, split, device, render_tiles_fn=None, dist=None, image_ess=False,
-                 hit_io=None):
+                 hit_io=None, batch=1):
         import torch
         self.torch = torch
         self.vr, self.split, self.device = vr, split, device
@@ -76,45 +80,82 @@ class TileDriver:
         if dist is None and s.world > 1:
             import torch.distributed as dist
         self.dist = dist
-        self.pending = []          # (buffer index, work handle) of the gathers in flight
+        self.pending = []          # (buffer index, frames, work handle) of the gathers in flight
         self.next_buf = 0
+        self.batch = B = max(1, int(batch))
         if s.world > 1:
-            self.local = [torch.zeros((s.cap, s.th, s.tw, 4), dtype=torch.float32, device=device)
+            # [frame of the batch, slot, th, tw, 4]
+            self.local = [torch.zeros((B, s.cap, s.th, s.tw, 4), dtype=torch.float32, device=device)
                           for _ in range(2)]
             if s.rank == 0:
-                # one block per buffer: [rank, slot, th, tw, 4]; the gather writes rank r's
+                # one block per buffer: [rank, frame, slot, th, tw, 4]; the gather writes rank r's
                 # tiles into staging[b][r]
-                self.staging = [torch.zeros((s.world, s.cap, s.th, s.tw, 4), dtype=torch.float32,
+                self.staging = [torch.zeros((s.world, B, s.cap, s.th, s.tw, 4), dtype=torch.float32,
                                             device=device) for _ in range(2)]
-                # tile id -> row of staging.view(world * cap, ...)
-                perm = np.zeros(s.n_tiles, dtype=np.int64)
-                for r in range(s.world):
-                    perm[s.tiles_of[r].astype(np.int64)] = r * s.cap + np.arange(len(s.tiles_of[r]))
+                # (frame f, tile id) -> row of staging.view(world * B * cap, ...)
+                perm = np.zeros((B, s.n_tiles), dtype=np.int64)
+                for f in range(B):
+                    for r in range(s.world):
+                        perm[f, s.tiles_of[r].astype(np.int64)] = (
+                            (r * B + f) * s.cap + np.arange(len(s.tiles_of[r])))
                 self.perm = torch.as_tensor(perm, device=device)
                 self.exact = (s.W % s.tw == 0) and (s.H % s.th == 0)
                 if not self.exact:
-                    self.padded = torch.zeros((s.tiles_y * s.th, s.tiles_x * s.tw, 4),
+                    self.padded = torch.zeros((B, s.tiles_y * s.th, s.tiles_x * s.tw, 4),
                                               dtype=torch.float32, device=device)
 
     # ---- pipelined interface
     def submit(self):
         """Render this rank's tiles of the next frame and start its gather (world > 1)."""
+        self.submit_batch(1)
+
+    def submit_batch(self, n, before_frame=None):
+        """Render this rank's tiles of the next `n` <= batch frames -- `before_frame(i)` is called
+        ahead of frame i (jitter seed, iteration, ...) -- and start ONE gather for all of them."""
         s = self.split
         if s.world == 1:
             raise RuntimeError("submit/collect are for world > 1; use render_frame")
+        if not 1 <= n <= self.batch:
+            raise ValueError("1 <= n <= batch (%d) frames per gather" % self.batch)
         if len(self.pending) >= 2:
-            raise RuntimeError("two frames already in flight: collect() first")
+            raise RuntimeError("two gathers already in flight: collect first")
         b = self.next_buf
         self.next_buf ^= 1
-        if self.render_tiles_fn is None:
-            self.vr.render_tiles(s.W, s.H, s.tw, s.th, s.my_tiles, self.local[b].data_ptr())
-        else:
-            self.render_tiles_fn(s.my_tiles, self.local[b])
+        for i in range(n):
+            if before_frame is not None:
+                before_frame(i)
+            if self.render_tiles_fn is None:
+                self.vr.render_tiles(s.W, s.H, s.tw, s.th, s.my_tiles, self.local[b][i].data_ptr())
+            else:
+                self.render_tiles_fn(s.my_tiles, self.local[b][i])
+            if self.hit_io is not None:
+                self.merge_hit_image()      # the next frame reads the merged hit image
         glist = [self.staging[b][r] for r in range(s.world)] if s.rank == 0 else None
         work = self.dist.gather(self.local[b], glist, dst=0, async_op=True)
-        self.pending.append((b, work))
-        if self.hit_io is not None:
-            self.merge_hit_image()
+        self.pending.append((b, n, work))
+
+    def collect(self, frame):
+        """Finish the oldest frame in flight; returns the assembled frame on rank 0."""
+        out = self.collect_batch(None if frame is None else frame.unsqueeze(0))
+        return None if out is None else frame
+
+    def collect_batch(self, frames):
+        """Finish the oldest gather in flight; on rank 0 `frames` ([>= n, H, W, 4]) receives its n
+        assembled frames (one index_select + one strided copy for the whole batch)."""
+        s = self.split
+        b, n, work = self.pending.pop(0)
+        work.wait()
+        if s.rank != 0:
+            return None
+        rows = self.staging[b].view(s.world * self.batch * s.cap, s.th, s.tw, 4)
+        tiles_sorted = rows.index_select(0, self.perm[:n].reshape(-1))
+        tv = tiles_sorted.view(n, s.tiles_y, s.tiles_x, s.th, s.tw, 4).permute(0, 1, 3, 2, 4, 5)
+        if self.exact:
+            frames[:n].view(n, s.tiles_y, s.th, s.tiles_x, s.tw, 4).copy_(tv)
+        else:
+            self.padded[:n].view(n, s.tiles_y, s.th, s.tiles_x, s.tw, 4).copy_(tv)
+            frames[:n].copy_(self.padded[:n, : s.H, : s.W])
+        return frames
 
     def merge_hit_image(self):
         """Image-order ESS: give every rank the hit texels the tile owners produced this frame.
@@ -126,22 +167,6 @@ class TileDriver:
         merged = np.where(self.hit_owned_by_any, mine.cpu().numpy().astype(np.uint8), hit)
         put(merged)
         return merged
-
-    def collect(self, frame):
-        """Finish the oldest frame in flight; returns the assembled frame on rank 0."""
-        s = self.split
-        b, work = self.pending.pop(0)
-        work.wait()
-        if s.rank != 0:
-            return None
-        tiles_sorted = self.staging[b].view(s.world * s.cap, s.th, s.tw, 4).index_select(0, self.perm)
-        tv = tiles_sorted.view(s.tiles_y, s.tiles_x, s.th, s.tw, 4).permute(0, 2, 1, 3, 4)
-        if self.exact:
-            frame.view(s.tiles_y, s.th, s.tiles_x, s.tw, 4).copy_(tv)
-        else:
-            self.padded.view(s.tiles_y, s.th, s.tiles_x, s.tw, 4).copy_(tv)
-            frame.copy_(self.padded[: s.H, : s.W])
-        return frame
 
     # ---- one synchronous frame
     def render_frame(self, frame):
