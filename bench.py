@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--tile", type=int, default=64, help="tile edge for the multi-GPU split")
     ap.add_argument("--frames-per-gather", type=int, default=4,
                     help="multi-GPU: independent frames per RCCL gather")
+    ap.add_argument("--frames-in-flight", type=int, default=2,
+                    help="single GPU: renderers (one stream each, sharing the volume) that alternate "
+                         "frames, so that the tail of one frame overlaps the head of the next")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="target CPU work for the bounded cpu_baseline sample")
@@ -198,8 +201,27 @@ def main():
         vr.setIteration(k if technique == 1 else 0)   # path tracer: progressive running mean
         return driver.render_frame(frame)
 
+    # Frames in flight (single GPU; the path tracer's running mean chains its frames, so it keeps
+    # one): the extra renderers share the first one's voxels and bricks (vrhip_share_volumes) and
+    # own a stream, a frame buffer and scratch each.
+    fif = max(1, args.frames_in_flight) if (world == 1 and technique == 0) else 1
+    lanes = [(vr, stream, frame)]
+    for _ in range(fif - 1):
+        s2 = torch.cuda.Stream(dev)
+        twin = vr.shareVolumes()
+        twin.set_stream(s2.cuda_stream)
+        lanes.append((twin, s2, torch.empty((H, W, 4), dtype=torch.float32, device=dev)))
+
+    def render_lane(seed, k):
+        r, _, out = lanes[k % fif]
+        r.setSeed(seed)
+        r.setIteration(0)
+        r.runRaycast(W, H, out_dev_ptr=out.data_ptr())
+
     for k in range(args.warmup):
         render(seeds[k])
+    for k in range(fif if fif > 1 else 0):   # every lane once: buffers, skip bitmap, cell grid
+        render_lane(seeds[0], k)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -207,7 +229,12 @@ def main():
     ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(stream)
-    if world == 1:
+    for _, s2, _ in lanes[1:]:
+        s2.wait_event(ev0)
+    if world == 1 and fif > 1:
+        for k in range(args.steps):
+            render_lane(seeds[args.warmup + k], k)
+    elif world == 1:
         for k in range(args.steps):
             render(seeds[args.warmup + k], k)
     else:
@@ -226,6 +253,8 @@ def main():
             submit_chunk(chunk)
             driver.collect_batch(frames)
         driver.collect_batch(frames)
+    for _, s2, _ in lanes[1:]:
+        stream.wait_stream(s2)       # the region ends when every lane's last frame has
     ev1.record(stream)
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -238,6 +267,19 @@ def main():
     if world > 1:
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
     wall = float(wall_t.item())
+
+    # ---- untimed: the same frames one at a time (what one launch takes when it has the GPU to itself)
+    serial_s = None
+    if world == 1 and fif > 1:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for k in range(args.steps):
+            render(seeds[args.warmup + k], k)
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+        serial_s = e0.elapsed_time(e1) * 1e-3 / args.steps
+        last_kernel_s = vr.getLastExecTime()
+        last_phases = vr.getLastPhaseTimes()
 
     # ---- untimed: exact work counters of the K timed frames (instrumented kernel variant)
     vr.setStatsEnabled(True)
@@ -295,6 +337,13 @@ def main():
                                if traffic else None),
             "algorithmic_bytes_per_launch": int(alg_bytes),
             "avg_launch_ms": kernel_s * 1e3,
+            "frames_in_flight": fif,
+            "serial_launch_ms": serial_s * 1e3 if serial_s else None,
+            "launch_note": ("%d renderers on %d streams alternate frames over one shared volume: avg_launch_ms "
+                            "= HIP-event time of the timed region / frames (launches of consecutive frames "
+                            "overlap); serial_launch_ms = the same frames one at a time, which is what a "
+                            "rocprofv3 kernel trace of `--frames-in-flight 1` sums to" % (fif, fif))
+                           if fif > 1 else "one frame at a time",
             "last_pass_ms_hip_events": {"phase1": last_phases[0] * 1e3, "phase2": last_phases[1] * 1e3,
                                         "total": last_kernel_s * 1e3},
             "request_bytes_per_launch": int(b * 8 * (st1["samples_taken"] +
@@ -338,7 +387,7 @@ def main():
                                "samplingRate unused" if technique == 1 else ""),
                 "parallelism": "tiles%dx%d/%d ranks, volume replicated, one RCCL gather per %d frames "
                                "(one gather in flight)" % (args.tile, args.tile, world, fpg)
-                               if world > 1 else "single GPU, full frame",
+                               if world > 1 else "single GPU, full frames, %d in flight" % fif,
             },
             "msamples_nominal_per_s": work["samples_nominal"] / wall / 1e6,
             "work_per_frame": {k: v // args.steps for k, v in work.items()},

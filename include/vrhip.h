@@ -126,6 +126,13 @@ int vrhip_download_volume(vrhip_renderer *r, uint32_t timestep, void *host_dst, 
  * greater or equal 2."); low-res x size < 64 -> VRHIP_ERR_INVALID (the reference's minimum). */
 int vrhip_downsample_volume(vrhip_renderer *r, uint32_t timestep, int factor, void *host_dst,
                             size_t bytes, uint32_t out_res[3]);
+/* Frames in flight: renderer `r` (same device) renders from `owner`'s voxels and ESS bricks
+ * instead of holding copies -- everything else (transfer function, parameters, frame and scratch
+ * buffers, footprint volume, stream) is its own, so two renderers on two streams can
+ * have one frame each in flight over one 8 GiB volume.  The owner must keep its volumes (no upload,
+ * clear or destroy) while they are shared; `r` gives them back with vrhip_clear_volumes or by
+ * uploading its own.  vrhip_build_bricks on `r` keeps the shared bricks. */
+int vrhip_share_volumes(vrhip_renderer *r, vrhip_renderer *owner);
 int vrhip_clear_volumes(vrhip_renderer *r);
 /* setTimestep (volumerendercl.cpp:1167-1174) */
 int vrhip_set_timestep(vrhip_renderer *r, uint32_t timestep);

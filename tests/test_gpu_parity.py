@@ -1042,3 +1042,52 @@ def test_midsize_synthetic_volume_matches_oracle(vr, kind, fmt):
     plain = vr.runRaycastNoGL(W, H)
     vr.setIteration(0)
     assert np.array_equal(plain, got)
+
+
+def test_shared_volume_twin_renders_the_same_frames(vr):
+    """vrhip_share_volumes / VolumeRenderCL.shareVolumes: a second renderer on its own stream
+    renders from the first one's voxels and bricks; frames of both equal the oracle's, also when
+    they are in flight together, and the owner is untouched when the twin goes away."""
+    import torch
+    vol = common.noise_volume((56, 48, 40), USHORT, seed=17, smooth=False)
+    tff = common.tffs()["default"]
+    W, H = 96, 72
+    _setup(vr, vol, USHORT, tff, common.views()["rot30"])
+    vr.setStatsEnabled(False)
+    twin = vr.shareVolumes()
+    s2 = torch.cuda.Stream()
+    twin.set_stream(s2.cuda_stream)
+    try:
+        seeds = [SEED, 581869302, 3890346734, 3586334585]
+        outs = [torch.empty((H, W, 4), dtype=torch.float32, device="cuda") for _ in seeds]
+        for k, seed in enumerate(seeds):            # alternate: two frames in flight at a time
+            r = (vr, twin)[k % 2]
+            r.setSeed(seed)
+            r.setIteration(0)
+            r.runRaycast(W, H, out_dev_ptr=outs[k].data_ptr())
+        torch.cuda.synchronize()
+        cam, rp, rc, pt = common.to_oracle_params(*vr.params())
+        for k, seed in enumerate(seeds):
+            rp.seed, rp.iteration = seed, 0
+            ref, _, _ = vro.render_tile(vol, USHORT, tff, cam, rp, rc, pt, W=W, H=H)
+            assert np.abs(outs[k].cpu().numpy() - ref).max() <= TOL, "frame %d" % k
+        # the twin has its own transfer function and parameters
+        twin.setTransferFunction(common.tffs()["opaque"])
+        twin.setIllumination(0)
+        twin.setSeed(SEED)
+        twin.setIteration(0)
+        got = twin.runRaycastNoGL(W, H)
+        cam, rp, rc, pt = common.to_oracle_params(*twin.params())   # (after the render: its seed)
+        rp.iteration = 0
+        ref, _, _ = vro.render_tile(vol, USHORT, common.tffs()["opaque"], cam, rp, rc, pt, W=W, H=H)
+        assert np.abs(got - ref).max() <= TOL
+        with pytest.raises(ValueError):
+            twin.shareVolumes()                     # only an owner can share
+    finally:
+        twin.close()
+    vr.setSeed(SEED)
+    vr.setIteration(0)
+    again = vr.runRaycastNoGL(W, H)
+    vr.setIteration(0)
+    ref, _, _ = common.oracle_frame(vr, vol, USHORT, tff, W, H)
+    assert np.abs(again - ref).max() <= TOL

@@ -21,6 +21,7 @@ struct VolumeSlot {
     void *bricks = nullptr;   // (min,max) grid
     float2 *pt_minmax = nullptr;   // path tracer: per-cell (min,max) incl. halo, built on demand
     bool pt_minmax_valid = false;
+    bool borrowed = false;    // dev / chan / bricks belong to another renderer (vrhip_share_volumes)
 };
 
 std::string g_create_error;
@@ -298,6 +299,7 @@ int prepare_slot(vrhip_renderer *r, const uint32_t res[3], int format, uint32_t 
                "Volume resolution above 8192 per axis is not supported.");
     bool same = r->format == format && r->res[0] == res[0] && r->res[1] == res[1] &&
                 r->res[2] == res[2] && r->channels == channels;
+    for (const VolumeSlot &vs : r->vols) same = same && !vs.borrowed;   // never write into shared voxels
     if (!same) {
         VR_REQUIRE(r, timestep == 0 || r->vols.empty(), VRHIP_ERR_INVALID,
                    "Volume size does not match size of the other time steps.");
@@ -942,14 +944,17 @@ int vrhip_clear_volumes(vrhip_renderer *r)
     (void)hipSetDevice(r->device);
     (void)hipStreamSynchronize(r->stream);
     for (VolumeSlot &s : r->vols) {
-        if (s.dev) (void)hipFree(s.dev);
-        for (void *c : s.chan)
-            if (c) (void)hipFree(c);
-        if (s.bricks) (void)hipFree(s.bricks);
+        if (!s.borrowed) {
+            if (s.dev) (void)hipFree(s.dev);
+            for (void *c : s.chan)
+                if (c) (void)hipFree(c);
+            if (s.bricks) (void)hipFree(s.bricks);
+        }
         if (s.pt_minmax) (void)hipFree(s.pt_minmax);
     }
     r->vols.clear();
     r->fp_valid = false;
+
     r->bricks_valid = false;
     r->skip_dirty = true;
     r->pt_dirty = true;
@@ -957,6 +962,47 @@ int vrhip_clear_volumes(vrhip_renderer *r)
     r->channels = 1;
     r->res[0] = r->res[1] = r->res[2] = 0;
     r->timestep = 0;
+    return VRHIP_OK;
+}
+
+int vrhip_share_volumes(vrhip_renderer *r, vrhip_renderer *owner)
+{
+    if (!r || !owner || r == owner) return VRHIP_ERR_INVALID;
+    VR_REQUIRE(r, r->device == owner->device, VRHIP_ERR_INVALID,
+               "vrhip_share_volumes: both renderers must live on the same device.");
+    VR_REQUIRE(r, !owner->vols.empty(), VRHIP_ERR_NODATA, "No volume data is loaded.");
+    for (const VolumeSlot &s : owner->vols)
+        VR_REQUIRE(r, s.dev && !s.borrowed, VRHIP_ERR_INVALID,
+                   "vrhip_share_volumes: the owner must hold its own, complete volumes.");
+    int rc = vrhip_clear_volumes(r);
+    if (rc) return rc;
+    // what the owner has written must be complete before this renderer's stream reads it
+    if (hipStreamSynchronize(owner->stream) != hipSuccess)
+        return fail(r, VRHIP_ERR_HIP, "ERROR: vrhip_share_volumes (stream synchronize)");
+    std::memcpy(r->res, owner->res, sizeof r->res);
+    r->format = owner->format;
+    r->channels = owner->channels;
+    set_layout(r);
+    for (int i = 0; i < 3; ++i) {
+        r->brick_edge[i] = owner->brick_edge[i];
+        r->brick_res[i] = owner->brick_res[i];
+        r->brick_tex[i] = owner->brick_tex[i];
+        r->raycast.brickRes[i] = owner->raycast.brickRes[i];
+    }
+    r->vols.resize(owner->vols.size());
+    for (size_t t = 0; t < owner->vols.size(); ++t) {
+        VolumeSlot &d = r->vols[t];
+        const VolumeSlot &s = owner->vols[t];
+        d.dev = s.dev;
+        for (int c = 0; c < 3; ++c) d.chan[c] = s.chan[c];
+        d.bricks = s.bricks;
+        d.borrowed = true;
+    }
+    r->bricks_valid = owner->bricks_valid;
+    r->timestep = owner->timestep < r->vols.size() ? owner->timestep : 0;
+    r->fp_valid = false;   // the footprint volume follows the renderer's own time step: not shared
+    r->skip_dirty = true;
+    r->pt_dirty = true;
     return VRHIP_OK;
 }
 
@@ -1047,12 +1093,14 @@ int vrhip_build_bricks(vrhip_renderer *r)
     for (VolumeSlot &s : r->vols) {
         if (!s.dev) return fail(r, VRHIP_ERR_NODATA,
                                 "Error loading timeseries data: size mismatch.");   // :227
+        if (s.borrowed) continue;   // shared voxels come with their bricks (they depend on nothing else)
         if (s.bricks) VR_HIP(r, hipFree(s.bricks));
         s.bricks = nullptr;
         VR_HIP(r, hipMalloc(&s.bricks, bricks_bytes(r)));
     }
     VR_HIP(r, hipEventRecord(r->evb0, r->stream));
     for (VolumeSlot &s : r->vols) {
+        if (s.borrowed) continue;
         VolView v = make_vol_view(r, s.dev);
         VR_HIP(r, vr_launch_build_bricks(v, r->format, r->brick_tex, s.bricks, r->stream));
     }

@@ -93,6 +93,38 @@ class VolumeRenderCL:
             msg = self._lib.vrhip_last_error(None)
             raise RuntimeError(msg.decode() if msg else "vrhip_create failed")
         self._h = h
+        self._device_id = int(device_id)
+
+    def shareVolumes(self):
+        """A second renderer on the same GPU that renders from THIS renderer's voxels and ESS
+        bricks (vrhip_share_volumes) with everything else of its own -- transfer function, kernel
+        arguments, frame buffer, scratch, stream: one frame each can be in flight on two streams
+        over a single copy of the volume.  Starts as a copy of this renderer's settings; this
+        renderer must keep its volumes (no load / clear / close) while the twin is alive."""
+        if not self._vol_loaded:
+            raise RuntimeError("No volume data is loaded.")
+        twin = VolumeRenderCL()
+        twin.initialize(device_id=getattr(self, "_device_id", 0))
+        twin._check(twin._lib.vrhip_share_volumes(twin._h, self._h))
+        for name in ("_res", "_thickness", "_histograms"):
+            setattr(twin, name, list(getattr(self, name)))
+        twin._format = self._format
+        twin._model_scale = self._model_scale.copy()
+        twin._timestep = self._timestep
+        twin._props = getattr(self, "_props", None)
+        for name in ("_camera", "_rendering", "_raycast", "_pathtrace"):
+            C.memmove(C.byref(getattr(twin, name)), C.byref(getattr(self, name)),
+                      C.sizeof(getattr(self, name)))
+        twin._fixed_seed = self._fixed_seed
+        twin._vol_loaded = True
+        twin._check(twin._lib.vrhip_set_timestep(twin._h, int(self._timestep)))
+        twin._check(twin._lib.vrhip_set_object_ess(twin._h, 1 if getattr(self, "_obj_ess", True) else 0))
+        if getattr(self, "_tff", None) is not None:
+            twin.setTransferFunction(self._tff)
+            if getattr(self, "_prefix", None) is not None:
+                twin.setTffPrefixSum(self._prefix)
+        twin._rendering.iteration = self._rendering.iteration
+        return twin
 
     def close(self):
         if self._lib is not None and self._h:
@@ -362,6 +394,7 @@ class VolumeRenderCL:
         if not self._vol_loaded:
             return
         tff = np.ascontiguousarray(tff, dtype=np.uint8).reshape(-1)
+        self._tff = tff.copy()
         self._check(self._lib.vrhip_set_transfer_function(
             self._h, tff.ctypes.data_as(C.c_void_p), tff.size // 4))
         self._generate_bricks()
@@ -373,6 +406,7 @@ class VolumeRenderCL:
         if not self._vol_loaded:
             return
         prefix = np.ascontiguousarray(prefix, dtype=np.uint32)
+        self._prefix = prefix.copy()
         self._check(self._lib.vrhip_set_tff_prefix_sum(
             self._h, prefix.ctypes.data_as(C.c_void_p), prefix.size))
 
@@ -424,6 +458,7 @@ class VolumeRenderCL:
 
     def setObjEss(self, v):
         """The reference rebuilds its program with/without -DESS; here a variant switch."""
+        self._obj_ess = bool(v)
         self._check(self._lib.vrhip_set_object_ess(self._h, 1 if v else 0))
 
     def setBackground(self, color):
