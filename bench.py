@@ -204,13 +204,16 @@ def main():
     # Frames in flight (single GPU; the path tracer's running mean chains its frames, so it keeps
     # one): the extra renderers share the first one's voxels and bricks (vrhip_share_volumes) and
     # own a stream, a frame buffer and scratch each.
-    fif = max(1, args.frames_in_flight) if (world == 1 and technique == 0) else 1
+    fif = max(1, args.frames_in_flight) if technique == 0 else 1
     lanes = [(vr, stream, frame)]
     for _ in range(fif - 1):
         s2 = torch.cuda.Stream(dev)
         twin = vr.shareVolumes()
         twin.set_stream(s2.cuda_stream)
-        lanes.append((twin, s2, torch.empty((H, W, 4), dtype=torch.float32, device=dev)))
+        lanes.append((twin, s2, torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+                      if world == 1 else None))
+    if world > 1 and fif > 1:
+        driver_mt = vtiles.TileDriver(vr, split, dev, batch=fpg, lanes=[(r, s_) for r, s_, _ in lanes])
 
     def render_lane(seed, k):
         r, _, out = lanes[k % fif]
@@ -218,10 +221,26 @@ def main():
         r.setIteration(0)
         r.runRaycast(W, H, out_dev_ptr=out.data_ptr())
 
+    # world > 1: one gather in flight -- the gather + assembly of a batch of frames overlap the
+    # rendering of the next batch
+    chunks = [list(range(c0, min(c0 + fpg, args.steps))) for c0 in range(0, args.steps, fpg)]
+    drv = driver_mt if (world > 1 and fif > 1) else driver
+
+    def submit_chunk(chunk):
+        def before(i, r=vr):
+            r.setSeed(seeds[args.warmup + chunk[i]])
+            r.setIteration(chunk[i] if technique == 1 else 0)
+        drv.submit_batch(len(chunk), before)
+
     for k in range(args.warmup):
         render(seeds[k])
-    for k in range(fif if fif > 1 else 0):   # every lane once: buffers, skip bitmap, cell grid
-        render_lane(seeds[0], k)
+    if fif > 1:   # every lane once, untimed: buffers, skip bitmap, cell grid
+        if world == 1:
+            for k in range(fif):
+                render_lane(seeds[0], k)
+        else:
+            submit_chunk(chunks[0])
+            drv.collect_batch(frames)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -238,21 +257,11 @@ def main():
         for k in range(args.steps):
             render(seeds[args.warmup + k], k)
     else:
-        # one gather in flight: the gather + assembly of a batch of frames overlap the rendering
-        # of the next batch
-        chunks = [list(range(c0, min(c0 + fpg, args.steps))) for c0 in range(0, args.steps, fpg)]
-
-        def submit_chunk(chunk):
-            def before(i):
-                vr.setSeed(seeds[args.warmup + chunk[i]])
-                vr.setIteration(chunk[i] if technique == 1 else 0)
-            driver.submit_batch(len(chunk), before)
-
         submit_chunk(chunks[0])
         for chunk in chunks[1:]:
             submit_chunk(chunk)
-            driver.collect_batch(frames)
-        driver.collect_batch(frames)
+            drv.collect_batch(frames)
+        drv.collect_batch(frames)
     for _, s2, _ in lanes[1:]:
         stream.wait_stream(s2)       # the region ends when every lane's last frame has
     ev1.record(stream)
@@ -385,8 +394,9 @@ def main():
                                H + (8 - H % 8), args.view, tff_name, illum, "on" if ess else "off")
                             + (" -- technique 1 (path tracer, max_extinction 100): illumType/ESS/ERT/"
                                "samplingRate unused" if technique == 1 else ""),
-                "parallelism": "tiles%dx%d/%d ranks, volume replicated, one RCCL gather per %d frames "
-                               "(one gather in flight)" % (args.tile, args.tile, world, fpg)
+                "parallelism": "tiles%dx%d/%d ranks, volume replicated, %d renderer(s) per rank alternating "
+                               "frames, one RCCL gather per %d frames (one gather in flight)" % (
+                                   args.tile, args.tile, world, fif, fpg)
                                if world > 1 else "single GPU, full frames, %d in flight" % fif,
             },
             "msamples_nominal_per_s": work["samples_nominal"] / wall / 1e6,

@@ -1091,3 +1091,56 @@ def test_shared_volume_twin_renders_the_same_frames(vr):
     vr.setIteration(0)
     ref, _, _ = common.oracle_frame(vr, vol, USHORT, tff, W, H)
     assert np.abs(again - ref).max() <= TOL
+
+
+def test_tile_driver_lanes_and_batches_on_one_gpu(vr):
+    """TileDriver with two renderers per rank (frames in flight) and several frames per gather:
+    rank 0 of a 2-rank split with a stand-in collective -- its tiles of every frame of the batch
+    must equal the same pixels of the full frame with that frame's seed."""
+    import torch
+    from volumerenderercl_amd import tiles
+
+    class OneRankDist:           # gather: rank 0's own block arrives, the others stay zero
+        class _Done:
+            def wait(self):
+                pass
+
+        def gather(self, tensor, gather_list, dst=0, async_op=False):
+            gather_list[0].copy_(tensor)
+            return self._Done()
+
+    vol = common.noise_volume((48, 48, 48), UCHAR, seed=21, smooth=False)
+    tff = common.tffs()["default"]
+    W, H, T = 160, 96, 32
+    _setup(vr, vol, UCHAR, tff, common.views()["rot30"])
+    vr.setStatsEnabled(False)
+    dev = torch.device("cuda")
+    twin = vr.shareVolumes()
+    s2 = torch.cuda.Stream()
+    twin.set_stream(s2.cuda_stream)
+    vr.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        split = tiles.TileSplit(W, H, T, T, 2, 0)
+        drv = tiles.TileDriver(vr, split, dev, dist=OneRankDist(), batch=3,
+                               lanes=[(vr, torch.cuda.current_stream()), (twin, s2)])
+        seeds = [SEED, 581869302, 3890346734]
+        frames = torch.zeros((3, H, W, 4), dtype=torch.float32, device=dev)
+
+        def before(i, r):
+            r.setSeed(seeds[i])
+            r.setIteration(0)
+
+        drv.submit_batch(3, before)
+        drv.collect_batch(frames)
+        torch.cuda.synchronize()
+        got = frames.cpu().numpy()
+        for i, seed in enumerate(seeds):
+            vr.setSeed(seed)
+            vr.setIteration(0)
+            full = vr.runRaycastNoGL(W, H)
+            for t in split.my_tiles:
+                x0, y0, w, h = split.tile_rect(t)
+                np.testing.assert_array_equal(got[i, y0:y0 + h, x0:x0 + w], full[y0:y0 + h, x0:x0 + w])
+    finally:
+        twin.close()
+        vr.set_stream(None, use_own=True)

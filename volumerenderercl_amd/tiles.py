@@ -56,12 +56,17 @@ class TileDriver:
     """
 
     def __init__(self, vr, split, device, render_tiles_fn=None, dist=None, image_ess=False,
-                 hit_io=None, batch=1):
+                 hit_io=None, batch=1, lanes=None):
         import torch
         self.torch = torch
         self.vr, self.split, self.device = vr, split, device
         self.render_tiles_fn = render_tiles_fn
         s = split
+        # frames in flight on this rank: [(renderer, torch stream), ...]; the frames of a batch are
+        # dealt to them in turn (renderers sharing one volume, VolumeRenderCL.shareVolumes)
+        self.lanes = list(lanes) if lanes else None
+        if self.lanes and (image_ess or hit_io is not None):
+            raise ValueError("image-order ESS chains its frames: one renderer per rank")
         # image-order ESS: (get, set) of the hit image the next frame reads
         self.hit_io = hit_io
         if image_ess and hit_io is None:
@@ -110,8 +115,9 @@ class TileDriver:
         self.submit_batch(1)
 
     def submit_batch(self, n, before_frame=None):
-        """Render this rank's tiles of the next `n` <= batch frames -- `before_frame(i)` is called
-        ahead of frame i (jitter seed, iteration, ...) -- and start ONE gather for all of them."""
+        """Render this rank's tiles of the next `n` <= batch frames -- `before_frame(i)` (with
+        `lanes`: `before_frame(i, renderer)`) is called ahead of frame i (jitter seed, iteration,
+        ...) -- and start ONE gather for all of them."""
         s = self.split
         if s.world == 1:
             raise RuntimeError("submit/collect are for world > 1; use render_frame")
@@ -121,7 +127,21 @@ class TileDriver:
             raise RuntimeError("two gathers already in flight: collect first")
         b = self.next_buf
         self.next_buf ^= 1
+        cur = None
+        if self.lanes:
+            # the buffer may only be overwritten once the gather that last read it is done: that
+            # wait sits on the current stream (collect_batch), so every lane's stream joins it
+            cur = self.torch.cuda.current_stream(self.device)
+            for _, ls in self.lanes:
+                if ls is not None and ls != cur:
+                    ls.wait_stream(cur)
         for i in range(n):
+            if self.lanes:
+                lane_vr = self.lanes[i % len(self.lanes)][0]
+                if before_frame is not None:
+                    before_frame(i, lane_vr)
+                lane_vr.render_tiles(s.W, s.H, s.tw, s.th, s.my_tiles, self.local[b][i].data_ptr())
+                continue
             if before_frame is not None:
                 before_frame(i)
             if self.render_tiles_fn is None:
@@ -130,6 +150,10 @@ class TileDriver:
                 self.render_tiles_fn(s.my_tiles, self.local[b][i])
             if self.hit_io is not None:
                 self.merge_hit_image()      # the next frame reads the merged hit image
+        if self.lanes:
+            for _, ls in self.lanes:        # the gather follows every lane's frames
+                if ls is not None and ls != cur:
+                    cur.wait_stream(ls)
         glist = [self.staging[b][r] for r in range(s.world)] if s.rank == 0 else None
         work = self.dist.gather(self.local[b], glist, dst=0, async_op=True)
         self.pending.append((b, n, work))
