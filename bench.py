@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--tile", type=int, default=64, help="tile edge for the multi-GPU split")
     ap.add_argument("--frames-per-gather", type=int, default=4,
                     help="multi-GPU: independent frames per RCCL gather")
-    ap.add_argument("--frames-in-flight", type=int, default=2,
+    ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="single GPU: renderers (one stream each, sharing the volume) that alternate "
                          "frames, so that the tail of one frame overlaps the head of the next")
     ap.add_argument("--no-cpu-baseline", action="store_true")
