@@ -1144,3 +1144,33 @@ def test_tile_driver_lanes_and_batches_on_one_gpu(vr):
     finally:
         twin.close()
         vr.set_stream(None, use_own=True)
+
+
+def test_shared_twin_follows_its_own_time_step(vr):
+    """A twin shares every time step of the owner and selects its own: bricks come shared, skip
+    bitmap, cell grid and footprint volume are the twin's."""
+    steps = [common.noise_volume((40, 40, 40), UCHAR, seed=60 + t, smooth=False) for t in range(2)]
+    tff = common.tffs()["default"]
+    W, H = 64, 48
+    vr.loadVolumeArrays(steps, UCHAR)
+    vr.setTransferFunction(tff)
+    for name, val in (("setIllumination", 1), ("setObjEss", True), ("setTechnique", 0),
+                      ("setAmbientOcclusion", False), ("setShowESS", False), ("setImgEss", False),
+                      ("setContours", False), ("setAerial", False), ("setCamOrtho", False)):
+        getattr(vr, name)(val)
+    vr.updateView(common.views()["rot30"])
+    vr.setStatsEnabled(False)
+    vr.setTimestep(0)
+    twin = vr.shareVolumes()
+    try:
+        twin.setTimestep(1)
+        for r, t in ((vr, 0), (twin, 1), (vr, 0)):
+            r.setSeed(SEED)
+            r.setIteration(0)
+            got = r.runRaycastNoGL(W, H)
+            cam, rp, rc, pt = common.to_oracle_params(*r.params())
+            rp.iteration = 0
+            ref, _, _ = vro.render_tile(steps[t], UCHAR, tff, cam, rp, rc, pt, W=W, H=H)
+            assert np.abs(got - ref).max() <= TOL, "time step %d" % t
+    finally:
+        twin.close()
