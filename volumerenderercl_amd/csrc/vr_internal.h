@@ -106,6 +106,7 @@ struct FrameView {
     uint32_t *cont_count;  // zeroed before each launch
     uint32_t *cont_head;   // zeroed before each launch
     uint32_t round_budget;
+    uint32_t refill_min;   // phase 2: idle ray slots of a wave before they take new rays (0 = all 16)
     // DDA pre-pass (ESS, un-instrumented): a light, high-occupancy kernel walks every ray to its
     // first non-skipped brick; rays that never reach one get their (background) pixel there and
     // phase 1 only visits the patches listed in `live`.  nullptr: phase 1 walks the whole queue.

@@ -1002,7 +1002,7 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t slot = lane & (kSplit - 1), rsel = lane / kSplit;   // 16 rays per wave
+    const uint32_t slot = lane & (kSplit - 1);   // 16 rays per wave, 4 lanes each
     constexpr uint32_t kRaysPerWave = 64 / kSplit;
     const int tffn = (int)tf.tff_n;
     unsigned long long c_taken = 0, c_shaded = 0, c_bricks = 0, c_skipped = 0;
@@ -1014,40 +1014,83 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
     const uint32_t *sb = SKIP_LDS ? s_skip : skip.bits;
     const bool skip_empty = INSTR != 2 && cells.empty != nullptr && rp.useLinear != 0 &&
                             !(XS && rp.illumType == 4);
-    const uint32_t n_groups = (n_rays + kRaysPerWave - 1u) / kRaysPerWave;
+    // Rays are handed out one by one from the sorted list: when `refill_min` ray slots (quads) of
+    // the wave are idle they retire their rays and take the next ones (their set-up runs
+    // together).  With the default, 16, a wave refills when all its rays are done, but draws as
+    // many rays as it has slots from wherever the list head is -- finer than fixed groups of 16,
+    // and with the longest rays first the tail is made of the shortest ones.  Smaller values keep
+    // the waves fuller at the price of more (divergent) set-ups: measured better by 2-3 % on the
+    // "shells" volumes, worse by as much on dense ones.  Exit condition reached by every wave: the
+    // list head only grows, and every ray ends.
+    const uint32_t refill_min = fr.refill_min ? fr.refill_min : kRaysPerWave;
+    unsigned long long dummy0 = 0, dummy1 = 0;
+    const bool count = INSTR && slot == 0;
+    bool have = false, drained = false;
+    uint32_t gx = 0, gy = 0, out_index = 0, my_rounds = 0;
+    bool guess_empty = true;   // identical in the four lanes of a ray, like all of its state
+    RayCtx c;
+    RayDyn d;
+    setup_ray<ESS>(0u, 0u, false, fr, cam, rp, rc, resf, voxLen, grid, c, d);   // S_DONE
 
-    uint32_t q_next = 0;
-    if (lane == 0) q_next = atomicAdd(fr.cont_head, 1u);
     for (;;) {
-        const uint32_t q = __builtin_amdgcn_readfirstlane(q_next);
-        if (q >= n_groups) break;
-        if (lane == 0) q_next = atomicAdd(fr.cont_head, 1u);
-        VR_COUNT(11);
-        const uint32_t ri = q * kRaysPerWave + rsel;
-        const bool have = ri < n_rays;
-        const uint32_t rix = have ? (fr.order ? fr.order[ri] : ri) : 0u;
-        const ContRec rec = fr.cont[rix];
-        uint32_t my_rounds = 0;   // rounds this ray stays alive: next frame's sort key
-        const uint32_t gx = rec.pix & 0xffffu, gy = rec.pix >> 16;
-
-        RayCtx c;
-        RayDyn d;
-        setup_ray<ESS>(gx, gy, have, fr, cam, rp, rc, resf, voxLen, grid, c, d);
-        d.state = have ? rec.state : S_DONE;
-        d.t = rec.t; d.t_exit = rec.t_exit; d.alpha = rec.alpha;
-        d.r0 = rec.r0; d.r1 = rec.r1; d.r2 = rec.r2;
-        d.c0 = rec.cx; d.c1 = rec.cy; d.c2 = rec.cz;
-        d.tv0 = rec.tv0; d.tv1 = rec.tv1; d.tv2 = rec.tv2;
+        {
+            const bool idle = d.state == S_DONE;
+            const unsigned long long idle_m = __ballot(idle);
+            const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle_m) / kSplit;
+            const bool all_idle = idle_m == ~0ull;
+            if ((!drained && n_idle >= refill_min) || all_idle) {
+                VR_COUNT(11);
+                // retire the finished rays
+                if (idle && have) {
+                    if (XS && rc.useAO && slot == 0 && d.ert)
+                        apply_ao<VT, INSTR>(vol, s_tff, tffn, c, d, rp, gx, gy);
+                    if (slot == 0) {
+                        write_pixel<XS>(fr, rp, c, d, voxLen, gx, gy, (size_t)out_index);
+                        if (fr.cost)
+                            fr.cost[(size_t)gy * fr.W + gx] = (uint16_t)(my_rounds < 65535u ? my_rounds : 65535u);
+                    }
+                    have = false;
+                }
+                if (!drained) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(fr.cont_head, n_idle);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base + n_idle >= n_rays) drained = true;
+                    if (idle) {
+                        // my quad's rank among the idle quads (every lane of a quad is idle or none is)
+                        const uint32_t below = (uint32_t)__builtin_popcountll(
+                            idle_m & ((1ull << (lane & ~(uint64_t)(kSplit - 1))) - 1ull)) / kSplit;
+                        const uint32_t ri = base + below;
+                        have = ri < n_rays;
+                        if (have) {
+                            const uint32_t rix = fr.order ? fr.order[ri] : ri;
+                            const ContRec rec = fr.cont[rix];
+                            gx = rec.pix & 0xffffu;
+                            gy = rec.pix >> 16;
+                            out_index = rec.out_index;
+                            setup_ray<ESS>(gx, gy, true, fr, cam, rp, rc, resf, voxLen, grid, c, d);
+                            d.state = rec.state;
+                            d.t = rec.t; d.t_exit = rec.t_exit; d.alpha = rec.alpha;
+                            d.r0 = rec.r0; d.r1 = rec.r1; d.r2 = rec.r2;
+                            d.c0 = rec.cx; d.c1 = rec.cy; d.c2 = rec.cz;
+                            d.tv0 = rec.tv0; d.tv1 = rec.tv1; d.tv2 = rec.tv2;
 #ifdef VR_RAYLEN
-        d.nsmp = rec.pad;
+                            d.nsmp = rec.pad;
 #endif
-        if (ESS) fetch_skip_word(sb, grid, d);
-        unsigned long long dummy0 = 0, dummy1 = 0;
-        const bool count = INSTR && slot == 0;
-        bool guess_empty = true;   // identical in the four lanes of a ray, like all of its state
-        VR_STAMP(1);
-
-        for (;;) {
+                            if (ESS) fetch_skip_word(sb, grid, d);
+                            my_rounds = 0;
+                            guess_empty = true;
+                        }
+                    }
+                }
+                VR_STAMP(1);
+                if (!__ballot(d.state != S_DONE)) {
+                    if (drained) break;
+                    continue;
+                }
+            }
+        }
+        {   // ---- one round
             if (ESS) {
                 for (int it = 0;; ++it) {
                     if (!__ballot(d.state == S_BRICK)) break;
@@ -1066,7 +1109,7 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
                 }
             }
             VR_STAMP(2);
-            if (!__ballot(d.state != S_DONE)) break;
+            if (!__ballot(d.state != S_DONE)) continue;
             VR_COUNT(10);
             my_rounds += d.state != S_DONE ? 1u : 0u;
 #ifdef VR_CAP_ROUNDS   // diagnostic build (wrong image): is phase 2 bound by its longest rays?
@@ -1156,13 +1199,6 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
                 VR_STAMP(6);
             }
         }
-        if (XS && rc.useAO && have && slot == 0 && d.ert)
-            apply_ao<VT, INSTR>(vol, s_tff, tffn, c, d, rp, gx, gy);
-        if (have && slot == 0) {
-            write_pixel<XS>(fr, rp, c, d, voxLen, gx, gy, (size_t)rec.out_index);
-            if (fr.cost) fr.cost[(size_t)gy * fr.W + gx] = (uint16_t)(my_rounds < 65535u ? my_rounds : 65535u);
-        }
-        VR_STAMP(7);
     }
     VR_STAMP_FLUSH_AT(16);
 

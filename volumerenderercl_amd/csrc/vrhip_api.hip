@@ -96,6 +96,7 @@ struct vrhip_renderer {
     ContRec *cont = nullptr;          // suspended rays of the two-phase march
     size_t cont_cap = 0;
     uint32_t round_budget = 10;       // phase-1 sample rounds per patch (0 = single phase)
+    uint32_t refill_min = 16;         // phase 2: idle ray slots per wave before a refill (VRHIP_REFILL_MIN)
     std::vector<uint32_t> queue_key;   // W, H, tile_w, tile_h, tile ids...
     // image-order ESS: ping-pong hit images (volumerendercl.cpp:482-488, :524-530) + per-frame scratch
     uint8_t *hit_in = nullptr, *hit_out = nullptr, *hit_status = nullptr, *hit_any = nullptr;
@@ -590,6 +591,7 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
     a->frame.cont_count = r->queue_head + 1;
     a->frame.cont_head = r->queue_head + 2;
     a->frame.round_budget = r->cont ? r->round_budget : 0;
+    a->frame.refill_min = r->refill_min;
     a->frame.live = r->prepass ? r->live : nullptr;
     a->frame.live_count = r->queue_head + 3;
     a->frame.cost = r->sort_cont ? r->cost : nullptr;
@@ -764,6 +766,10 @@ int vrhip_create(int device_id, vrhip_renderer **out)
     if (getenv("VRHIP_PT_NO_CULL")) r->pt_cull = false;        // experiments: no opacity-bound culling
     if (getenv("VRHIP_NO_EMPTY_SKIP")) r->skip_empty = false;  // experiments: no empty-run skipping
     if (getenv("VRHIP_NO_FOOTPRINT")) r->use_fp = false;       // plain volume layout only
+    if (const char *e = getenv("VRHIP_REFILL_MIN")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 16) r->refill_min = (uint32_t)v;
+    }
     if (const char *e = getenv("VRHIP_FOOTPRINT_MAX_GB")) {
         const double gb = atof(e);
         if (gb >= 0.0) r->fp_max_bytes = (size_t)(gb * 1073741824.0);
