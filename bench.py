@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--tile", type=int, default=64, help="tile edge for the multi-GPU split")
     ap.add_argument("--frames-per-gather", type=int, default=4,
                     help="multi-GPU: independent frames per RCCL gather")
+    ap.add_argument("--round-budget", type=int, default=32,
+                    help="phase-1 sample rounds per ray when several frames are in flight")
     ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="single GPU: renderers (one stream each, sharing the volume) that alternate "
                          "frames, so that the tail of one frame overlaps the head of the next")
@@ -205,6 +207,10 @@ def main():
     # one): the extra renderers share the first one's voxels and bricks (vrhip_share_volumes) and
     # own a stream, a frame buffer and scratch each.
     fif = max(1, args.frames_in_flight) if technique == 0 else 1
+    if fif > 1:
+        # throughput schedule: with other frames hiding the latency, rays stay longer in the
+        # leaner one-lane phase (vrhip_set_round_budget; the serial pass below sets 10 again)
+        vr.setRoundBudget(args.round_budget)
     lanes = [(vr, stream, frame)]
     for _ in range(fif - 1):
         s2 = torch.cuda.Stream(dev)
@@ -279,6 +285,8 @@ def main():
 
     # ---- untimed: the same frames one at a time (what one launch takes when it has the GPU to itself)
     serial_s = None
+    if fif > 1:
+        vr.setRoundBudget(10)      # the single-frame schedule for everything that follows
     if world == 1 and fif > 1:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
@@ -347,11 +355,13 @@ def main():
             "algorithmic_bytes_per_launch": int(alg_bytes),
             "avg_launch_ms": kernel_s * 1e3,
             "frames_in_flight": fif,
+            "round_budget": args.round_budget if fif > 1 else 10,
             "serial_launch_ms": serial_s * 1e3 if serial_s else None,
             "launch_note": ("%d renderers on %d streams alternate frames over one shared volume: avg_launch_ms "
                             "= HIP-event time of the timed region / frames (launches of consecutive frames "
-                            "overlap); serial_launch_ms = the same frames one at a time, which is what a "
-                            "rocprofv3 kernel trace of `--frames-in-flight 1` sums to" % (fif, fif))
+                            "overlap), phase-1 round budget %d (throughput schedule); serial_launch_ms = the same "
+                            "frames one at a time with the single-frame schedule (budget 10), which is what a "
+                            "rocprofv3 kernel trace of `--frames-in-flight 1` sums to" % (fif, fif, args.round_budget))
                            if fif > 1 else "one frame at a time",
             "last_pass_ms_hip_events": {"phase1": last_phases[0] * 1e3, "phase2": last_phases[1] * 1e3,
                                         "total": last_kernel_s * 1e3},

@@ -971,6 +971,14 @@ int vrhip_clear_volumes(vrhip_renderer *r)
     return VRHIP_OK;
 }
 
+int vrhip_set_round_budget(vrhip_renderer *r, uint32_t rounds)
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    VR_REQUIRE(r, rounds <= 100000u, VRHIP_ERR_INVALID, "vrhip_set_round_budget: out of range");
+    r->round_budget = rounds;
+    return VRHIP_OK;
+}
+
 int vrhip_share_volumes(vrhip_renderer *r, vrhip_renderer *owner)
 {
     if (!r || !owner || r == owner) return VRHIP_ERR_INVALID;

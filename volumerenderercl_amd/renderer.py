@@ -95,6 +95,12 @@ class VolumeRenderCL:
         self._h = h
         self._device_id = int(device_id)
 
+    def setRoundBudget(self, rounds):
+        """Scheduling knob of the two-phase march (vrhip_set_round_budget): 10 (default) for the
+        shortest single frame, ~32 when several frames are in flight.  No effect on pixels."""
+        self._round_budget = int(rounds)
+        self._check(self._lib.vrhip_set_round_budget(self._h, int(rounds)))
+
     def shareVolumes(self):
         """A second renderer on the same GPU that renders from THIS renderer's voxels and ESS
         bricks (vrhip_share_volumes) with everything else of its own -- transfer function, kernel
@@ -124,6 +130,8 @@ class VolumeRenderCL:
             if getattr(self, "_prefix", None) is not None:
                 twin.setTffPrefixSum(self._prefix)
         twin._rendering.iteration = self._rendering.iteration
+        if getattr(self, "_round_budget", None) is not None:
+            twin.setRoundBudget(self._round_budget)
         return twin
 
     def close(self):
