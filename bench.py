@@ -52,8 +52,8 @@ FMT_BYTES = {"UCHAR": 1, "USHORT": 2, "FLOAT": 4}
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="shells2048", choices=sorted(WORKLOADS))
     ap.add_argument("--viewport", type=int, default=1024)
     ap.add_argument("--tile", type=int, default=64, help="tile edge for the multi-GPU split")
