@@ -1174,3 +1174,33 @@ def test_shared_twin_follows_its_own_time_step(vr):
             assert np.abs(got - ref).max() <= TOL, "time step %d" % t
     finally:
         twin.close()
+
+
+@pytest.mark.parametrize("refill,budget", [("1", 1), ("5", 3), ("16", 32), ("3", 0)])
+def test_phase2_schedules_do_not_change_pixels(vr, monkeypatch, refill, budget):
+    """The scheduling knobs of the two-phase march -- rounds in phase 1 before a ray is suspended
+    (vrhip_set_round_budget; 0 = single phase) and idle ray slots per wave before phase 2 refills
+    them from the sorted list (VRHIP_REFILL_MIN; partial refills rank the idle slots) -- move work
+    between kernels and lanes, never a pixel."""
+    vol = vro.synth_volume("shells", [96, 96, 96], UCHAR)
+    tff = common.tffs()["default"]
+    W, H = 136, 120
+    _setup(vr, vol, UCHAR, tff, common.views()["rot30"])
+    vr.setStatsEnabled(False)
+    want = vr.runRaycastNoGL(W, H)
+    vr.setIteration(0)
+    ref, _, _ = common.oracle_frame(vr, vol, UCHAR, tff, W, H)
+    assert np.abs(want - ref).max() <= TOL
+    monkeypatch.setenv("VRHIP_REFILL_MIN", refill)
+    r2 = VolumeRenderCL()
+    r2.initialize()
+    try:
+        _setup(r2, vol, UCHAR, tff, common.views()["rot30"])
+        r2.setRoundBudget(budget)
+        r2.setStatsEnabled(False)
+        for _ in range(2):          # second frame: sorted by the first one's per-pixel cost
+            got = r2.runRaycastNoGL(W, H)
+            r2.setIteration(0)
+            assert np.array_equal(got, want)
+    finally:
+        r2.close()
