@@ -207,9 +207,11 @@ def main():
     # one): the extra renderers share the first one's voxels and bricks (vrhip_share_volumes) and
     # own a stream, a frame buffer and scratch each.
     fif = max(1, args.frames_in_flight) if technique == 0 else 1
-    if fif > 1:
+    if fif > 1 and world == 1:
         # throughput schedule: with other frames hiding the latency, rays stay longer in the
-        # leaner one-lane phase (vrhip_set_round_budget; the serial pass below sets 10 again)
+        # leaner one-lane phase (vrhip_set_round_budget; the serial pass below sets 10 again).
+        # Not for tile shares (world > 1): there the chain of phase-1 rounds is the longer pole
+        # (measured on rank 0's share of 2 and 8: 0.24 / 0.16 ms per frame at 10, 0.26 / 0.19 at 32).
         vr.setRoundBudget(args.round_budget)
     lanes = [(vr, stream, frame)]
     for _ in range(fif - 1):
@@ -355,7 +357,7 @@ def main():
             "algorithmic_bytes_per_launch": int(alg_bytes),
             "avg_launch_ms": kernel_s * 1e3,
             "frames_in_flight": fif,
-            "round_budget": args.round_budget if fif > 1 else 10,
+            "round_budget": args.round_budget if (fif > 1 and world == 1) else 10,
             "serial_launch_ms": serial_s * 1e3 if serial_s else None,
             "launch_note": ("%d renderers on %d streams alternate frames over one shared volume: avg_launch_ms "
                             "= HIP-event time of the timed region / frames (launches of consecutive frames "
