@@ -52,16 +52,19 @@ FMT_BYTES = {"UCHAR": 1, "USHORT": 2, "FLOAT": 4}
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="shells2048", choices=sorted(WORKLOADS))
     ap.add_argument("--viewport", type=int, default=1024)
     ap.add_argument("--tile", type=int, default=64, help="tile edge for the multi-GPU split")
-    ap.add_argument("--frames-per-gather", type=int, default=4,
+    ap.add_argument("--frames-per-gather", type=int, default=16,
                     help="multi-GPU: independent frames per RCCL gather")
+    ap.add_argument("--frames-per-launch", type=int, default=8,
+                    help="independent frames (own jitter seeds) rendered by one set of launches "
+                         "(vrhip_render_batch); 1 = one frame per launch set")
     ap.add_argument("--round-budget", type=int, default=32,
                     help="phase-1 sample rounds per ray when several frames are in flight")
-    ap.add_argument("--frames-in-flight", type=int, default=4,
+    ap.add_argument("--frames-in-flight", type=int, default=2,
                     help="single GPU: renderers (one stream each, sharing the volume) that alternate "
                          "frames, so that the tail of one frame overlaps the head of the next")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -207,34 +210,39 @@ def main():
     # one): the extra renderers share the first one's voxels and bricks (vrhip_share_volumes) and
     # own a stream, a frame buffer and scratch each.
     fif = max(1, args.frames_in_flight) if technique == 0 else 1
-    if fif > 1 and world == 1:
+    fpl = max(1, min(args.frames_per_launch, 32)) if technique == 0 else 1
+    throughput = fif > 1 or fpl > 1
+    if throughput:
         # throughput schedule: with other frames hiding the latency, rays stay longer in the
-        # leaner one-lane phase (vrhip_set_round_budget; the serial pass below sets 10 again).
-        # Not for tile shares (world > 1): there the chain of phase-1 rounds is the longer pole
-        # (measured on rank 0's share of 2 and 8: 0.24 / 0.16 ms per frame at 10, 0.26 / 0.19 at 32).
+        # leaner one-lane phase (vrhip_set_round_budget; the serial pass below sets 10 again)
         vr.setRoundBudget(args.round_budget)
     lanes = [(vr, stream, frame)]
     for _ in range(fif - 1):
         s2 = torch.cuda.Stream(dev)
         twin = vr.shareVolumes()
         twin.set_stream(s2.cuda_stream)
-        lanes.append((twin, s2, torch.empty((H, W, 4), dtype=torch.float32, device=dev)
-                      if world == 1 else None))
-    if world > 1 and fif > 1:
+        lanes.append((twin, s2, None))
+    if world == 1 and throughput:   # one output block of fpl frames per renderer
+        lanes = [(r, s_, torch.empty((fpl, H, W, 4), dtype=torch.float32, device=dev)) for r, s_, _ in lanes]
+    if world > 1 and throughput:
         driver_mt = vtiles.TileDriver(vr, split, dev, batch=fpg, lanes=[(r, s_) for r, s_, _ in lanes])
 
-    def render_lane(seed, k):
-        r, _, out = lanes[k % fif]
-        r.setSeed(seed)
-        r.setIteration(0)
-        r.runRaycast(W, H, out_dev_ptr=out.data_ptr())
+    def render_block(j, frame_ids):
+        # renderer j % fif renders these frames (their own jitter seeds) with one set of launches
+        r, _, out = lanes[j % fif]
+        r.render_batch(W, H, [seeds[args.warmup + k] for k in frame_ids], out.data_ptr())
 
     # world > 1: one gather in flight -- the gather + assembly of a batch of frames overlap the
     # rendering of the next batch
     chunks = [list(range(c0, min(c0 + fpg, args.steps))) for c0 in range(0, args.steps, fpg)]
-    drv = driver_mt if (world > 1 and fif > 1) else driver
+    blocks = [list(range(c0, min(c0 + fpl, args.steps))) for c0 in range(0, args.steps, fpl)]
+    drv = driver_mt if (world > 1 and throughput) else driver
 
     def submit_chunk(chunk):
+        if throughput:   # the rank's share of all the chunk's frames: one launch set per renderer
+            drv.submit_frames([seeds[args.warmup + k] for k in chunk])
+            return
+
         def before(i, r=vr):
             r.setSeed(seeds[args.warmup + chunk[i]])
             r.setIteration(chunk[i] if technique == 1 else 0)
@@ -242,10 +250,10 @@ def main():
 
     for k in range(args.warmup):
         render(seeds[k])
-    if fif > 1:   # every lane once, untimed: buffers, skip bitmap, cell grid
+    if throughput:   # every renderer once, untimed: buffers, work queue, skip bitmap, cell grid
         if world == 1:
-            for k in range(fif):
-                render_lane(seeds[0], k)
+            for j in range(fif):
+                render_block(j, blocks[0])
         else:
             submit_chunk(chunks[0])
             drv.collect_batch(frames)
@@ -258,9 +266,9 @@ def main():
     ev0.record(stream)
     for _, s2, _ in lanes[1:]:
         s2.wait_event(ev0)
-    if world == 1 and fif > 1:
-        for k in range(args.steps):
-            render_lane(seeds[args.warmup + k], k)
+    if world == 1 and throughput:
+        for j, blk in enumerate(blocks):
+            render_block(j, blk)
     elif world == 1:
         for k in range(args.steps):
             render(seeds[args.warmup + k], k)
@@ -287,9 +295,9 @@ def main():
 
     # ---- untimed: the same frames one at a time (what one launch takes when it has the GPU to itself)
     serial_s = None
-    if fif > 1:
+    if throughput:
         vr.setRoundBudget(10)      # the single-frame schedule for everything that follows
-    if world == 1 and fif > 1:
+    if world == 1 and throughput:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
         for k in range(args.steps):
@@ -357,14 +365,16 @@ def main():
             "algorithmic_bytes_per_launch": int(alg_bytes),
             "avg_launch_ms": kernel_s * 1e3,
             "frames_in_flight": fif,
-            "round_budget": args.round_budget if (fif > 1 and world == 1) else 10,
+            "frames_per_launch": fpl,
+            "round_budget": args.round_budget if throughput else 10,
             "serial_launch_ms": serial_s * 1e3 if serial_s else None,
-            "launch_note": ("%d renderers on %d streams alternate frames over one shared volume: avg_launch_ms "
-                            "= HIP-event time of the timed region / frames (launches of consecutive frames "
-                            "overlap), phase-1 round budget %d (throughput schedule); serial_launch_ms = the same "
-                            "frames one at a time with the single-frame schedule (budget 10), which is what a "
-                            "rocprofv3 kernel trace of `--frames-in-flight 1` sums to" % (fif, fif, args.round_budget))
-                           if fif > 1 else "one frame at a time",
+            "launch_note": ("%d renderer(s) on as many streams over one shared volume, each rendering %d independent "
+                            "frames (own jitter seeds) per set of launches (vrhip_render_batch): avg_launch_ms = "
+                            "HIP-event time of the timed region / frames, phase-1 round budget %d (throughput "
+                            "schedule); serial_launch_ms = the same frames one at a time with the single-frame "
+                            "schedule (budget 10), which is what a rocprofv3 kernel trace of `--frames-in-flight 1 "
+                            "--frames-per-launch 1` sums to" % (fif, fpl, args.round_budget))
+                           if throughput else "one frame at a time",
             "last_pass_ms_hip_events": {"phase1": last_phases[0] * 1e3, "phase2": last_phases[1] * 1e3,
                                         "total": last_kernel_s * 1e3},
             "request_bytes_per_launch": int(b * 8 * (st1["samples_taken"] +
@@ -406,10 +416,11 @@ def main():
                                H + (8 - H % 8), args.view, tff_name, illum, "on" if ess else "off")
                             + (" -- technique 1 (path tracer, max_extinction 100): illumType/ESS/ERT/"
                                "samplingRate unused" if technique == 1 else ""),
-                "parallelism": "tiles%dx%d/%d ranks, volume replicated, %d renderer(s) per rank alternating "
-                               "frames, one RCCL gather per %d frames (one gather in flight)" % (
+                "parallelism": "tiles%dx%d/%d ranks, volume replicated, %d renderer(s) per rank, one RCCL "
+                               "gather per %d frames (one gather in flight)" % (
                                    args.tile, args.tile, world, fif, fpg)
-                               if world > 1 else "single GPU, full frames, %d in flight" % fif,
+                               if world > 1 else "single GPU, full frames, %d renderer(s) x %d frames per "
+                                                 "launch set" % (fif, fpl),
             },
             "msamples_nominal_per_s": work["samples_nominal"] / wall / 1e6,
             "work_per_frame": {k: v // args.steps for k, v in work.items()},

@@ -202,6 +202,19 @@ int vrhip_get_image_ess(vrhip_renderer *r, uint32_t width, uint32_t height, uint
                         uint8_t *hit_out);
 int vrhip_set_image_ess(vrhip_renderer *r, uint32_t width, uint32_t height, const uint8_t *hit_in,
                         const uint8_t *hit_out);
+/* A batch of n_frames <= 32 INDEPENDENT frames -- same camera and parameters, frame f with jitter
+ * seed seeds[f] (rendering_params.seed is not used) -- in ONE set of launches: the work queue holds
+ * every patch once per frame, so a small tile share still fills the GPU and the latency chain of
+ * a frame (pre-pass, phase-1 rounds, sort, the longest rays of phase 2) is paid once per batch.
+ * tile_ids == NULL: whole frames, out_dev[n_frames][height][width][4]; else the tile subset like
+ * vrhip_render_tiles, out_dev[n_frames][n_tiles][tile_h][tile_w][4]; out_frame_stride != 0 gives the
+ * distance between the frames of out_dev in pixels (>= one frame).  DEVICE output only (the
+ * renderer's own frame buffer is not meaningful afterwards).  Ray caster, iteration 0, no
+ * image-order ESS, no ambient occlusion: anything else is VRHIP_ERR_UNSUPPORTED. */
+int vrhip_render_batch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t tile_w,
+                       uint32_t tile_h, const uint32_t *tile_ids, uint32_t n_tiles,
+                       const uint32_t *seeds, uint32_t n_frames, float *out_dev,
+                       uint32_t out_frame_stride);
 /* getLastExecTime (volumerendercl.cpp:1053-1056): HIP-event time of the last ray-cast
  * kernel launch, seconds. */
 double vrhip_last_kernel_seconds(const vrhip_renderer *r);

@@ -1204,3 +1204,54 @@ def test_phase2_schedules_do_not_change_pixels(vr, monkeypatch, refill, budget):
             assert np.array_equal(got, want)
     finally:
         r2.close()
+
+
+@pytest.mark.parametrize("fmt,res,kw", [(UCHAR, (48, 48, 48), {}), (USHORT, (40, 56, 36), {"ess": False}),
+                                         (FLOAT, (44, 44, 44), {"illum": 0, "contours": True})])
+def test_batch_of_frames_in_one_launch_set(vr, fmt, res, kw):
+    """vrhip_render_batch: several independent frames (own jitter seeds) share one work queue and
+    one set of launches; every frame equals its stand-alone rendering (and the oracle), whole
+    frames and tile subsets, default and instrumented kernels."""
+    import torch
+    vol = common.noise_volume(res, fmt, seed=33, smooth=False)
+    tff = common.tffs()["default"]
+    W, H, T = 112, 80, 32
+    _setup(vr, vol, fmt, tff, common.views()["rot30"], **kw)
+    seeds = [SEED, 581869302, 3890346734, 3586334585, 545404204]
+    singles = []
+    vr.setStatsEnabled(False)
+    for s in seeds:
+        vr.setSeed(s)
+        vr.setIteration(0)
+        singles.append(vr.runRaycastNoGL(W, H))
+    cam, rp, rc, pt = common.to_oracle_params(*vr.params())
+    rp.seed, rp.iteration = seeds[3], 0
+    ref, _, _ = vro.render_tile(vol, fmt, tff, cam, rp, rc, pt, use_ess=kw.get("ess", True), W=W, H=H)
+    assert np.abs(singles[3] - ref).max() <= TOL
+    for stats in (False, True):
+        vr.setStatsEnabled(stats)
+        out = torch.zeros((len(seeds), H, W, 4), dtype=torch.float32, device="cuda")
+        vr.render_batch(W, H, seeds, out.data_ptr())
+        torch.cuda.synchronize()
+        vr.getLastExecTime()
+        got = out.cpu().numpy()
+        for f in range(len(seeds)):
+            assert np.array_equal(got[f], singles[f]), "frame %d (stats %s)" % (f, stats)
+    # tile subset, compact output per frame
+    vr.setStatsEnabled(False)
+    tiles_x = (W + T - 1) // T
+    ids = np.array([0, 2, 5, 7, 9], dtype=np.uint32)
+    out = torch.zeros((3, len(ids), T, T, 4), dtype=torch.float32, device="cuda")
+    vr.render_batch(W, H, seeds[:3], out.data_ptr(), tile_w=T, tile_h=T, tile_ids=ids)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    for f in range(3):
+        for k, t in enumerate(ids):
+            x0, y0 = (int(t) % tiles_x) * T, (int(t) // tiles_x) * T
+            w, h = min(T, W - x0), min(T, H - y0)
+            assert np.array_equal(got[f, k, :h, :w], singles[f][y0:y0 + h, x0:x0 + w])
+    # what chains frames is refused
+    vr.setAmbientOcclusion(True)
+    with pytest.raises(RuntimeError):
+        vr.render_batch(W, H, seeds[:2], out.data_ptr())
+    vr.setAmbientOcclusion(False)

@@ -67,6 +67,8 @@ SYMBOLS = {
     "vrhip_upload_volume_channels": (C.c_int, [_H, C.c_void_p, C.POINTER(C.c_uint32), C.c_int,
                                                C.c_int, C.c_uint32]),
     "vrhip_share_volumes": (C.c_int, [_H, _H]),
+    "vrhip_render_batch": (C.c_int, [_H, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                     C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]),
     "vrhip_set_round_budget": (C.c_int, [_H, C.c_uint32]),
     "vrhip_upload_volume_device": (C.c_int, [_H, C.c_void_p, _U3, C.c_int, C.c_uint32]),
     "vrhip_synth_volume": (C.c_int, [_H, C.c_int, _U3, C.c_int, C.c_uint32]),

@@ -69,9 +69,15 @@ struct SkipView {
 
 // One 8x8-pixel patch (= one wave64) of the work queue.
 struct WaveTile {
-    uint16_t tx8, ty8;     // patch origin / 8 in the frame
+    uint16_t tx8, ty8;     // patch origin / 8 in the frame; ty8 bits 11..15: frame of the batch
     uint32_t out_base;     // index of its first pixel in FrameView::out
 };
+// Several independent frames (jitter seeds) in one set of launches: the work queue holds every
+// patch once per frame, the frame index rides in the upper bits of WaveTile::ty8 (patch rows need
+// 11 bits up to 16384 pixels) and of ContRec::state, FrameView::seeds gives each frame its seed.
+constexpr uint32_t kFrameShift = 11, kMaxBatchFrames = 32;
+__host__ __device__ inline uint32_t wt_row(const WaveTile &w) { return w.ty8 & ((1u << kFrameShift) - 1u); }
+__host__ __device__ inline uint32_t wt_frame(const WaveTile &w) { return w.ty8 >> kFrameShift; }
 
 // A patch with at least one ray that reaches a non-skipped brick (DDA pre-pass), and which rays.
 struct LiveTile {
@@ -106,6 +112,7 @@ struct FrameView {
     uint32_t *cont_count;  // zeroed before each launch
     uint32_t *cont_head;   // zeroed before each launch
     uint32_t round_budget;
+    const uint32_t *seeds; // per frame of a batch (WaveTile frame index), or nullptr: rendering_params.seed
     uint32_t refill_min;   // phase 2: idle ray slots of a wave before they take new rays (0 = all 16)
     // DDA pre-pass (ESS, un-instrumented): a light, high-occupancy kernel walks every ray to its
     // first non-skipped brick; rays that never reach one get their (background) pixel there and

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
                     px.out_index = wt.out_base + ly * fr.out_stride + lx;
                     // pixels outside the frame (ragged right / bottom patches) are dropped
                     if (px.gx < fr.W && px.gy < fr.H) {
-                        const Ray ray = make_ray(px.gx, px.gy, fr, cam, rp);
+                        const Ray ray = make_ray(px.gx, px.gy, fr, cam, rp, rp.seed);
                         px.env0 = ray.env[0]; px.env1 = ray.env[1];
                         px.env2 = ray.env[2]; px.env3 = ray.env[3];
                         if (!ray.hit) {   // :677-683

@@ -81,9 +81,9 @@ template <bool ESS>
 VR_DEV void setup_ray(uint32_t gx, uint32_t gy, bool inside, const FrameView &fr,
                       const vrhip_camera_params &cam, const vrhip_rendering_params &rp,
                       const vrhip_raycast_params &rcp, f3 resf, f3 voxLen, const Grid &g, RayCtx &c,
-                      RayDyn &d)
+                      RayDyn &d, uint32_t seed)
 {
-    const Ray ray = make_ray(gx, gy, fr, cam, rp);
+    const Ray ray = make_ray(gx, gy, fr, cam, rp, seed);
     c.cam = ray.cam;
     c.dir = ray.dir;
     c.env0 = ray.env[0]; c.env1 = ray.env[1]; c.env2 = ray.env[2]; c.env3 = ray.env[3];
@@ -633,10 +633,10 @@ VR_DEV bool image_ess_patch(const FrameView &fr, const vrhip_rendering_params &r
                             const WaveTile &wt, uint32_t lane, bool inside, uint32_t gx, uint32_t gy,
                             size_t out_index)
 {
-    const bool unhit = group_unhit(fr, wt.tx8, wt.ty8, lane);
+    const bool unhit = group_unhit(fr, wt.tx8, wt_row(wt), lane);
     const unsigned long long valid = __ballot(c.valid);
     if (lane == 0)
-        fr.hit_status[(size_t)wt.ty8 * fr.hit_w + wt.tx8] =
+        fr.hit_status[(size_t)wt_row(wt) * fr.hit_w + wt.tx8] =
             (uint8_t)(unhit ? HIT_SKIPPED : ((valid & 1ull) ? HIT_FIRST_ENDS : HIT_FIRST_MISSES));
     if (unhit && inside) {
         float4 o = make_float4(c.env0, c.env1, c.env2, c.env3);
@@ -749,14 +749,15 @@ __global__ __launch_bounds__(kBlockDim) void vr_dda_prepass_kernel(
     if (q >= fr.n_wave_tiles) return;
     const WaveTile wt = fr.queue[q];
     const uint32_t lx = lane & 7u, ly = lane >> 3;
-    const uint32_t gx = (uint32_t)wt.tx8 * 8u + lx, gy = (uint32_t)wt.ty8 * 8u + ly;
+    const uint32_t gx = (uint32_t)wt.tx8 * 8u + lx, gy = wt_row(wt) * 8u + ly;
+    const uint32_t seed = fr.seeds ? fr.seeds[wt_frame(wt)] : rp.seed;
     const bool inside = gx < fr.W && gy < fr.H;
     const f3 resf = mk3(vv.fw, vv.fh, vv.fd);
     const f3 voxLen = mk3(1.f / vv.fw, 1.f / vv.fh, 1.f / vv.fd);
     const Grid grid = make_grid(bricks, rc, skip.n_words, true);
     RayCtx c;
     RayDyn d;
-    setup_ray<true>(gx, gy, inside, fr, cam, rp, rc, resf, voxLen, grid, c, d);
+    setup_ray<true>(gx, gy, inside, fr, cam, rp, rc, resf, voxLen, grid, c, d, seed);
     const size_t out_index = (size_t)wt.out_base + (size_t)ly * fr.out_stride + lx;
     if (rp.imgEss && image_ess_patch(fr, rp, c, wt, lane, inside, gx, gy, out_index)) return;
     fetch_skip_word(skip.bits, grid, d);
@@ -836,12 +837,14 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_kernel(
         VR_STAMP(0);
         VR_COUNT(11);
         const uint32_t lx = lane & 7u, ly = lane >> 3;
-        const uint32_t gx = (uint32_t)wt.tx8 * 8u + lx, gy = (uint32_t)wt.ty8 * 8u + ly;
+        const uint32_t gx = (uint32_t)wt.tx8 * 8u + lx, gy = wt_row(wt) * 8u + ly;
+        const uint32_t frame_idx = wt_frame(wt);
+        const uint32_t seed = fr.seeds ? fr.seeds[frame_idx] : rp.seed;
         const bool inside = gx < fr.W && gy < fr.H;
 
         RayCtx c;
         RayDyn d;
-        setup_ray<ESS>(gx, gy, inside, fr, cam, rp, rc, resf, voxLen, grid, c, d);
+        setup_ray<ESS>(gx, gy, inside, fr, cam, rp, rc, resf, voxLen, grid, c, d, seed);
         if (XS && rp.imgEss && !use_live &&   // (with a live list the pre-pass has done this)
             image_ess_patch(fr, rp, c, wt, lane, inside, gx, gy,
                             (size_t)wt.out_base + (size_t)ly * fr.out_stride + lx))
@@ -926,7 +929,7 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_kernel(
                 ContRec r;
                 r.pix = gx | (gy << 16);
                 r.out_index = wt.out_base + ly * fr.out_stride + lx;
-                r.state = d.state;
+                r.state = d.state | (int32_t)(frame_idx << 8);   // (states fit 8 bits)
                 r.t = d.t; r.t_exit = d.t_exit; r.alpha = d.alpha;
                 r.r0 = d.r0; r.r1 = d.r1; r.r2 = d.r2;
                 r.cx = d.c0; r.cy = d.c1; r.cz = d.c2;
@@ -1030,7 +1033,7 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
     bool guess_empty = true;   // identical in the four lanes of a ray, like all of its state
     RayCtx c;
     RayDyn d;
-    setup_ray<ESS>(0u, 0u, false, fr, cam, rp, rc, resf, voxLen, grid, c, d);   // S_DONE
+    setup_ray<ESS>(0u, 0u, false, fr, cam, rp, rc, resf, voxLen, grid, c, d, rp.seed);   // S_DONE
 
     for (;;) {
         {
@@ -1068,8 +1071,10 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
                             gx = rec.pix & 0xffffu;
                             gy = rec.pix >> 16;
                             out_index = rec.out_index;
-                            setup_ray<ESS>(gx, gy, true, fr, cam, rp, rc, resf, voxLen, grid, c, d);
-                            d.state = rec.state;
+                            const uint32_t f = (uint32_t)rec.state >> 8;
+                            setup_ray<ESS>(gx, gy, true, fr, cam, rp, rc, resf, voxLen, grid, c, d,
+                                           fr.seeds ? fr.seeds[f] : rp.seed);
+                            d.state = rec.state & 0xff;
                             d.t = rec.t; d.t_exit = rec.t_exit; d.alpha = rec.alpha;
                             d.r0 = rec.r0; d.r1 = rec.r1; d.r2 = rec.r2;
                             d.c0 = rec.cx; d.c1 = rec.cy; d.c2 = rec.cz;
@@ -1281,7 +1286,7 @@ __global__ __launch_bounds__(kBlockDim) void vr_hit_resolve_kernel(FrameView fr,
     const uint32_t i = blockIdx.x * kBlockDim + threadIdx.x;
     if (i >= fr.n_wave_tiles) return;
     const WaveTile wt = fr.queue[i];
-    const size_t g = (size_t)wt.ty8 * fr.hit_w + wt.tx8;
+    const size_t g = (size_t)wt_row(wt) * fr.hit_w + wt.tx8;
     hit_out[g] = fr.hit_status[g] == HIT_FIRST_ENDS ? fr.hit_any[g] : (uint8_t)0;
 }
 

@@ -446,12 +446,12 @@ struct Ray {
 
 // volumeraycast.cl:605-683: RNG jitter, padded-grid NDC, view transform, background, bbox
 VR_DEV Ray make_ray(uint32_t gx, uint32_t gy, const FrameView &fr, const vrhip_camera_params &cam,
-                    const vrhip_rendering_params &rp)
+                    const vrhip_rendering_params &rp, uint32_t seed)
 {
     Ray r;
     const float *V = cam.viewMat;
     const f3 ms = mk3(rp.modelScale[0], rp.modelScale[1], rp.modelScale[2]);
-    r.rnd = (float)parallel_rng3(gx, gy, rp.seed) / 4294967296.0f;
+    r.rnd = (float)parallel_rng3(gx, gy, seed) / 4294967296.0f;
 
     float gsx = (float)fr.gsx, gsy = (float)fr.gsy;
     float aspect = gsy / gsx;
@@ -463,7 +463,7 @@ VR_DEV Ray make_ray(uint32_t gx, uint32_t gy, const FrameView &fr, const vrhip_c
     else { icx -= aspect; icy -= 1.0f; }
     icy *= -1.f;
     float psx = 2.f / gsx, psy = 2.f / gsy;
-    float rnd2 = (float)parallel_rng3(gy, gx, 2u * rp.seed) / 4294967296.0f;
+    float rnd2 = (float)parallel_rng3(gy, gx, 2u * seed) / 4294967296.0f;
     icx += rnd2 * psx;
     icy += (-r.rnd) * psy;
 

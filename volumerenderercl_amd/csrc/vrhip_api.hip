@@ -90,6 +90,7 @@ struct vrhip_renderer {
     uint32_t *queue_head = nullptr;   // kControlWords: queue head, cont count, cont head, pad, sort bins + cursors
     uint16_t *cost = nullptr;         // per pixel: phase-2 rounds of the previous frame (sort key)
     uint32_t *order = nullptr;        // sorted permutation of the suspended rays
+    uint32_t *seeds_dev = nullptr;    // kMaxBatchFrames jitter seeds of a batch of frames
     bool sort_cont = true;            // VRHIP_NO_SORT=1 disables
     LiveTile *live = nullptr;         // DDA pre-pass output: patches with rays that sample
     bool prepass = true;              // VRHIP_NO_PREPASS=1 disables
@@ -499,9 +500,10 @@ int ensure_cells(vrhip_renderer *r)
 // Build (or reuse) the centre-first queue of 8x8 wave tiles.  tile_ids == nullptr: the whole
 // frame, `out` in frame layout; else the listed tiles, `out` compact [n][tile_h][tile_w].
 int ensure_queue(vrhip_renderer *r, uint32_t W, uint32_t H, uint32_t tile_w, uint32_t tile_h,
-                 const uint32_t *tile_ids, uint32_t n_tiles)
+                 const uint32_t *tile_ids, uint32_t n_tiles, uint32_t n_frames = 1,
+                 uint32_t frame_stride = 0)
 {
-    std::vector<uint32_t> key = {W, H, tile_w, tile_h, tile_ids ? 1u : 0u};
+    std::vector<uint32_t> key = {W, H, tile_w, tile_h, tile_ids ? 1u : 0u, n_frames, frame_stride};
     if (tile_ids) key.insert(key.end(), tile_ids, tile_ids + n_tiles);
     if (key == r->queue_key && r->queue_dev) return VRHIP_OK;
 
@@ -532,8 +534,17 @@ int ensure_queue(vrhip_renderer *r, uint32_t W, uint32_t H, uint32_t tile_w, uin
     }
     std::stable_sort(items.begin(), items.end(),
                      [](const Item &a, const Item &b) { return a.d2 < b.d2; });
-    std::vector<WaveTile> q(items.size());
-    for (size_t i = 0; i < items.size(); ++i) q[i] = items[i].wt;
+    // a batch of frames: every patch once per frame (frame index in the upper bits of ty8), the
+    // frames' outputs one after the other
+    const uint32_t frame_pixels = frame_stride ? frame_stride : (tile_ids ? n_tiles * tile_w * tile_h : W * H);
+    std::vector<WaveTile> q(items.size() * n_frames);
+    for (size_t i = 0; i < items.size(); ++i)
+        for (uint32_t f = 0; f < n_frames; ++f) {
+            WaveTile wt = items[i].wt;
+            wt.ty8 = (uint16_t)(wt.ty8 | (f << kFrameShift));
+            wt.out_base += f * frame_pixels;
+            q[i * n_frames + f] = wt;
+        }
 
     VR_HIP(r, hipStreamSynchronize(r->stream));
     if (q.size() > r->queue_cap) {
@@ -645,7 +656,8 @@ int launch_timed(vrhip_renderer *r, const RaycastLaunch &a)
 }
 
 int prepare_render(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t tile_w,
-                   uint32_t tile_h, const uint32_t *tile_ids, uint32_t n_tiles)
+                   uint32_t tile_h, const uint32_t *tile_ids, uint32_t n_tiles, uint32_t n_frames = 1,
+                   uint32_t frame_stride = 0)
 {
     int rc = check_renderable(r, width, height);
     if (rc) return rc;
@@ -673,7 +685,7 @@ int prepare_render(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t 
         rc = ensure_cells(r);
         if (rc) return rc;
     }
-    return ensure_queue(r, width, height, tile_w, tile_h, tile_ids, n_tiles);
+    return ensure_queue(r, width, height, tile_w, tile_h, tile_ids, n_tiles, n_frames, frame_stride);
 }
 
 int count_touched_impl(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t tile_w,
@@ -797,6 +809,7 @@ void vrhip_destroy(vrhip_renderer *r)
     for (uint8_t *p : {r->hit_in, r->hit_out, r->hit_status, r->hit_any})
         if (p) (void)hipFree(p);
     if (r->env) (void)hipFree(r->env);
+    if (r->seeds_dev) (void)hipFree(r->seeds_dev);
     if (r->fp) (void)hipFree(r->fp);
     if (r->live) (void)hipFree(r->live);
     if (r->order) (void)hipFree(r->order);
@@ -1232,6 +1245,40 @@ int vrhip_render_tiles(vrhip_renderer *r, uint32_t width, uint32_t height, uint3
     RaycastLaunch a;
     fill_launch(r, width, height, tile_w, &a);
     a.frame.out = (float4 *)out_tiles_dev;
+    return launch_timed(r, a);
+}
+
+int vrhip_render_batch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t tile_w,
+                       uint32_t tile_h, const uint32_t *tile_ids, uint32_t n_tiles,
+                       const uint32_t *seeds, uint32_t n_frames, float *out_dev,
+                       uint32_t out_frame_stride)
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    if (set_device(r)) return VRHIP_ERR_HIP;
+    VR_REQUIRE(r, out_dev && seeds, VRHIP_ERR_INVALID, "vrhip_render_batch: NULL argument");
+    VR_REQUIRE(r, n_frames >= 1 && n_frames <= kMaxBatchFrames, VRHIP_ERR_INVALID,
+               "vrhip_render_batch: 1..32 frames per batch");
+    VR_REQUIRE(r, height <= (8u << kFrameShift), VRHIP_ERR_INVALID, "Invalid output image size.");
+    VR_REQUIRE(r, !tile_ids || n_tiles > 0, VRHIP_ERR_INVALID, "vrhip_render_batch: empty tile list");
+    // the frames of a batch are independent: nothing that chains frames, nothing that draws from
+    // rendering_params.seed outside the ray set-up
+    const vrhip_rendering_params &rp = r->render;
+    VR_REQUIRE(r, rp.technique == 0 && rp.iteration == 0 && !rp.imgEss && !r->raycast.useAO,
+               VRHIP_ERR_UNSUPPORTED,
+               "vrhip_render_batch: ray caster only, iteration 0, no image-order ESS, no ambient occlusion");
+    const uint32_t packed = tile_ids ? n_tiles * tile_w * tile_h : width * height;
+    VR_REQUIRE(r, out_frame_stride == 0 || out_frame_stride >= packed, VRHIP_ERR_INVALID,
+               "vrhip_render_batch: frame stride smaller than a frame");
+    int rc = prepare_render(r, width, height, tile_w, tile_h, tile_ids, n_tiles, n_frames,
+                            out_frame_stride);
+    if (rc) return rc;
+    if (!r->seeds_dev) VR_HIP(r, hipMalloc((void **)&r->seeds_dev, kMaxBatchFrames * sizeof(uint32_t)));
+    VR_HIP(r, hipMemcpyAsync(r->seeds_dev, seeds, n_frames * sizeof(uint32_t), hipMemcpyHostToDevice,
+                             r->stream));
+    RaycastLaunch a;
+    fill_launch(r, width, height, tile_ids ? tile_w : width, &a);
+    a.frame.out = (float4 *)out_dev;
+    a.frame.seeds = r->seeds_dev;
     return launch_timed(r, a);
 }
 

@@ -245,6 +245,23 @@ class VolumeRenderCL:
                                                  int(tile_h), ids.ctypes.data_as(C.c_void_p),
                                                  int(ids.size), C.c_void_p(out_dev_ptr)))
 
+    def render_batch(self, width, height, seeds, out_dev_ptr, tile_w=0, tile_h=0, tile_ids=None,
+                     frame_stride=0):
+        """len(seeds) <= 32 independent frames (frame f jittered by seeds[f]) in one set of
+        launches (vrhip_render_batch): whole frames into out[f][height][width][4], or -- with
+        tile_ids -- the tile subset into out[f][n_tiles][tile_h][tile_w][4] (device memory);
+        frame_stride: pixels between the frames of `out` when they are not packed."""
+        if not self._vol_loaded:
+            return
+        self._rendering.iteration = 0
+        self._push_params()
+        sd = np.ascontiguousarray(seeds, dtype=np.uint32)
+        ids = None if tile_ids is None else np.ascontiguousarray(tile_ids, dtype=np.uint32)
+        self._check(self._lib.vrhip_render_batch(
+            self._h, int(width), int(height), int(tile_w), int(tile_h),
+            None if ids is None else ids.ctypes.data_as(C.c_void_p), 0 if ids is None else int(ids.size),
+            sd.ctypes.data_as(C.c_void_p), int(sd.size), C.c_void_p(out_dev_ptr), int(frame_stride)))
+
     # ---- volume
     def loadVolumeData(self, props):
         """volumerendercl.cpp:765-805. `props` is a datraw.Properties (dat_file_name or

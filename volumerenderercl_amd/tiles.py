@@ -158,6 +158,42 @@ class TileDriver:
         work = self.dist.gather(self.local[b], glist, dst=0, async_op=True)
         self.pending.append((b, n, work))
 
+    def submit_frames(self, seeds):
+        """len(seeds) <= batch independent frames (frame i jittered by seeds[i]) rendered in as few
+        launch sets as there are renderers on this rank (VolumeRenderCL.render_batch: the rank's
+        tile share of several frames in one work queue), then ONE gather for all of them."""
+        s = self.split
+        n = len(seeds)
+        if s.world == 1:
+            raise RuntimeError("submit/collect are for world > 1; use render_frame")
+        if not 1 <= n <= self.batch:
+            raise ValueError("1 <= n <= batch (%d) frames per gather" % self.batch)
+        if len(self.pending) >= 2:
+            raise RuntimeError("two gathers already in flight: collect first")
+        b = self.next_buf
+        self.next_buf ^= 1
+        lanes = self.lanes or [(self.vr, None)]
+        cur = self.torch.cuda.current_stream(self.device) if self.lanes else None
+        if cur is not None:
+            for _, ls in lanes:
+                if ls is not None and ls != cur:
+                    ls.wait_stream(cur)
+        per = -(-n // len(lanes))
+        stride = s.cap * s.th * s.tw
+        for j, (r, _) in enumerate(lanes):
+            lo, hi = j * per, min(n, (j + 1) * per)
+            if lo >= hi:
+                break
+            r.render_batch(s.W, s.H, seeds[lo:hi], self.local[b][lo].data_ptr(), s.tw, s.th,
+                           s.my_tiles, frame_stride=stride)
+        if cur is not None:
+            for _, ls in lanes:
+                if ls is not None and ls != cur:
+                    cur.wait_stream(ls)
+        glist = [self.staging[b][r] for r in range(s.world)] if s.rank == 0 else None
+        work = self.dist.gather(self.local[b], glist, dst=0, async_op=True)
+        self.pending.append((b, n, work))
+
     def collect(self, frame):
         """Finish the oldest frame in flight; returns the assembled frame on rank 0."""
         out = self.collect_batch(None if frame is None else frame.unsqueeze(0))
