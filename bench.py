@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--frames-per-launch", type=int, default=8,
                     help="independent frames (own jitter seeds) rendered by one set of launches "
                          "(vrhip_render_batch); 1 = one frame per launch set")
-    ap.add_argument("--round-budget", type=int, default=32,
+    ap.add_argument("--round-budget", type=int, default=48,
                     help="phase-1 sample rounds per ray when several frames are in flight")
     ap.add_argument("--frames-in-flight", type=int, default=2,
                     help="single GPU: renderers (one stream each, sharing the volume) that alternate "
