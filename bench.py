@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--workload", default="shells2048", choices=sorted(WORKLOADS))
     ap.add_argument("--viewport", type=int, default=1024)
     ap.add_argument("--tile", type=int, default=64, help="tile edge for the multi-GPU split")
-    ap.add_argument("--frames-per-gather", type=int, default=16,
+    ap.add_argument("--frames-per-gather", type=int, default=32,
                     help="multi-GPU: independent frames per RCCL gather")
     ap.add_argument("--frames-per-launch", type=int, default=8,
                     help="independent frames (own jitter seeds) rendered by one set of launches "
