@@ -1255,3 +1255,57 @@ def test_batch_of_frames_in_one_launch_set(vr, fmt, res, kw):
     with pytest.raises(RuntimeError):
         vr.render_batch(W, H, seeds[:2], out.data_ptr())
     vr.setAmbientOcclusion(False)
+
+
+def test_tile_driver_submit_frames_on_one_gpu(vr):
+    """TileDriver.submit_frames: the rank's tile share of several frames rendered as one launch
+    set per renderer (render_batch with the gather buffer's frame stride, which is larger than
+    the rank's own tile count here), gathered with a stand-in collective."""
+    import torch
+    from volumerenderercl_amd import tiles
+
+    class OneRankDist:
+        class _Done:
+            def wait(self):
+                pass
+
+        def __init__(self, rank):
+            self.rank = rank
+
+        def gather(self, tensor, gather_list, dst=0, async_op=False):
+            gather_list[self.rank].copy_(tensor)
+            return self._Done()
+
+    vol = common.noise_volume((48, 48, 48), UCHAR, seed=23, smooth=False)
+    tff = common.tffs()["default"]
+    W, H, T = 160, 96, 32
+    _setup(vr, vol, UCHAR, tff, common.views()["rot30"])
+    vr.setStatsEnabled(False)
+    dev = torch.device("cuda")
+    twin = vr.shareVolumes()
+    s2 = torch.cuda.Stream()
+    twin.set_stream(s2.cuda_stream)
+    vr.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        # the share of "rank 3 of 4", which has fewer tiles than the slot count of the gather
+        split = tiles.TileSplit(W, H, T, T, 4, 3)
+        assert len(split.my_tiles) < split.cap
+        split.rank = 0          # assemble locally; the stand-in puts the block where rank 3's goes
+        drv = tiles.TileDriver(vr, split, dev, dist=OneRankDist(3), batch=6,
+                               lanes=[(vr, torch.cuda.current_stream()), (twin, s2)])
+        seeds = [SEED, 581869302, 3890346734, 3586334585, 545404204]
+        frames = torch.zeros((6, H, W, 4), dtype=torch.float32, device=dev)
+        drv.submit_frames(seeds)
+        drv.collect_batch(frames)
+        torch.cuda.synchronize()
+        got = frames.cpu().numpy()
+        for i, seed in enumerate(seeds):
+            vr.setSeed(seed)
+            vr.setIteration(0)
+            full = vr.runRaycastNoGL(W, H)
+            for t in split.my_tiles:
+                x0, y0, w, h = split.tile_rect(t)
+                np.testing.assert_array_equal(got[i, y0:y0 + h, x0:x0 + w], full[y0:y0 + h, x0:x0 + w])
+    finally:
+        twin.close()
+        vr.set_stream(None, use_own=True)
