@@ -197,7 +197,12 @@ def main():
     # world > 1: `--frames-per-gather` independent frames share one collective (fewer, larger
     # gathers: the host-side cost of a collective is comparable to a rank's rendering time)
     fpg = max(1, min(args.frames_per_gather, args.steps))
-    driver = vtiles.TileDriver(vr, split, dev, batch=fpg)
+    fif = max(1, args.frames_in_flight) if technique == 0 else 1
+    fpl = max(1, min(args.frames_per_launch, 32)) if technique == 0 else 1
+    throughput = fif > 1 or fpl > 1
+    # (in throughput mode this driver only serves the warm-up and the untimed one-frame-at-a-time
+    # passes; the timed loop has its own, below)
+    driver = vtiles.TileDriver(vr, split, dev, batch=1 if throughput else fpg)
     frames = (torch.empty((fpg, H, W, 4), dtype=torch.float32, device=dev)
               if rank == 0 and world > 1 else None)
 
@@ -209,9 +214,6 @@ def main():
     # Frames in flight (single GPU; the path tracer's running mean chains its frames, so it keeps
     # one): the extra renderers share the first one's voxels and bricks (vrhip_share_volumes) and
     # own a stream, a frame buffer and scratch each.
-    fif = max(1, args.frames_in_flight) if technique == 0 else 1
-    fpl = max(1, min(args.frames_per_launch, 32)) if technique == 0 else 1
-    throughput = fif > 1 or fpl > 1
     if throughput:
         # throughput schedule: with other frames hiding the latency, rays stay longer in the
         # leaner one-lane phase (vrhip_set_round_budget; the serial pass below sets 10 again)
