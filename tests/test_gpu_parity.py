@@ -1309,3 +1309,25 @@ def test_tile_driver_submit_frames_on_one_gpu(vr):
     finally:
         twin.close()
         vr.set_stream(None, use_own=True)
+
+
+def test_batch_with_the_maximum_number_of_frames(vr):
+    """32 frames per batch: the frame index uses all five spare bits of the work items."""
+    import torch
+    vol = common.noise_volume((40, 40, 40), UCHAR, seed=35, smooth=False)
+    tff = common.tffs()["default"]
+    W, H = 72, 56
+    _setup(vr, vol, UCHAR, tff, common.views()["rot30"])
+    vr.setStatsEnabled(False)
+    mt = frontend.Mt19937()
+    seeds = [mt() for _ in range(32)]
+    out = torch.zeros((32, H, W, 4), dtype=torch.float32, device="cuda")
+    vr.render_batch(W, H, seeds, out.data_ptr())
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    for f in (0, 1, 15, 16, 30, 31):
+        vr.setSeed(seeds[f])
+        vr.setIteration(0)
+        assert np.array_equal(got[f], vr.runRaycastNoGL(W, H)), "frame %d" % f
+    with pytest.raises(ValueError):
+        vr.render_batch(W, H, seeds + [1], out.data_ptr())
