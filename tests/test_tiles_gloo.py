@@ -41,7 +41,9 @@ def _worker(rank, world, port, W, H, T, q):
     vol, tff, cam, rp, rc = _scene()
     split = tiles.TileSplit(W, H, T, T, world, rank)
 
-    def render_tiles(ids, out):
+    def render_tiles(ids, out, seed=None):
+        if seed is not None:
+            rp.seed = seed
         for k, t in enumerate(ids):
             x0, y0, w, h = split.tile_rect(t)
             img, _, _ = vro.render_tile(vol, vro.UCHAR, tff, cam, rp, rc, W=W, H=H,
@@ -79,6 +81,14 @@ def _worker(rank, world, port, W, H, T, q):
         o = drvb.collect_batch(frames)
         if rank == 0:
             batched += [o[i].numpy().copy() for i in range(n)]
+    # the same frames through submit_frames (seeds handed to the renderer, one gather per call)
+    drvf = tiles.TileDriver(None, split, torch.device("cpu"), render_tiles_fn=render_tiles, dist=dist,
+                            batch=5)
+    drvf.submit_frames(BATCH_SEEDS)
+    o = drvf.collect_batch(torch.zeros((5, H, W, 4)) if rank == 0 else None)
+    if rank == 0:
+        for i in range(5):
+            np.testing.assert_array_equal(o[i].numpy(), batched[i])
     if rank == 0:
         for o in outs:
             np.testing.assert_array_equal(o, first)
