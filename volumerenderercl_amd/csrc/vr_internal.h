@@ -119,6 +119,10 @@ struct FrameView {
     // phase 1 only visits the patches listed in `live`.  nullptr: phase 1 walks the whole queue.
     LiveTile *live;
     uint32_t *live_count;  // zeroed before each launch
+    // Default kernels: the pre-pass lists the live RAYS instead (with the DDA state they have
+    // reached; live_count counts them) and phase 1 runs on that list, one lane per ray, lanes
+    // refilled as rays end (vr_raycast_rays_kernel).  nullptr: the patch list above.
+    ContRec *live_rays;
     // Phase-2 scheduling: `cost` keeps, per pixel, the phase-2 rounds the pixel's ray needed in the
     // previous frame.  Suspended rays are sorted by it, longest first (counting sort into
     // `order`), so that the longest chains start first and the 16 rays of a group are alike.

@@ -769,6 +769,29 @@ __global__ __launch_bounds__(kBlockDim) void vr_dda_prepass_kernel(
         // what the march would leave for a ray without samples: background colour, alpha 0
         write_pixel<true>(fr, rp, c, d, voxLen, gx, gy, out_index);
     }
+    if (fr.live_rays) {
+        // ray list for phase 1 (vr_raycast_rays_kernel): the live rays with the DDA state they have
+        // reached, so that phase 1 neither repeats the walk nor carries the patch's dead lanes
+        if (m) {
+            uint32_t base = 0;
+            if (lane == (uint32_t)__builtin_ctzll(m))
+                base = atomicAdd(fr.live_count, (uint32_t)__builtin_popcountll(m));
+            base = __shfl(base, __builtin_ctzll(m), 64);
+            if (live) {
+                ContRec r;
+                r.pix = gx | (gy << 16);
+                r.out_index = (uint32_t)out_index;
+                r.state = d.state | (int32_t)(wt_frame(wt) << 8);
+                r.t = d.t; r.t_exit = d.t_exit; r.alpha = d.alpha;
+                r.r0 = d.r0; r.r1 = d.r1; r.r2 = d.r2;
+                r.cx = d.c0; r.cy = d.c1; r.cz = d.c2;
+                r.tv0 = d.tv0; r.tv1 = d.tv1; r.tv2 = d.tv2;
+                r.pad = 0;
+                fr.live_rays[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = r;
+            }
+        }
+        return;
+    }
     if (m && lane == 0) {
         const uint32_t slot = atomicAdd(fr.live_count, 1u);
         LiveTile lt;
@@ -776,6 +799,159 @@ __global__ __launch_bounds__(kBlockDim) void vr_dda_prepass_kernel(
         lt.mask_lo = (uint32_t)m;
         lt.mask_hi = (uint32_t)(m >> 32);
         fr.live[slot] = lt;
+    }
+}
+
+// ------------------------------------------------------------------ phase 1 on the ray list
+
+// Phase 1 for the default modes with ESS: one lane per ray, the rays taken from the pre-pass's ray
+// list (FrameView::live_rays) with the DDA state reached there; a lane whose ray ends -- or is
+// suspended for phase 2 after `round_budget` rounds of its own -- takes the next ray as soon as 16
+// lanes of the wave are idle.  Same per-ray operation sequence as the patch kernel above; no dead
+// lanes carried through a patch, no second DDA walk.  Exit condition reached by every wave: the
+// list head only grows, and every ray ends or is suspended.
+template <typename VT, bool SKIP_LDS, bool FP>
+__global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
+    VolView vv, BrickView bricks, TfView tf, SkipView skip, CellView cells, FrameView fr,
+    vrhip_camera_params cam, vrhip_rendering_params rp, vrhip_raycast_params rc)
+{
+    const uint32_t n_rays = *fr.live_count;   // written by the pre-pass (previous kernel on the stream)
+    if (n_rays == 0) return;
+    extern __shared__ float4 s_mem[];
+    float *s_stage = reinterpret_cast<float *>(s_mem) + (threadIdx.x >> 6) * kStageFloatsPerWave;
+    float4 *s_tff = s_mem + kStageF4;
+    uint32_t *s_skip = reinterpret_cast<uint32_t *>(s_tff + tf.tff_n);
+    for (uint32_t i = threadIdx.x; i < tf.tff_n; i += kBlockDim) s_tff[i] = tf.tff[i];
+    if (SKIP_LDS)
+        for (uint32_t i = threadIdx.x; i <= skip.n_words; i += kBlockDim) s_skip[i] = skip.bits[i];
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const int tffn = (int)tf.tff_n;
+    const Vol<VT, 0, FP> vol = make_vol<VT, 0, FP>(vv, nullptr);
+    const f3 resf = mk3(vol.fw, vol.fh, vol.fd);
+    const f3 voxLen = mk3(1.f / vol.fw, 1.f / vol.fh, 1.f / vol.fd);
+    const float refInterval = 1.f / rc.samplingRate;
+    const Grid grid = make_grid(bricks, rc, skip.n_words, true);
+    const uint32_t *sb = SKIP_LDS ? s_skip : skip.bits;
+    const bool skip_empty = cells.empty != nullptr && rp.useLinear != 0;
+    const uint32_t budget = fr.round_budget ? fr.round_budget : 0xffffffffu;
+    const uint32_t kRefillLanes = (fr.refill_min ? fr.refill_min : 16u) * 4u;   // idle lanes before a refill
+
+    unsigned long long n0 = 0, n1 = 0;
+    bool have = false, drained = false;
+    uint32_t gx = 0, gy = 0, out_index = 0, my_rounds = 0, frame_idx = 0;
+    bool guess_empty = true;
+    RayCtx c;
+    RayDyn d;
+    setup_ray<true>(0u, 0u, false, fr, cam, rp, rc, resf, voxLen, grid, c, d, rp.seed);   // S_DONE
+
+    for (;;) {
+        {
+            const bool idle = d.state == S_DONE;
+            const unsigned long long idle_m = __ballot(idle);
+            const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle_m);
+            const bool all_idle = idle_m == ~0ull;
+            if ((!drained && n_idle >= kRefillLanes) || all_idle) {
+                if (idle && have) {   // retire a finished ray (suspended ones have given up `have`)
+                    write_pixel<false>(fr, rp, c, d, voxLen, gx, gy, (size_t)out_index);
+                    have = false;
+                }
+                if (!drained) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(fr.queue_head, n_idle);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base + n_idle >= n_rays) drained = true;
+                    if (idle) {
+                        const uint32_t ri = base + (uint32_t)__builtin_popcountll(idle_m & ((1ull << lane) - 1ull));
+                        have = ri < n_rays;
+                        if (have) {
+                            const ContRec rec = fr.live_rays[ri];
+                            gx = rec.pix & 0xffffu;
+                            gy = rec.pix >> 16;
+                            out_index = rec.out_index;
+                            frame_idx = (uint32_t)rec.state >> 8;
+                            setup_ray<true>(gx, gy, true, fr, cam, rp, rc, resf, voxLen, grid, c, d,
+                                            fr.seeds ? fr.seeds[frame_idx] : rp.seed);
+                            d.state = rec.state & 0xff;
+                            d.t = rec.t; d.t_exit = rec.t_exit; d.alpha = rec.alpha;
+                            d.r0 = rec.r0; d.r1 = rec.r1; d.r2 = rec.r2;
+                            d.c0 = rec.cx; d.c1 = rec.cy; d.c2 = rec.cz;
+                            d.tv0 = rec.tv0; d.tv1 = rec.tv1; d.tv2 = rec.tv2;
+                            fetch_skip_word(sb, grid, d);
+                            my_rounds = 0;
+                            guess_empty = true;
+                        }
+                    }
+                }
+                if (!__ballot(d.state != S_DONE)) {
+                    if (drained) break;
+                    continue;
+                }
+            }
+        }
+        // ---- one round (the patch kernel's)
+        for (int it = 0;; ++it) {
+            if (!__ballot(d.state == S_BRICK)) break;
+            if (it >= kMaxBrickSteps && __ballot(d.state == S_SAMPLE)) break;
+            dda_step<0>(sb, grid, c, d, n0, n1);
+        }
+        if (!__ballot(d.state != S_DONE)) continue;
+        // a ray that has used its rounds goes to the continuation buffer (phase 2)
+        {
+            const bool susp = d.state != S_DONE && my_rounds >= budget;
+            const unsigned long long cm = __ballot(susp);
+            if (cm) {
+                uint32_t base = 0;
+                if (lane == (uint32_t)__builtin_ctzll(cm))
+                    base = atomicAdd(fr.cont_count, (uint32_t)__builtin_popcountll(cm));
+                base = __shfl(base, __builtin_ctzll(cm), 64);
+                if (susp) {
+                    ContRec r;
+                    r.pix = gx | (gy << 16);
+                    r.out_index = out_index;
+                    r.state = d.state | (int32_t)(frame_idx << 8);
+                    r.t = d.t; r.t_exit = d.t_exit; r.alpha = d.alpha;
+                    r.r0 = d.r0; r.r1 = d.r1; r.r2 = d.r2;
+                    r.cx = d.c0; r.cy = d.c1; r.cz = d.c2;
+                    r.tv0 = d.tv0; r.tv1 = d.tv1; r.tv2 = d.tv2;
+                    r.pad = fr.cost ? (uint32_t)fr.cost[(size_t)gy * fr.W + gx] : 0u;   // sort key
+                    fr.cont[base + (uint32_t)__builtin_popcountll(cm & ((1ull << lane) - 1ull))] = r;
+                    d.state = S_DONE;
+                    have = false;
+                }
+                if (!__ballot(d.state != S_DONE)) continue;
+            }
+        }
+        if (__ballot(d.state == S_SAMPLE)) my_rounds += d.state == S_SAMPLE ? 1u : 0u;
+        bool more_empty = false;
+        if (skip_empty && lookahead_pays(d.state == S_SAMPLE, guess_empty)) {
+            if (d.state == S_SAMPLE) {
+                const uint32_t em = empty_mask<VT, 0, kLook1>(cells, vol, c, d.t);
+                more_empty = skip_empty_run(em, c, d, false, n0);
+                guess_empty = (em & 1u) != 0u;
+                after_segment<true>(c, d);
+            }
+        }
+        if (d.state == S_SAMPLE && !more_empty) {
+            float tk[kBatch];
+            bool vk[kBatch], litk[kBatch];
+            tk[0] = d.t;
+            vk[0] = d.t < d.t_exit;   // inner loop condition (:790)
+#pragma unroll
+            for (int k = 1; k < kBatch; ++k) {
+                tk[k] = tk[k - 1] + c.stepSize;                                     // :879
+                vk[k] = vk[k - 1] && !(tk[k - 1] >= c.tfar) && (tk[k] < d.t_exit);  // :868, :790
+            }
+            float p0[kBatch], p1[kBatch], p2[kBatch], opk[kBatch];
+            eval_batch<VT, 0, false, FP>(vol, s_tff, tffn, s_stage, c, rp, rc, refInterval, tk, vk, p0, p1, p2,
+                                         opk, litk);
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k)
+                if (vk[k] && d.state == S_SAMPLE) composite(c, d, p0[k], p1[k], p2[k], opk[k], tk[k]);
+            if (vk[kBatch - 1]) guess_empty = opk[kBatch - 1] == 0.f;
+            after_segment<true>(c, d);
+        }
     }
 }
 
@@ -1340,6 +1516,7 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
     dim3 grid(want < cap ? want : cap), block(kBlockDim);
     if (grid.x == 0) return hipSuccess;
     FrameView frame = a.frame;
+    if (XS || INSTR != 0 || !ESS) frame.live_rays = nullptr;   // the ray list serves the default kernels
     if (ESS && INSTR == 0 && frame.live) {
         hipLaunchKernelGGL(vr_dda_prepass_kernel<VT>, dim3(want), block, 0, stream, a.vol, a.bricks,
                            a.skip, frame, a.cam, a.render, a.raycast);
@@ -1348,9 +1525,23 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
     } else {
         frame.live = nullptr;
     }
-    hipLaunchKernelGGL(k1, grid, block, lds, stream, a.vol, a.bricks, a.tf, a.skip, a.cells, frame, a.cam,
-                       a.render, a.raycast, a.stats, a.touched);
-    hipError_t e = hipGetLastError();
+    hipError_t e;
+    if (ESS && INSTR == 0 && !XS && frame.live && frame.live_rays) {   // phase 1 on the ray list
+        auto kr = vr_raycast_rays_kernel<VT, SKIP_LDS, FP>;
+        static int nbr = 0;
+        static size_t cached_ldsr = ~(size_t)0;
+        if (cached_ldsr != lds) {
+            e = prepare_variant(kr, lds, &nbr, "raycast phase 1 (ray list)", a.num_cus);
+            if (e != hipSuccess) return e;
+            cached_ldsr = lds;
+        }
+        hipLaunchKernelGGL(kr, dim3(cus * (uint32_t)nbr), block, lds, stream, a.vol, a.bricks, a.tf, a.skip,
+                           a.cells, frame, a.cam, a.render, a.raycast);
+    } else {
+        hipLaunchKernelGGL(k1, grid, block, lds, stream, a.vol, a.bricks, a.tf, a.skip, a.cells, frame, a.cam,
+                           a.render, a.raycast, a.stats, a.touched);
+    }
+    e = hipGetLastError();
     if (e == hipSuccess && a.mid_event) e = hipEventRecord(a.mid_event, stream);
     if (e != hipSuccess || a.frame.round_budget == 0) return e;
     if (a.frame.order) {   // longest rays first (keys: last frame's phase-2 rounds per pixel)

@@ -90,6 +90,8 @@ struct vrhip_renderer {
     uint32_t *queue_head = nullptr;   // kControlWords: queue head, cont count, cont head, pad, sort bins + cursors
     uint16_t *cost = nullptr;         // per pixel: phase-2 rounds of the previous frame (sort key)
     uint32_t *order = nullptr;        // sorted permutation of the suspended rays
+    ContRec *live_rays = nullptr;     // pre-pass output: live rays with their DDA state (phase 1's list)
+    bool ray_list = true;             // VRHIP_NO_RAYLIST=1: phase 1 walks the live patches instead
     uint32_t *seeds_dev = nullptr;    // kMaxBatchFrames jitter seeds of a batch of frames
     bool sort_cont = true;            // VRHIP_NO_SORT=1 disables
     LiveTile *live = nullptr;         // DDA pre-pass output: patches with rays that sample
@@ -571,6 +573,9 @@ int ensure_queue(vrhip_renderer *r, uint32_t W, uint32_t H, uint32_t tile_w, uin
         if (r->order) VR_HIP(r, hipFree(r->order));
         r->order = nullptr;
         VR_HIP(r, hipMalloc((void **)&r->order, need * sizeof(uint32_t)));
+        if (r->live_rays) VR_HIP(r, hipFree(r->live_rays));
+        r->live_rays = nullptr;
+        VR_HIP(r, hipMalloc((void **)&r->live_rays, need * sizeof(ContRec)));
         r->cont_cap = need;
     }
     return VRHIP_OK;
@@ -604,6 +609,7 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
     a->frame.round_budget = r->cont ? r->round_budget : 0;
     a->frame.refill_min = r->refill_min;
     a->frame.live = r->prepass ? r->live : nullptr;
+    a->frame.live_rays = (r->prepass && r->ray_list) ? r->live_rays : nullptr;
     a->frame.live_count = r->queue_head + 3;
     a->frame.cost = r->sort_cont ? r->cost : nullptr;
     a->frame.order = r->sort_cont && r->cost ? r->order : nullptr;
@@ -774,6 +780,7 @@ int vrhip_create(int device_id, vrhip_renderer **out)
     r->stream = r->own_stream;
     if (const char *b = getenv("VRHIP_ROUND_BUDGET")) r->round_budget = (uint32_t)atoi(b);   // tuning
     if (getenv("VRHIP_NO_PREPASS")) r->prepass = false;        // experiments: phase 1 walks every patch
+    if (getenv("VRHIP_NO_RAYLIST")) r->ray_list = false;       // experiments: phase 1 on live patches
     if (getenv("VRHIP_NO_SORT")) r->sort_cont = false;         // experiments: phase 2 in append order
     if (getenv("VRHIP_PT_NO_CULL")) r->pt_cull = false;        // experiments: no opacity-bound culling
     if (getenv("VRHIP_NO_EMPTY_SKIP")) r->skip_empty = false;  // experiments: no empty-run skipping
@@ -813,6 +820,7 @@ void vrhip_destroy(vrhip_renderer *r)
     if (r->fp) (void)hipFree(r->fp);
     if (r->live) (void)hipFree(r->live);
     if (r->order) (void)hipFree(r->order);
+    if (r->live_rays) (void)hipFree(r->live_rays);
     if (r->skip_bits) (void)hipFree(r->skip_bits);
     if (r->cell_bound) (void)hipFree(r->cell_bound);
     if (r->cell_empty) (void)hipFree(r->cell_empty);
