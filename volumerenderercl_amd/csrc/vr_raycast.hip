@@ -6,24 +6,30 @@
 // as explicit address arithmetic + loads following the OpenCL 1.2 image rules
 // (vr_sampling.h).
 //
-// Execution design (DESIGN.md "Kernels"):
-//  * PHASE 1 (vr_raycast_kernel): one lane per pixel, one wave64 per 8x8-pixel patch (the
-//    reference's work-group).  PERSISTENT workgroups sized to fill the 256 CUs; every wave
-//    pulls patches from a global queue ordered centre-first (dynamic load balance).  The
-//    transfer function (float4 table) and the ESS skip bitmap (1 bit per brick, precomputed
-//    from bricks + TF + prefix sum) live in LDS: a DDA step touches no global memory.  The
-//    reference's nested loops (DDA over bricks / samples inside a brick) are flattened into a
-//    per-lane state machine driven by wave ballots; each sample round evaluates up to kBatch
-//    consecutive samples of every ray as independent straight-line code.
+// Execution design, four launches per frame on one stream:
+//  * PRE-PASS (vr_dda_prepass_kernel, with ESS): one wave per 8x8-pixel patch (the reference's
+//    work-group) at high occupancy: ray set-up and the reference's DDA up to the first brick the
+//    ESS bitmap does not skip.  Rays that never reach one get their background pixel here; the
+//    others go to a ray list with the DDA state they have reached.
+//  * PHASE 1 (vr_raycast_rays_kernel on that list; vr_raycast_kernel on 8x8 patches for the
+//    instrumented / XS variants and without ESS): one lane per ray in PERSISTENT waves.  The
+//    transfer function (float4 table) and the ESS skip bitmap (1 bit per brick, precomputed from
+//    bricks + TF + prefix sum) live in LDS: a DDA step touches no global memory.  The reference's
+//    nested loops (DDA over bricks / samples inside a brick) are flattened into a per-lane state
+//    machine driven by wave ballots; each sample round evaluates up to kBatch consecutive samples
+//    of every ray as independent straight-line code.
 //  * The frame time of a ray caster on a machine this wide is set by its LONGEST rays: their
-//    samples form a serial chain.  So phase 1 marches every ray for at most `round_budget`
-//    sample rounds; rays still alive are SUSPENDED (13 words of state) and
+//    samples form a serial chain.  So phase 1 marches a ray for at most `round_budget` sample
+//    rounds; rays still alive are SUSPENDED (13 words of state), counting-sorted by the rounds
+//    their pixel needed in the previous frame (longest first), and
 //  * PHASE 2 (vr_raycast_split_kernel) resumes them with kSplit = 4 lanes per ray: each lane
 //    evaluates 4 of the ray's next 16 consecutive samples, then the 16 contributions are
-//    composited in ray order (in-quad DPP broadcasts).  The chain of a long ray shrinks 4x
-//    and the tail of the frame is re-balanced over the whole chip.
-//  The per-ray sequence of t values and of fp32 operations is exactly the reference's in both
-//  phases, so the image is bit-identical whatever the budget.
+//    composited in ray order (in-quad DPP broadcasts).  The chain of a long ray shrinks 4x; the
+//    16 ray slots of a wave draw their rays one by one from the sorted list.
+//  Several independent frames (jitter seeds) can share one set of these launches: the work items
+//  carry a frame index (vrhip_render_batch).
+//  The per-ray sequence of t values and of fp32 operations is exactly the reference's in every
+//  kernel, so the image is bit-identical whatever the schedule (budget, refill, batch, lists).
 #include "vr_sampling.h"
 
 namespace {
