@@ -71,6 +71,11 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="target CPU work for the bounded cpu_baseline sample")
     ap.add_argument("--view", default="rot30", choices=["default", "rot30"])
+    ap.add_argument("--profile-region", action="store_true",
+                    help="warm-up + the timed region only (no one-frame-at-a-time pass, no instrumented "
+                         "pass, no CPU baseline): a rocprofv3 --kernel-trace --stats of this command "
+                         "holds the timed launches and nothing else after the warm-up")
+    ap.add_argument("--out-json", default=None, help="also write the JSON line to this file")
     return ap.parse_args()
 
 
@@ -87,18 +92,21 @@ def cpu_baseline(vr, vol_host, bricks_host, tff, fmt, W, H, target_s, seeds, use
     prefix = vro.prefix_sum(tff)
     cores = host_cpu_share()
     frames, samples, secs = 0, 0, 0.0
+    first = None
     for seed in seeds:
         orp.seed = seed
         orp.iteration = 0
         t0 = time.perf_counter()
-        _, st, _ = vro.render_tile(vol_host, fmt, tff, ocam, orp, orc, opt, use_ess=use_ess,
-                                   W=W, H=H, bricks=bricks_host, prefix=prefix, threads=cores)
+        img, st, _ = vro.render_tile(vol_host, fmt, tff, ocam, orp, orc, opt, use_ess=use_ess,
+                                     W=W, H=H, bricks=bricks_host, prefix=prefix, threads=cores)
         secs += time.perf_counter() - t0
+        if first is None:
+            first = (seed, img, st)     # the checker's frame for the first timed seed
         samples += st["samples_taken"]
         frames += 1
         if secs >= target_s:
             break
-    return {
+    return first, {
         "value": samples / secs / 1e6 if secs > 0 else 0.0,
         "unit": "Msamples/s",
         "cores": int(cores),
@@ -126,6 +134,21 @@ def pmc_traffic(workload):
     return None
 
 
+def pmc_issue(workload):
+    """VALU wave-instructions per frame of the timed ray-cast launches, from the committed
+    rocprofv3 --pmc pass of `bench.py --profile-region` (profiles/<round>/pmc_issue.json, written
+    by tools/pmc_issue.py).  None when no profile of this workload is committed."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_issue.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if workload in d:
+            return d[workload]
+    return None
+
+
 def host_cpu_share():
     """Threads this process may actually use: min(affinity mask, cgroup cpu quota)."""
     n = len(os.sched_getaffinity(0))
@@ -140,6 +163,7 @@ def host_cpu_share():
 
 def main():
     args = parse()
+    parity_failed = False
     import torch
     import torch.distributed as dist
 
@@ -295,6 +319,26 @@ def main():
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
     wall = float(wall_t.item())
 
+    if args.profile_region:
+        # nothing but warm-up + timed launches has run: for rocprofv3 --kernel-trace --stats / --pmc
+        if rank == 0:
+            line = json.dumps({
+                "profile_region": True, "workload": args.workload, "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+                "avg_launch_ms": gpu_region_s / args.steps * 1e3,
+                "frames_in_flight": fif, "frames_per_launch": fpl,
+                "round_budget": args.round_budget if throughput else 10,
+                "launch_sets_in_region": len(blocks) if (world == 1 and throughput) else args.steps,
+                "note": "timed region only; work counters, roofline and cpu_baseline come from the full run"})
+            print(line, flush=True)
+            if args.out_json:
+                open(args.out_json, "w").write(line + "\n")
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        vr.close()
+        return
+
     # ---- untimed: the same frames one at a time (what one launch takes when it has the GPU to itself)
     serial_s = None
     if throughput:
@@ -328,7 +372,9 @@ def main():
 
     # ---- untimed: compulsory traffic of ONE launch on rank 0 (first timed seed)
     roofline = None
+    roofline_valu = None
     cpu = None
+    parity = None
     if rank == 0:
         vr.setSeed(seeds[args.warmup])
         vr.setIteration(0)
@@ -384,13 +430,55 @@ def main():
             "note": "not HBM-bound: a latency/issue-bound march (DESIGN.md 'Kernels'); the "
                     "streaming kernel of the path is vr_build_bricks (see bricks_build)",
         }
+        # What actually bounds the march: VALU issue.  A gfx950 SIMD issues one wave64 VALU
+        # instruction per 2 cycles (MI355X_MICROARCH.md "Wave scheduling"; = the 157.3 TFLOP/s fp32
+        # vector peak / 128 flops), so the chip peaks at 256 CUs x 4 SIMDs x 2.4 GHz / 2.
+        issue = pmc_issue(args.workload) if world == 1 else None
+        if issue:
+            peak_wi = 256 * 4 * 2.4e9 / 2.0
+            ach_wi = issue["valu_wave_insts_per_frame"] / kernel_s
+            roofline_valu = {
+                "bound": "valu_issue",
+                "achieved": ach_wi / 1e9,
+                "peak": peak_wi / 1e9,
+                "unit": "G wave-instructions/s",
+                "frac": ach_wi / peak_wi,
+                "valu_wave_insts_per_frame": issue["valu_wave_insts_per_frame"],
+                "valu_lane_utilisation": issue.get("valu_lane_utilisation"),
+                "source": issue.get("source"),
+                "note": "SQ_INSTS_VALU of the timed launches (rocprofv3 --pmc of `bench.py --profile-region`, "
+                        "committed under profiles/) / frames, over this run's avg_launch_ms",
+            }
         if world == 1 and not args.no_cpu_baseline:
             vol_host = vr.downloadVolume()
             bricks_host = vr.downloadBricks()
             cpu_seeds = seeds[args.warmup:] + [mt() for _ in range(2000)]   # bounded by cpu_seconds
-            cpu = cpu_baseline(vr, vol_host, bricks_host, tff, fmt, W, H, args.cpu_seconds,
-                               cpu_seeds, use_ess=ess)
+            first, cpu = cpu_baseline(vr, vol_host, bricks_host, tff, fmt, W, H, args.cpu_seconds,
+                                      cpu_seeds, use_ess=ess)
             del vol_host
+            # ---- the checker's frame for the first timed seed against the GPU's: the production
+            # kernels' image and the instrumented kernels' image + six work counters (technique 1
+            # chains its frames through the running mean: iteration 0 = a frame on its own)
+            seed0, ref_img, ref_st = first
+            vr.setSeed(seed0)
+            vr.setIteration(0)
+            vr.setStatsEnabled(False)
+            gpu_img = vr.runRaycastNoGL(W, H)
+            vr.setIteration(0)
+            vr.setStatsEnabled(True)
+            gpu_img_i = vr.runRaycastNoGL(W, H)
+            gpu_st = vr.getStats()
+            vr.setStatsEnabled(False)
+            if technique == 1:   # the path tracer's brick counters count its culling, not bricks
+                gpu_st = dict(gpu_st, bricks_visited=0, bricks_skipped=0)
+            parity = {
+                "max_abs_diff": float(max(np.abs(gpu_img.astype(np.float64) - ref_img).max(),
+                                          np.abs(gpu_img_i.astype(np.float64) - ref_img).max())),
+                "tolerance": 1e-4,
+                "counters_equal": gpu_st == ref_st,
+                "frame": "first timed seed %d, %dx%d, production (un-instrumented) and instrumented "
+                         "kernels vs the oracle frame of the cpu_baseline leg" % (seed0, W, H),
+            }
 
     if rank == 0:
         out = {
@@ -424,6 +512,9 @@ def main():
                                if world > 1 else "single GPU, full frames, %d renderer(s) x %d frames per "
                                                  "launch set" % (fif, fpl),
             },
+            "value_note": "samples TAKEN = inner-loop bodies the reference executes after ESS/ERT; those that lie in "
+                          "provably empty cells (opacity exactly 0) are stepped over without a voxel fetch and still "
+                          "count, as the reference takes them",
             "msamples_nominal_per_s": work["samples_nominal"] / wall / 1e6,
             "work_per_frame": {k: v // args.steps for k, v in work.items()},
             "bricks_build": {
@@ -433,13 +524,24 @@ def main():
                                   if bricks_s > 0 else None),
             },
             "roofline": roofline,
+            "roofline_valu_issue": roofline_valu,
             "cpu_baseline": cpu,
+            "parity": parity,
+            "parity_max_abs_diff": parity["max_abs_diff"] if parity else None,
         }
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
+        print(line, flush=True)
+        if args.out_json:
+            open(args.out_json, "w").write(line + "\n")
+        if parity and not (parity["max_abs_diff"] <= parity["tolerance"] and parity["counters_equal"]):
+            sys.stderr.write("bench.py: PARITY FAILURE against the oracle: %s\n" % json.dumps(parity))
+            parity_failed = True
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     vr.close()
+    if parity_failed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -99,6 +99,10 @@ int vrhip_device_name(const vrhip_renderer *r, char *buf, size_t buf_len);
 /* Launch on a caller-owned hipStream_t (e.g. torch's current stream; NULL is the legacy
  * default stream) instead of the renderer's own stream; use_own != 0 restores the latter. */
 int vrhip_set_stream(vrhip_renderer *r, void *hip_stream, int use_own);
+/* The hipStream_t the renderer launches on right now (its own stream unless vrhip_set_stream
+ * gave it another): render calls return without synchronising, so whoever consumes a frame on
+ * another stream (a collective, a copy) orders that stream behind this one. */
+int vrhip_get_stream(const vrhip_renderer *r, void **hip_stream);
 
 /* ---- volume: volDataToCLmem (volumerendercl.cpp:690-759) ----------------------- */
 /* Dense x-fastest scalar field (CL_R image) of `format`, host memory. */
@@ -138,7 +142,9 @@ int vrhip_set_round_budget(vrhip_renderer *r, uint32_t rounds);
  * buffers, footprint volume, stream) is its own, so two renderers on two streams can
  * have one frame each in flight over one 8 GiB volume.  The owner must keep its volumes (no upload,
  * clear or destroy) while they are shared; `r` gives them back with vrhip_clear_volumes or by
- * uploading its own.  vrhip_build_bricks on `r` keeps the shared bricks. */
+ * uploading its own.  vrhip_build_bricks on `r` keeps the shared bricks, and on the owner it
+ * never moves them: a brick grid is allocated once per time step and rebuilt only after that
+ * step's voxels were uploaded again, so transfer-function edits on either renderer are safe. */
 int vrhip_share_volumes(vrhip_renderer *r, vrhip_renderer *owner);
 int vrhip_clear_volumes(vrhip_renderer *r);
 /* setTimestep (volumerendercl.cpp:1167-1174) */

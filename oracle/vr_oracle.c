@@ -48,12 +48,37 @@ static inline f3 scale3(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); 
 static inline f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
 static inline f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
 static inline f3 neg3(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+/*
+ * LITERAL mode (vro_set_literal(1); CPU tests only): every place where the parity definitions
+ * above re-associate, re-factor or approximate what the reference's source text says is
+ * evaluated the way the text says instead -- gradients as six (27) full read_imagef at
+ * pos -+ 1/res (volumeraycast.cl:159-178, :217-277), image reads with the per-texel
+ * normalised conversion c / 255.0f (c / 65535.0f) BEFORE the filter and the filter as the
+ * weighted sum of OpenCL 1.2 spec 8.2, native_powr / log / sin / cos / atan2 / acos by libm,
+ * normalize (:289) as v / |v|.  tests/test_oracle_literal.py bounds |literal - parity| <= 1e-4 per
+ * channel on every parity scene: the definitions the HIP kernel shares with this file are
+ * then within north_star's tolerance of the literal reading, not merely equal to each other.
+ */
+static int g_literal = 0;
+void vro_set_literal(int on) { g_literal = on ? 1 : 0; }
+int vro_get_literal(void) { return g_literal; }
+
 static inline f3 normalize3(f3 v)
 {
     float d = dot3(v, v);
     if (d == 0.0f) return mk3(0.0f, 0.0f, 0.0f); /* SURVEY C5 */
     float inv = 1.0f / sqrtf(d);
     return scale3(v, inv);
+}
+/* `normalize` proper (only :289, the half vector): LITERAL mode divides by the length.  The
+ * fast_normalize / fast_length / native_divide calls have no literal form -- OpenCL leaves
+ * their precision to the implementation -- and keep the parity definition in both modes. */
+static inline f3 normalize3_full(f3 v)
+{
+    if (!g_literal) return normalize3(v);
+    float l = sqrtf(dot3(v, v));
+    if (l == 0.0f) return mk3(0.0f, 0.0f, 0.0f);
+    return mk3(v.x / l, v.y / l, v.z / l);
 }
 static inline float lerpf(float p, float q, float w) { return fmaf(w, q - p, p); }
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
@@ -95,6 +120,7 @@ float vro_map_uint_float(uint32_t v) { return (float)v / 4294967296.0f; }
  */
 float vro_powr(float x, float y)
 {
+    if (g_literal) return powf(x, y);
     if (!(x > 0.0f)) return (x == 0.0f) ? 0.0f : NAN;
     /* ---- log(x) = e*ln2 + log(m), m in [sqrt(1/2), sqrt(2)) */
     uint32_t ux = f2u(x);
@@ -242,6 +268,18 @@ static inline float vox_raw_c(const vol_t *v, int x, int y, int z, int ch)
 /* the .x component every single-channel reader of the kernel looks at */
 static inline float vox_raw(const vol_t *v, int x, int y, int z) { return vox_raw_c(v, x, y, z, 0); }
 
+/* LITERAL mode: a texel as the image unit hands it to the filter -- CL_UNORM_INT8/16 converted
+ * with c / 255.0f (c / 65535.0f), OpenCL 1.2 spec 8.3.1.1; CL_FLOAT as stored */
+static inline float vox_norm_c(const vol_t *v, int x, int y, int z, int ch)
+{
+    float raw = vox_raw_c(v, x, y, z, ch);
+    switch (v->s->format) {
+    case VRO_UCHAR: return raw / 255.0f;
+    case VRO_USHORT: return raw / 65535.0f;
+    default: return raw;
+    }
+}
+
 /* linearSmp (volumeraycast.cl:30-31) on the CL_R volume: OpenCL 1.2 spec 8.2,
  * normalised coords, CLAMP_TO_EDGE, LINEAR. */
 static float vol_linear_c(const vol_t *v, float px, float py, float pz, int ch)
@@ -254,6 +292,14 @@ static float vol_linear_c(const vol_t *v, float px, float py, float pz, int ch)
     int x0 = iclamp(ix, 0, v->w - 1), x1 = iclamp(ix + 1, 0, v->w - 1);
     int y0 = iclamp(iy, 0, v->h - 1), y1 = iclamp(iy + 1, 0, v->h - 1);
     int z0 = iclamp(iz, 0, v->d - 1), z1 = iclamp(iz + 1, 0, v->d - 1);
+    if (g_literal) {
+        /* spec 8.2: T = (1-a)(1-b)(1-c) T000 + a(1-b)(1-c) T100 + ... + a b c T111 */
+        float a1 = 1.0f - a, b1 = 1.0f - b, c1 = 1.0f - c;
+        return a1 * b1 * c1 * vox_norm_c(v, x0, y0, z0, ch) + a * b1 * c1 * vox_norm_c(v, x1, y0, z0, ch) +
+               a1 * b * c1 * vox_norm_c(v, x0, y1, z0, ch) + a * b * c1 * vox_norm_c(v, x1, y1, z0, ch) +
+               a1 * b1 * c * vox_norm_c(v, x0, y0, z1, ch) + a * b1 * c * vox_norm_c(v, x1, y0, z1, ch) +
+               a1 * b * c * vox_norm_c(v, x0, y1, z1, ch) + a * b * c * vox_norm_c(v, x1, y1, z1, ch);
+    }
     float c00 = lerpf(vox_raw_c(v, x0, y0, z0, ch), vox_raw_c(v, x1, y0, z0, ch), a);
     float c10 = lerpf(vox_raw_c(v, x0, y1, z0, ch), vox_raw_c(v, x1, y1, z0, ch), a);
     float c01 = lerpf(vox_raw_c(v, x0, y0, z1, ch), vox_raw_c(v, x1, y0, z1, ch), a);
@@ -275,6 +321,7 @@ static float vol_nearest_c(const vol_t *v, float px, float py, float pz, int ch)
     if (!(fx >= 0.0f && fx <= (float)(v->w - 1) && fy >= 0.0f && fy <= (float)(v->h - 1) &&
           fz >= 0.0f && fz <= (float)(v->d - 1)))
         return 0.0f;
+    if (g_literal) return vox_norm_c(v, (int)fx, (int)fy, (int)fz, ch);
     return vox_raw_c(v, (int)fx, (int)fy, (int)fz, ch) * v->inv_max;
 }
 
@@ -296,7 +343,7 @@ static void tff_linear(const vro_scene *s, float x, float out[4])
     for (int c = 0; c < 4; ++c) {
         float t0 = (float)s->tff[4 * (size_t)i0 + c] / 255.0f;
         float t1 = (float)s->tff[4 * (size_t)i1 + c] / 255.0f;
-        out[c] = lerpf(t0, t1, a);
+        out[c] = g_literal ? (1.0f - a) * t0 + a * t1 : lerpf(t0, t1, a);
     }
 }
 
@@ -323,10 +370,18 @@ static void brick_minmax(const vol_t *v, int cx, int cy, int cz, float *mn, floa
     case VRO_UCHAR:
         *mn = (float)((const uint8_t *)v->s->bricks)[i] * v->inv_max;
         *mx = (float)((const uint8_t *)v->s->bricks)[i + 1] * v->inv_max;
+        if (g_literal) {
+            *mn = (float)((const uint8_t *)v->s->bricks)[i] / 255.0f;
+            *mx = (float)((const uint8_t *)v->s->bricks)[i + 1] / 255.0f;
+        }
         break;
     case VRO_USHORT:
         *mn = (float)((const uint16_t *)v->s->bricks)[i] * v->inv_max;
         *mx = (float)((const uint16_t *)v->s->bricks)[i + 1] * v->inv_max;
+        if (g_literal) {
+            *mn = (float)((const uint16_t *)v->s->bricks)[i] / 65535.0f;
+            *mx = (float)((const uint16_t *)v->s->bricks)[i + 1] / 65535.0f;
+        }
         break;
     default:
         *mn = ((const float *)v->s->bricks)[i];
@@ -378,8 +433,31 @@ static float vol_tri(const vol_t *v, const int xi[2], const int yi[2], const int
  * coordinate add (<= 2^-12 texel at 2048^3, below the 8-bit weight precision of the
  * texture units the reference ran on) and is the parity definition shared with the HIP
  * kernel, which reuses the 4x4x4-neighbourhood loads between taps (32 instead of 56). */
+static float vol_linear(const vol_t *v, float px, float py, float pz);
+
+/* LITERAL mode: s1 / s2 of gradientCentralDiff exactly as written (:161-171): six full image
+ * reads at pos -+ offset, offset = 1 / volRes */
+static void central_diff_taps_literal(const vol_t *v, f3 pos, f3 *s1, f3 *s2)
+{
+    f3 off = mk3(1.0f / v->fw, 1.0f / v->fh, 1.0f / v->fd);
+    s1->x = vol_linear(v, pos.x + (-off.x), pos.y + 0.0f, pos.z + 0.0f);
+    s1->y = vol_linear(v, pos.x + 0.0f, pos.y + (-off.y), pos.z + 0.0f);
+    s1->z = vol_linear(v, pos.x + 0.0f, pos.y + 0.0f, pos.z + (-off.z));
+    s2->x = vol_linear(v, pos.x + off.x, pos.y + 0.0f, pos.z + 0.0f);
+    s2->y = vol_linear(v, pos.x + 0.0f, pos.y + off.y, pos.z + 0.0f);
+    s2->z = vol_linear(v, pos.x + 0.0f, pos.y + 0.0f, pos.z + off.z);
+}
+
 static f3 neg_gradient_central_diff(const vol_t *v, f3 pos)
 {
+    if (g_literal) {
+        f3 s1, s2;
+        central_diff_taps_literal(v, pos, &s1, &s2);
+        f3 g = sub3(s2, s1);
+        f3 n = normalize3(g);
+        if (len3(n) == 0.0f) n = mk3(0.57735f, 0.57735f, 0.57735f);   /* :174-175 */
+        return neg3(n);
+    }
     float ub = pos.x * v->fw - 0.5f, vb = pos.y * v->fh - 0.5f, wb = pos.z * v->fd - 0.5f;
     float fx = floorf(ub), fy = floorf(vb), fz = floorf(wb);
     float a = ub - fx, b = vb - fy, c = wb - fz;
@@ -408,6 +486,11 @@ static f3 neg_gradient_central_diff(const vol_t *v, f3 pos)
  * illumType 4 feeds to the transfer function (:796-799). */
 static float gradient_central_diff_len(const vol_t *v, f3 pos)
 {
+    if (g_literal) {
+        f3 s1, s2;
+        central_diff_taps_literal(v, pos, &s1, &s2);
+        return len3(sub3(s2, s1));
+    }
     float ub = pos.x * v->fw - 0.5f, vb = pos.y * v->fh - 0.5f, wb = pos.z * v->fd - 0.5f;
     float fx = floorf(ub), fy = floorf(vb), fz = floorf(wb);
     float a = ub - fx, b = vb - fy, c = wb - fz;
@@ -441,6 +524,21 @@ static f3 neg_gradient_sobel(const vol_t *v, f3 pos)
     float a = ub - fx, b = vb - fy, c = wb - fz;
     int ix = (int)fx, iy = (int)fy, iz = (int)fz;
     float gx = 0.f, gy = 0.f, gz = 0.f;
+    if (g_literal) { /* :254-269: 27 full image reads at pos + offset * (i, j, k) */
+        f3 off = mk3(1.0f / v->fw, 1.0f / v->fh, 1.0f / v->fd);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                for (int k = 0; k < 3; ++k) {
+                    float smp = vol_linear(v, pos.x + off.x * (float)(i - 1), pos.y + off.y * (float)(j - 1),
+                                           pos.z + off.z * (float)(k - 1));
+                    gx = gx + ((dw[i] * sw[j]) * sw[k]) * smp;
+                    gy = gy + ((sw[i] * dw[j]) * sw[k]) * smp;
+                    gz = gz + ((sw[i] * sw[j]) * dw[k]) * smp;
+                }
+        f3 gl = mk3(gx / 27.f, gy / 27.f, gz / 27.f);
+        if (len3(gl) == 0.f) gl = mk3(1.f, 1.f, 1.f);
+        return neg3(normalize3(gl));
+    }
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j)
             for (int k = 0; k < 3; ++k) {
@@ -473,7 +571,7 @@ static float specular_blinn_phong(f3 normal, f3 toLightDir, f3 toCameraDir)
 {
     f3 h = add3(toCameraDir, toLightDir);
     if (dot3(h, h) < 1.e-6f) return 0.0f;
-    h = normalize3(h);
+    h = normalize3_full(h);
     return (1.0f * 1.0f) * vro_powr(vmax(dot3(normal, h), 0.f), 40.f);
 }
 
@@ -597,6 +695,7 @@ static inline int in_volume(f3 p) /* volumeraycast.cl:93-96 */
  * 456-459): fixed fp32 operation sequences shared verbatim with the HIP kernel. */
 static float vro_logf(float x) /* x in (0, 1] here */
 {
+    if (g_literal) return logf(x);
     if (!(x > 0.0f)) return -INFINITY;
     uint32_t ux = f2u(x);
     int e = 0;
@@ -633,6 +732,7 @@ static float vro_logf(float x) /* x in (0, 1] here */
 /* sin and cos of x in [0, 2*pi]: quadrant reduction + Cephes sinf/cosf kernels */
 static void vro_sincosf(float x, float *s, float *c)
 {
+    if (g_literal) { *s = sinf(x); *c = cosf(x); return; }
     float q = floorf(fmaf(x, 0.63661977236758134f, 0.5f)); /* nearest multiple of pi/2 */
     float r = fmaf(q, -1.5703125f, x);
     r = fmaf(q, -4.837512969970703125e-4f, r);
@@ -672,6 +772,7 @@ static float atan_pos(float x) /* x >= 0, +inf allowed */
 
 float vro_atan2f(float y, float x)
 {
+    if (g_literal) return atan2f(y, x);
     float ax = fabsf(x), ay = fabsf(y);
     float a = (ax == 0.0f && ay == 0.0f) ? 0.0f : atan_pos(ay / ax);
     if (x < 0.0f) a = 3.14159265358979323846f - a;
@@ -690,6 +791,7 @@ static float asin_kernel(float z, float s) /* asin(s) for z = s*s <= 0.25 */
 
 float vro_acosf(float x) /* x in [-1, 1] */
 {
+    if (g_literal) return acosf(x);
     float a = fabsf(x);
     if (a > 0.5f) {
         float z = 0.5f * (1.0f - a);
@@ -716,6 +818,10 @@ static void env_lookup(const vro_frame_extras *ex, f3 dir, float out[4])
         float t0 = lerpf(p[4 * ((size_t)y0 * w + x0) + c], p[4 * ((size_t)y0 * w + x1) + c], a);
         float t1 = lerpf(p[4 * ((size_t)y1 * w + x0) + c], p[4 * ((size_t)y1 * w + x1) + c], a);
         out[c] = lerpf(t0, t1, b);
+        if (g_literal) /* spec 8.2, 2-D: (1-a)(1-b) T00 + a(1-b) T10 + (1-a) b T01 + a b T11 */
+            out[c] = (1.0f - a) * (1.0f - b) * p[4 * ((size_t)y0 * w + x0) + c] +
+                     a * (1.0f - b) * p[4 * ((size_t)y0 * w + x1) + c] +
+                     (1.0f - a) * b * p[4 * ((size_t)y1 * w + x0) + c] + a * b * p[4 * ((size_t)y1 * w + x1) + c];
     }
 }
 

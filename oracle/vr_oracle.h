@@ -172,6 +172,13 @@ int vro_synth_volume(int kind, const uint32_t res[3], int format, void *out);
 
 int vro_num_threads(void);
 
+/* LITERAL mode (CPU tests only, see vr_oracle.c): evaluate gradients, image reads and the
+ * transcendental builtins the way the reference's source text reads instead of through the
+ * parity definitions shared with the HIP kernel.  Process-wide switch; not thread-safe
+ * against a render in progress. */
+void vro_set_literal(int on);
+int vro_get_literal(void);
+
 #ifdef __cplusplus
 }
 #endif

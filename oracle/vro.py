@@ -192,11 +192,13 @@ def hit_image_init(W, H):
 
 def render_tile(vol, fmt, tff, cam, rp, rc, pt=None, use_ess=True, W=64, H=64, tile=None,
                 in_accum=None, bricks=None, prefix=None, want_touched=False, threads=0,
-                hit_in=None, hit_out=None, env=None):
+                hit_in=None, hit_out=None, env=None, literal=False):
     """Render the tile (x0, y0, w, h) of a W x H frame with the oracle.
 
     hit_in / hit_out: image-order ESS state (uint8 [(H/8+1), (W/8+1)], hit_out is updated in
     place); env: environment map, float32 [h, w, 4].
+    literal: evaluate the reference's source text literally (vro_set_literal) instead of the parity
+    definitions shared with the HIP kernel -- CPU tests bound the difference.
     Returns (rgba float32 [h, w, 4], stats dict, touched-bitmap or None).
     """
     vol = np.ascontiguousarray(vol, dtype=_NP_DTYPE[fmt])
@@ -242,12 +244,14 @@ def render_tile(vol, fmt, tff, cam, rp, rc, pt=None, use_ess=True, W=64, H=64, t
     if env is not None:
         env = np.ascontiguousarray(env, dtype=np.float32)
         ex.env_rgba, ex.env_w, ex.env_h = env.ctypes.data, env.shape[1], env.shape[0]
+    lib().vro_set_literal(1 if literal else 0)
     r = lib().vro_render_tile_ex(C.byref(sc), C.byref(cam), C.byref(rp), C.byref(rc), C.byref(pt),
                                  1 if use_ess else 0, W, H, x0, y0, w, h,
                                  acc.ctypes.data if acc is not None else None,
                                  out.ctypes.data, C.byref(st),
                                  touched.ctypes.data if touched is not None else None, threads,
                                  C.byref(ex))
+    lib().vro_set_literal(0)
     if r != 0:
         raise RuntimeError("vro_render_tile failed: %d" % r)
     return out, st.as_dict(), touched

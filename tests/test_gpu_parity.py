@@ -8,6 +8,8 @@ import pytest
 
 from oracle import vro
 from tests import common
+from tests import scenes
+from tests.scenes import CASES, FP_CASES, MC_CASES, PT_CASES
 from volumerenderercl_amd import FLOAT, UCHAR, USHORT, VolumeRenderCL, frontend
 
 pytestmark = pytest.mark.gpu
@@ -52,10 +54,15 @@ def _setup(vr, vol, fmt, tff, view, **kw):
 
 
 def _compare(vr, vol, fmt, tff, W, H, ess=True, pathtrace=False):
+    """One frame through the INSTRUMENTED kernels (stats on: images + the six work counters) and
+    the same frame through the PRODUCTION kernels (stats off: DDA pre-pass, ray list, two-phase
+    march, footprint volume where it applies) -- both against the oracle."""
+    it = vr.params()[1].iteration
     vr.setStatsEnabled(True)
     got = vr.runRaycastNoGL(W, H)
     gstats = vr.getStats()
-    vr.setIteration(0)
+    seed = vr.params()[1].seed    # the jitter seed this frame was rendered with
+    vr.setIteration(it)
     ref, rstats, _ = common.oracle_frame(vr, vol, fmt, tff, W, H, use_ess=ess)
     diff = np.abs(got.astype(np.float64) - ref.astype(np.float64))
     assert np.isfinite(got).all()
@@ -67,46 +74,29 @@ def _compare(vr, vol, fmt, tff, W, H, ess=True, pathtrace=False):
         assert gstats["bricks_skipped"] <= gstats["bricks_visited"] <= gstats["samples_taken"]
         gstats = dict(gstats, bricks_visited=0, bricks_skipped=0)
     assert gstats == rstats
+    # the production (uninstrumented) instantiation of the same frame
+    vr.setStatsEnabled(False)
+    pinned = vr._fixed_seed
+    vr.setSeed(seed)              # (the frame above may have drawn from the mt19937 sequence)
+    prod = vr.runRaycastNoGL(W, H)
+    vr.setSeed(pinned)
+    vr.setIteration(it)
+    pdiff = np.abs(prod.astype(np.float64) - ref.astype(np.float64))
+    assert np.isfinite(prod).all()
+    assert pdiff.max() <= TOL, "production kernels: max abs diff %.3g at %s" % (
+        pdiff.max(), np.unravel_index(pdiff.argmax(), pdiff.shape))
     return got, ref, gstats
 
 
-CASES = [
-    # fmt, res, (W, H), view, tff, kwargs
-    (UCHAR, (48, 48, 48), (96, 80), "default", "default", {}),
-    (UCHAR, (48, 48, 48), (96, 80), "rot30", "default", {"ess": False}),
-    (UCHAR, (64, 40, 52), (120, 72), "rot30", "opaque", {"gradient_bg": True}),
-    (UCHAR, (33, 47, 29), (64, 64), "close", "haze", {"illum": 0}),
-    (UCHAR, (48, 48, 48), (64, 64), "inside", "default", {}),
-    (UCHAR, (48, 48, 48), (72, 56), "rot30", "default", {"linear": False}),
-    (UCHAR, (48, 48, 48), (72, 56), "rot30", "default", {"ortho": True}),
-    (UCHAR, (48, 48, 48), (64, 64), "default", "default",
-     {"bbox": (-0.5, -0.8, -1.0, 0.7, 0.6, 0.2)}),
-    (UCHAR, (40, 40, 40), (64, 48), "rot30", "haze", {"contours": True, "aerial": True}),
-    (UCHAR, (40, 40, 40), (64, 48), "close", "opaque", {"illum": 0, "contours": True}),
-    (UCHAR, (32, 32, 80), (64, 64), "rot30", "default", {"thickness": (1.0, 1.0, 2.5)}),
-    (UCHAR, (128, 128, 128), (128, 128), "rot30", "default", {"rate": 0.7}),
-    (USHORT, (48, 48, 48), (80, 64), "rot30", "default", {}),
-    (USHORT, (40, 56, 36), (64, 64), "close", "opaque", {"ess": False}),
-    (FLOAT, (48, 48, 48), (80, 64), "rot30", "default", {}),
-    (FLOAT, (36, 36, 36), (64, 64), "default", "haze", {"illum": 0}),
-    # shading modes 2-5: TF-opacity gradient, Sobel, gradient-magnitude TF, cel
-    (UCHAR, (48, 48, 48), (80, 64), "rot30", "default", {"illum": 2}),
-    (UCHAR, (40, 44, 36), (64, 64), "rot30", "opaque", {"illum": 3, "contours": True}),
-    (UCHAR, (40, 40, 40), (64, 64), "close", "default", {"illum": 4}),
-    (USHORT, (40, 40, 40), (64, 64), "rot30", "opaque", {"illum": 4, "ess": False}),
-    (FLOAT, (40, 40, 40), (72, 56), "rot30", "default", {"illum": 5}),
-    (FLOAT, (32, 32, 32), (64, 48), "default", "opaque", {"illum": 3, "ess": False}),
-    (UCHAR, (40, 40, 40), (64, 48), "inside", "default", {"illum": 5, "aerial": True}),
-    # ambient occlusion at early ray termination (calcAO, volumeraycast.cl:368-392, :870-876)
-    (UCHAR, (48, 48, 48), (80, 64), "rot30", "opaque", {"ao": True}),
-    (FLOAT, (40, 40, 40), (64, 64), "close", "opaque", {"ao": True, "ess": False, "illum": 0}),
-    (USHORT, (40, 44, 36), (64, 56), "rot30", "opaque", {"ao": True, "illum": 3}),
-    # showEss (:888-896): rays without a sample and rays ending next to a box edge are marked
-    (UCHAR, (48, 48, 48), (96, 80), "rot30", "default",
-     {"show_ess": True, "background": (0.25, 0.5, 1.0, 1.0)}),
-    (USHORT, (40, 44, 36), (64, 56), "default", "haze", {"show_ess": True, "ess": False}),
-    (FLOAT, (40, 40, 40), (64, 64), "close", "opaque", {"show_ess": True, "illum": 0}),
-]
+
+
+def _same_params(vr, res, view, kw):
+    """The renderer-free parameter builder of the CPU tests (tests/scenes.py) produces the
+    product's own kernel-argument structs, byte for byte."""
+    mine = scenes.oracle_params(res, view, kw, seed=vr.params()[1].seed)
+    mine[1].iteration = vr.params()[1].iteration
+    for a, b in zip(mine, vr.params()):
+        assert bytes(a) == bytes(b), type(a).__name__
 
 
 @pytest.mark.parametrize("fmt,res,size,view,tff,kw", CASES)
@@ -115,19 +105,10 @@ def test_frame_matches_oracle(vr, fmt, res, size, view, tff, kw):
     table = common.tffs()[tff]
     _setup(vr, vol, fmt, table, common.views()[view], **kw)
     got, ref, stats = _compare(vr, vol, fmt, table, size[0], size[1], ess=kw.get("ess", True))
+    _same_params(vr, res, view, kw)
     assert stats["rays_hit"] > 0 and stats["samples_taken"] > 0
 
 
-PT_CASES = [
-    # fmt, res, (W, H), view, tff, smooth, kwargs -- technique 1 (Woodcock-tracking path tracer)
-    (FLOAT, (48, 48, 48), (96, 80), "rot30", "default", True, {}),
-    (FLOAT, (48, 48, 48), (64, 64), "default", "haze", False, {"ext": 30.0}),
-    (UCHAR, (64, 40, 52), (72, 56), "rot30", "opaque", True, {"ext": 250.0, "gradient_bg": True}),
-    (USHORT, (40, 56, 36), (64, 64), "close", "default", True, {"ext": 60.0}),
-    (FLOAT, (48, 48, 48), (64, 64), "inside", "default", True, {}),
-    (UCHAR, (48, 48, 48), (64, 64), "default", "default", False,
-     {"bbox": (-0.5, -0.8, -1.0, 0.7, 0.6, 0.2), "ortho": True}),
-]
 
 
 @pytest.mark.parametrize("fmt,res,size,view,tff,smooth,kw", PT_CASES)
@@ -137,6 +118,7 @@ def test_pathtrace_frame_matches_oracle(vr, fmt, res, size, view, tff, smooth, k
     table = common.tffs()[tff]
     _setup(vr, vol, fmt, table, common.views()[view], technique=1, **kw)
     got, ref, stats = _compare(vr, vol, fmt, table, size[0], size[1], pathtrace=True)
+    _same_params(vr, res, view, dict(kw, technique=1))
     assert stats["rays_hit"] > 0 and stats["samples_taken"] > stats["rays_hit"]
     assert np.ptp(ref[..., :3]) > 0.05   # something was traced
 
@@ -855,27 +837,16 @@ def test_cpp_host_cli_environment_map(tmp_path):
     assert bad.returncode != 0 and "Error loading environment map file." in bad.stderr
 
 
-MC_CASES = [
-    # fmt, channels, res, view, kwargs -- CL_RGBA / CL_RG volumes (volumeraycast.cl:838-855)
-    (UCHAR, 4, (40, 40, 40), "rot30", {}),
-    (FLOAT, 4, (36, 40, 32), "close", {"ess": False, "linear": False}),
-    (USHORT, 2, (40, 36, 44), "rot30", {"aerial": True}),
-    (UCHAR, 2, (40, 40, 40), "default", {"ess": False, "illum": 0}),
-    (UCHAR, 4, (40, 40, 40), "rot30", {"illum": 4}),               # gradient magnitude of .x
-    (FLOAT, 4, (32, 32, 32), "inside", {"ao": True, "show_ess": True}),
-]
 
 
 @pytest.mark.parametrize("fmt,nch,res,view,kw", MC_CASES)
 def test_multichannel_volume_matches_oracle(vr, fmt, nch, res, view, kw):
-    planes = [common.noise_volume(res, fmt, seed=20 + c, smooth=False) for c in range(nch)]
-    vol = np.stack(planes, axis=-1)
-    if nch == 4:   # keep the opacity channel moderate so that rays are not cut at once
-        vol[..., 3] = (vol[..., 3] * 0.2).astype(vol.dtype)
+    vol = scenes.multichannel_volume(fmt, nch, res)
     tff = common.tffs()["default"]
     W, H = 80, 64
     _setup(vr, vol, fmt, tff, common.views()[view], **kw)
     got, ref, stats = _compare(vr, vol, fmt, tff, W, H, ess=kw.get("ess", True))
+    _same_params(vr, res, view, kw)
     assert stats["samples_taken"] > 0
     # the extra channels are really used: dropping them changes the frame
     _setup(vr, np.ascontiguousarray(vol[..., 0]), fmt, tff, common.views()[view], **kw)
@@ -932,17 +903,6 @@ def test_cpp_host_cli_rgba_dat(tmp_path):
     assert bad.returncode != 0 and "not supported" in bad.stderr
 
 
-FP_CASES = [
-    # fmt, res, (W, H), view, tff, kwargs -- frames the default kernels render from the footprint
-    # volume (un-instrumented, volume not much wider than the viewport)
-    (UCHAR, (48, 48, 48), (96, 80), "rot30", "default", {}),
-    (UCHAR, (33, 47, 29), (64, 64), "close", "haze", {"illum": 0}),
-    (UCHAR, (48, 48, 48), (64, 64), "inside", "default", {}),        # edge-clamped fetches
-    (USHORT, (40, 56, 36), (64, 64), "close", "opaque", {"ess": False}),
-    (USHORT, (45, 45, 45), (80, 64), "rot30", "default", {"contours": True}),
-    (FLOAT, (48, 48, 48), (80, 64), "rot30", "default", {}),
-    (FLOAT, (37, 37, 37), (64, 64), "inside", "haze", {"ess": False}),
-]
 
 
 @pytest.mark.parametrize("fmt,res,size,view,tff,kw", FP_CASES)
@@ -1044,6 +1004,59 @@ def test_midsize_synthetic_volume_matches_oracle(vr, kind, fmt):
     assert np.array_equal(plain, got)
 
 
+def test_headline_size_volume_matches_oracle():
+    """The benchmark's own size: 2048^3 UCHAR "shells" (2^33 voxels: 64-bit element offsets, 32-bit
+    brick-slice stride at its limit, ESS brick edge 32, 512^3 micro-bricks, a 256^3 cell grid).
+    Field generated in HBM, downloaded, and a small frame -- instrumented and production kernels --
+    compared with the oracle on the downloaded voxels: image, the six work counters, the ESS
+    bricks and the touched-micro-brick bitmap."""
+    N = 2048
+    res = (N, N, N)
+    tff = common.tffs()["default"]
+    W, H = 96, 80
+    r = VolumeRenderCL()
+    r.initialize()
+    try:
+        r.synthVolume("shells", res, UCHAR)
+        vol = r.downloadVolume(0)
+        assert vol.shape == (N, N, N)
+        # the field itself, on three slices (SURVEY 8d formula, the oracle's restatement of it)
+        c = 2.0 * (np.arange(N) + 0.5) / N - 1.0
+        for z in (0, 777, N - 1):
+            rr = np.sqrt(c[None, :] ** 2 + c[:, None] ** 2 + c[z] ** 2)
+            dv = np.maximum(1.0 - rr / 0.9, 0.0) * (0.5 + 0.5 * np.cos(24.0 * np.pi * rr))
+            dv[dv < 0.35] = 0.0
+            want = np.floor(255.0 * dv + 0.5).astype(np.uint8)
+            bad = int((want != vol[z]).sum())
+            # (cos() of the device's libm against numpy's: a value within rounding of a .5 may differ)
+            assert bad <= 8 and np.abs(want.astype(int) - vol[z].astype(int)).max() <= 1, (z, bad)
+        r.setTransferFunction(tff)
+        ref_bricks = vro.generate_bricks(vol, UCHAR)
+        assert ref_bricks.shape == (64, 64, 64, 2)
+        np.testing.assert_array_equal(r.downloadBricks(0), ref_bricks)
+        r.setSeed(SEED)
+        r.updateView(common.views()["rot30"])
+        r.setIteration(0)
+        cam, rp, rc, pt = common.to_oracle_params(*r.params())
+        rp.seed, rp.iteration = SEED, 0
+        ref, rstats, ref_bm = vro.render_tile(vol, UCHAR, tff, cam, rp, rc, pt, W=W, H=H,
+                                               bricks=ref_bricks, want_touched=True)
+        assert rstats["bricks_skipped"] > 0 and rstats["samples_shaded"] > 0
+        for stats in (True, False):
+            r.setStatsEnabled(stats)
+            r.setIteration(0)
+            got = r.runRaycastNoGL(W, H)
+            assert np.abs(got.astype(np.float64) - ref).max() <= TOL, "stats=%s" % stats
+            if stats:
+                assert r.getStats() == rstats
+        r.setIteration(0)
+        n, bm = r.countTouched(W, H, want_bitmap=True)
+        np.testing.assert_array_equal(bm, ref_bm)
+        assert n == int(np.unpackbits(ref_bm).sum()) and n > 0
+    finally:
+        r.close()
+
+
 def test_shared_volume_twin_renders_the_same_frames(vr):
     """vrhip_share_volumes / VolumeRenderCL.shareVolumes: a second renderer on its own stream
     renders from the first one's voxels and bricks; frames of both equal the oracle's, also when
@@ -1091,6 +1104,40 @@ def test_shared_volume_twin_renders_the_same_frames(vr):
     vr.setIteration(0)
     ref, _, _ = common.oracle_frame(vr, vol, USHORT, tff, W, H)
     assert np.abs(again - ref).max() <= TOL
+
+
+def test_transfer_function_edits_keep_shared_bricks_alive(vr):
+    """the owner's setTransferFunction (the most common interactive action) re-runs
+    generateBricks; the twin keeps a pointer to the owner's bricks, so they must neither move nor
+    be freed.  Owner TF edit -> twin TF edit (its skip bitmap is rebuilt from the shared bricks)
+    -> both frames against the oracle."""
+    vol = common.noise_volume((56, 48, 40), UCHAR, seed=23, smooth=False)
+    W, H = 96, 72
+    _setup(vr, vol, UCHAR, common.tffs()["default"], common.views()["rot30"])
+    vr.setStatsEnabled(False)
+    twin = vr.shareVolumes()
+    try:
+        ballast = []
+        for name_owner, name_twin in (("opaque", "haze"), ("haze", "default"), ("default", "opaque")):
+            vr.setTransferFunction(common.tffs()[name_owner])      # would have freed + re-allocated
+            # something else takes whatever allocation a free would have released
+            ballast.append(np.zeros(1, dtype=np.uint8))
+            other = VolumeRenderCL()
+            other.initialize()
+            other.loadVolumeArrays([common.noise_volume((64, 64, 64), UCHAR, seed=len(ballast))], UCHAR)
+            other.setTransferFunction(common.tffs()["opaque"])
+            twin.setTransferFunction(common.tffs()[name_twin])     # skip bitmap from the shared bricks
+            for r, name in ((vr, name_owner), (twin, name_twin)):
+                r.setSeed(SEED)
+                r.setIteration(0)
+                got = r.runRaycastNoGL(W, H)
+                cam, rp, rc, pt = common.to_oracle_params(*r.params())
+                rp.iteration = 0
+                ref, _, _ = vro.render_tile(vol, UCHAR, common.tffs()[name], cam, rp, rc, pt, W=W, H=H)
+                assert np.abs(got - ref).max() <= TOL, (name_owner, name_twin, name)
+            other.close()
+    finally:
+        twin.close()
 
 
 def test_tile_driver_lanes_and_batches_on_one_gpu(vr):
@@ -1144,6 +1191,59 @@ def test_tile_driver_lanes_and_batches_on_one_gpu(vr):
     finally:
         twin.close()
         vr.set_stream(None, use_own=True)
+
+
+def test_tile_driver_orders_the_renderers_own_stream(vr):
+    """a renderer left on its OWN (non-blocking) stream -- nobody called set_stream --
+    driven through TileDriver: the collective (here a stand-in that copies on torch's current
+    stream, like RCCL orders itself behind it) must see finished tiles, frame after frame into the
+    same two buffers."""
+    import torch
+    from volumerenderercl_amd import tiles
+
+    class OneRankDist:
+        class _Done:
+            def wait(self):
+                pass
+
+        def gather(self, tensor, gather_list, dst=0, async_op=False):
+            gather_list[0].copy_(tensor)      # on the current stream
+            return self._Done()
+
+    vol = common.noise_volume((96, 96, 96), UCHAR, seed=5, smooth=False)
+    tff = common.tffs()["haze"]               # dense: long frames, so a missing wait shows
+    W, H, T = 512, 384, 64
+    _setup(vr, vol, UCHAR, tff, common.views()["close"])
+    vr.setStatsEnabled(False)
+    vr.set_stream(None, use_own=True)
+    assert vr.get_stream() != torch.cuda.current_stream().cuda_stream
+    dev = torch.device("cuda")
+    split = tiles.TileSplit(W, H, T, T, 2, 0)
+    drv = tiles.TileDriver(vr, split, dev, dist=OneRankDist(), batch=1)
+    seeds = [SEED, 581869302, 3890346734, 3586334585, 545404204]
+    frames = [torch.zeros((H, W, 4), dtype=torch.float32, device=dev) for _ in seeds]
+    for i, seed in enumerate(seeds):
+        vr.setSeed(seed)
+        vr.setIteration(0)
+        drv.submit()
+        drv.collect(frames[i])
+    torch.cuda.synchronize()
+    for i, seed in enumerate(seeds):
+        vr.setSeed(seed)
+        vr.setIteration(0)
+        full = vr.runRaycastNoGL(W, H)
+        got = frames[i].cpu().numpy()
+        for t in split.my_tiles:
+            x0, y0, w, h = split.tile_rect(t)
+            np.testing.assert_array_equal(got[y0:y0 + h, x0:x0 + w], full[y0:y0 + h, x0:x0 + w])
+    # world == 1: the caller's frame tensor is consumed on the current stream
+    one = tiles.TileDriver(vr, tiles.TileSplit(W, H, T, T, 1, 0), dev)
+    vr.setSeed(SEED)
+    vr.setIteration(0)
+    out = one.render_frame(torch.zeros((H, W, 4), dtype=torch.float32, device=dev)).clone()
+    vr.setSeed(SEED)
+    vr.setIteration(0)
+    np.testing.assert_array_equal(out.cpu().numpy(), vr.runRaycastNoGL(W, H))
 
 
 def test_shared_twin_follows_its_own_time_step(vr):

@@ -3,6 +3,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "../../include/vrhip.h"
 
 // Scalar field in HBM (DESIGN.md "Data layout"): 4x4x4-voxel MICRO-BRICKS of 64 contiguous
@@ -221,3 +227,38 @@ hipError_t vr_launch_synth(int kind, const VolView &vol, int format, hipStream_t
 // dense x-fastest slices [z0, z0+nz) (device memory, `dense` points at slice z0) <-> bricks
 hipError_t vr_launch_retile(const VolView &vol, int format, const void *dense, int z0, int nz,
                             bool to_bricks, hipStream_t stream);
+
+// Blocks per CU of `kernel` (block_dim threads, `lds` bytes of dynamic LDS), after raising the
+// kernel's dynamic LDS limit where needed.  Both are per device (hipFuncSetAttribute acts on the
+// current device's copy of the function), so the answers are cached per (device, LDS size) of
+// each kernel instantiation, under a lock: renderers on several devices or host threads share
+// this code.
+template <typename K>
+hipError_t vr_prepare_kernel(K kernel, int block_dim, size_t lds, int *nb_out, const char *what, int num_cus)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, size_t>, int> cache;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    const auto key = std::make_pair(dev, lds);
+    const auto it = cache.find(key);
+    if (it != cache.end()) { *nb_out = it->second; return hipSuccess; }
+    if (lds > 48 * 1024) {
+        e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block_dim, lds) != hipSuccess || nb < 1)
+        nb = 1;
+    if (const char *ev = getenv("VRHIP_BLOCKS_PER_CU")) {   // tuning / experiments
+        const int v = atoi(ev);
+        if (v > 0) nb = v;
+    }
+    if (getenv("VRHIP_DEBUG"))
+        fprintf(stderr, "[vrhip] %s: device %d, lds=%zu B, blocks/CU=%d, CUs=%d\n", what, dev, lds, nb, num_cus);
+    cache[key] = nb;
+    *nb_out = nb;
+    return hipSuccess;
+}

@@ -335,23 +335,10 @@ hipError_t launch_pt(const RaycastLaunch &a, hipStream_t stream)
 {
     auto k = vr_pathtrace_kernel<VT, INSTR>;
     const size_t lds = (size_t)a.tf.tff_n * sizeof(float4);
-    static int nb = 0;
-    static size_t cached_lds = ~(size_t)0;
-    if (cached_lds != lds) {
-        if (lds > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void *)k,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-        }
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, kBlockDim, lds) != hipSuccess || nb < 1)
-            nb = 1;
-        if (const char *e = getenv("VRHIP_BLOCKS_PER_CU")) {
-            int v = atoi(e);
-            if (v > 0) nb = v;
-        }
-        if (getenv("VRHIP_DEBUG"))
-            fprintf(stderr, "[vrhip] pathtrace: lds=%zu B, blocks/CU=%d, CUs=%d\n", lds, nb, a.num_cus);
-        cached_lds = lds;
+    int nb = 0;
+    {
+        hipError_t e = vr_prepare_kernel(k, kBlockDim, lds, &nb, "pathtrace", a.num_cus);
+        if (e != hipSuccess) return e;
     }
     const uint32_t cus = (uint32_t)(a.num_cus > 0 ? a.num_cus : 256);
     const uint32_t want = (a.frame.n_wave_tiles + 3u) / 4u;

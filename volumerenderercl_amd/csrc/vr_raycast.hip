@@ -812,8 +812,8 @@ __global__ __launch_bounds__(kBlockDim) void vr_dda_prepass_kernel(
 
 // Phase 1 for the default modes with ESS: one lane per ray, the rays taken from the pre-pass's ray
 // list (FrameView::live_rays) with the DDA state reached there; a lane whose ray ends -- or is
-// suspended for phase 2 after `round_budget` rounds of its own -- takes the next ray as soon as 16
-// lanes of the wave are idle.  Same per-ray operation sequence as the patch kernel above; no dead
+// suspended for phase 2 after `round_budget` rounds of its own -- takes the next ray once
+// 4 * refill_min lanes of the wave are idle (default 64: the whole wave, measured best).  Same per-ray operation sequence as the patch kernel above; no dead
 // lanes carried through a patch, no second DDA walk.  Exit condition reached by every wave: the
 // list head only grows, and every ray ends or is suspended.
 template <typename VT, bool SKIP_LDS, bool FP>
@@ -1473,32 +1473,9 @@ __global__ __launch_bounds__(kBlockDim) void vr_hit_resolve_kernel(FrameView fr,
 }
 
 template <typename K>
-int blocks_per_cu(K kernel, size_t lds)
-{
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kBlockDim, lds) != hipSuccess ||
-        nb < 1)
-        nb = 1;
-    return nb;
-}
-
-template <typename K>
 hipError_t prepare_variant(K kernel, size_t lds, int *nb_out, const char *what, int num_cus)
 {
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    int nb = blocks_per_cu(kernel, lds);
-    if (const char *e = getenv("VRHIP_BLOCKS_PER_CU")) {   // tuning / experiments
-        int v = atoi(e);
-        if (v > 0) nb = v;
-    }
-    if (getenv("VRHIP_DEBUG"))
-        fprintf(stderr, "[vrhip] %s: lds=%zu B, blocks/CU=%d, CUs=%d\n", what, lds, nb, num_cus);
-    *nb_out = nb;
-    return hipSuccess;
+    return vr_prepare_kernel(kernel, kBlockDim, lds, nb_out, what, num_cus);
 }
 
 template <typename VT, bool ESS, int INSTR, bool SKIP_LDS, bool XS, bool FP = false>
@@ -1508,13 +1485,11 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
     auto k2 = vr_raycast_split_kernel<VT, ESS, INSTR, SKIP_LDS, XS, FP>;
     size_t lds = (size_t)kStageF4 * sizeof(float4) + (size_t)a.tf.tff_n * sizeof(float4);
     if (ESS && SKIP_LDS) lds += ((size_t)a.skip.n_words + 1) * sizeof(uint32_t);
-    static int nb1 = 0, nb2 = 0;
-    static size_t cached_lds = ~(size_t)0;
-    if (cached_lds != lds) {
+    int nb1 = 0, nb2 = 0;
+    {
         hipError_t e = prepare_variant(k1, lds, &nb1, "raycast phase 1", a.num_cus);
         if (e == hipSuccess) e = prepare_variant(k2, lds, &nb2, "raycast phase 2", a.num_cus);
         if (e != hipSuccess) return e;
-        cached_lds = lds;
     }
     const uint32_t cus = (uint32_t)(a.num_cus > 0 ? a.num_cus : 256);
     uint32_t want = (a.frame.n_wave_tiles + 3u) / 4u;
@@ -1534,13 +1509,9 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
     hipError_t e;
     if (ESS && INSTR == 0 && !XS && frame.live && frame.live_rays) {   // phase 1 on the ray list
         auto kr = vr_raycast_rays_kernel<VT, SKIP_LDS, FP>;
-        static int nbr = 0;
-        static size_t cached_ldsr = ~(size_t)0;
-        if (cached_ldsr != lds) {
-            e = prepare_variant(kr, lds, &nbr, "raycast phase 1 (ray list)", a.num_cus);
-            if (e != hipSuccess) return e;
-            cached_ldsr = lds;
-        }
+        int nbr = 0;
+        e = prepare_variant(kr, lds, &nbr, "raycast phase 1 (ray list)", a.num_cus);
+        if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kr, dim3(cus * (uint32_t)nbr), block, lds, stream, a.vol, a.bricks, a.tf, a.skip,
                            a.cells, frame, a.cam, a.render, a.raycast);
     } else {

@@ -19,6 +19,7 @@ struct VolumeSlot {
     void *dev = nullptr;      // micro-bricked voxels (channel 0 of a multi-channel volume)
     void *chan[3] = {nullptr, nullptr, nullptr};   // channels 1..3 of CL_RG / CL_RGBA volumes
     void *bricks = nullptr;   // (min,max) grid
+    bool bricks_built = false;   // `bricks` holds the (min,max) of the voxels now in `dev`
     float2 *pt_minmax = nullptr;   // path tracer: per-cell (min,max) incl. halo, built on demand
     bool pt_minmax_valid = false;
     bool borrowed = false;    // dev / chan / bricks belong to another renderer (vrhip_share_volumes)
@@ -320,6 +321,7 @@ int prepare_slot(vrhip_renderer *r, const uint32_t res[3], int format, uint32_t 
     for (int c = 1; c < channels; ++c)
         if (!s.chan[c - 1]) VR_HIP(r, hipMalloc(&s.chan[c - 1], volume_alloc_bytes(r)));
     r->bricks_valid = false;
+    s.bricks_built = false;
     r->skip_dirty = true;
     r->pt_dirty = true;
     r->fp_valid = false;
@@ -855,6 +857,13 @@ int vrhip_set_stream(vrhip_renderer *r, void *hip_stream, int use_own)
     return VRHIP_OK;
 }
 
+int vrhip_get_stream(const vrhip_renderer *r, void **hip_stream)
+{
+    if (!r || !hip_stream) return VRHIP_ERR_INVALID;
+    *hip_stream = (void *)r->stream;
+    return VRHIP_OK;
+}
+
 int vrhip_upload_volume(vrhip_renderer *r, const void *host_voxels, const uint32_t res[3],
                         int format, uint32_t timestep)
 {
@@ -1125,24 +1134,34 @@ int vrhip_build_bricks(vrhip_renderer *r)
         r->brick_tex[i] = (uint32_t)std::ceil((double)r->brick_res[i]);
         r->raycast.brickRes[i] = r->brick_res[i];   // :630-631
     }
+    // The bricks depend on the voxels alone, and renderers created with vrhip_share_volumes keep
+    // the pointer: an allocation is made once per slot and lives as long as the voxels do, and a
+    // slot whose voxels have not changed since its last build is left alone (the reference
+    // rebuilds on every setTransferFunction, :877 -- same values).
     for (VolumeSlot &s : r->vols) {
         if (!s.dev) return fail(r, VRHIP_ERR_NODATA,
                                 "Error loading timeseries data: size mismatch.");   // :227
         if (s.borrowed) continue;   // shared voxels come with their bricks (they depend on nothing else)
-        if (s.bricks) VR_HIP(r, hipFree(s.bricks));
-        s.bricks = nullptr;
-        VR_HIP(r, hipMalloc(&s.bricks, bricks_bytes(r)));
+        if (!s.bricks) {
+            VR_HIP(r, hipMalloc(&s.bricks, bricks_bytes(r)));
+            s.bricks_built = false;
+        }
     }
-    VR_HIP(r, hipEventRecord(r->evb0, r->stream));
-    for (VolumeSlot &s : r->vols) {
-        if (s.borrowed) continue;
-        VolView v = make_vol_view(r, s.dev);
-        VR_HIP(r, vr_launch_build_bricks(v, r->format, r->brick_tex, s.bricks, r->stream));
+    bool any = false;
+    for (const VolumeSlot &s : r->vols) any = any || (!s.borrowed && !s.bricks_built);
+    if (any) {   // (vrhip_last_bricks_seconds keeps reporting the last build that did something)
+        VR_HIP(r, hipEventRecord(r->evb0, r->stream));
+        for (VolumeSlot &s : r->vols) {
+            if (s.borrowed || s.bricks_built) continue;
+            VolView v = make_vol_view(r, s.dev);
+            VR_HIP(r, vr_launch_build_bricks(v, r->format, r->brick_tex, s.bricks, r->stream));
+            s.bricks_built = true;
+        }
+        VR_HIP(r, hipEventRecord(r->evb1, r->stream));
+        r->bricks_timed = true;
     }
-    VR_HIP(r, hipEventRecord(r->evb1, r->stream));
     VR_HIP(r, hipStreamSynchronize(r->stream));   // reference: _queueCL.finish() (:670)
     r->bricks_valid = true;
-    r->bricks_timed = true;
     r->skip_dirty = true;
     r->pt_dirty = true;
     return VRHIP_OK;

@@ -150,6 +150,12 @@ class VolumeRenderCL:
         self._check(self._lib.vrhip_set_stream(self._h, C.c_void_p(stream_ptr),
                                                1 if use_own else 0))
 
+    def get_stream(self):
+        """The hipStream_t handle (int, 0 = legacy default stream) render calls are enqueued on."""
+        p = C.c_void_p()
+        self._check(self._lib.vrhip_get_stream(self._h, C.byref(p)))
+        return p.value or 0
+
     def getPlatformNames(self):
         """volumerendercl.cpp:1062-1079 (OpenCL platforms): there is one, the HIP runtime."""
         return ["AMD HIP (ROCm)"]

@@ -53,6 +53,13 @@ class TileDriver:
         independent frames per collective (one gather and one assembly for all of them): at a few
         hundred microseconds of GPU work per rank and frame the host-side cost of a collective is
         as long as the rendering, so fewer, larger collectives keep the GPUs busy.
+
+    Stream ordering: a renderer enqueues on a stream of its own (vrhip_get_stream) and returns
+    without synchronising, while torch.distributed orders a collective behind torch's CURRENT
+    stream only.  The driver therefore brackets every render: the renderer's stream first waits
+    for the current stream (the gather that last read the tile buffer was waited for there), and
+    the current stream then waits for the renderer's stream before the gather is issued.  A
+    renderer that already launches on the current stream (vr.set_stream) needs neither wait.
     """
 
     def __init__(self, vr, split, device, render_tiles_fn=None, dist=None, image_ess=False,
@@ -109,6 +116,27 @@ class TileDriver:
                     self.padded = torch.zeros((B, s.tiles_y * s.th, s.tiles_x * s.tw, 4),
                                               dtype=torch.float32, device=device)
 
+    # ---- stream ordering between a renderer and the collective
+    def _stream_of(self, r, given=None):
+        """torch view of the stream renderer `r` launches on: asked from the renderer itself
+        (vrhip_get_stream); `given` (a lane's stream as the caller named it) only serves stand-in
+        renderers that cannot be asked."""
+        if r is None or not hasattr(r, "get_stream") or getattr(self.device, "type", str(self.device)) != "cuda":
+            return given
+        return self.torch.cuda.ExternalStream(r.get_stream(), device=self.device)
+
+    def _before_render(self, streams):
+        cur = self.torch.cuda.current_stream(self.device) if any(s is not None for s in streams) else None
+        for ls in streams:
+            if ls is not None and ls != cur:
+                ls.wait_stream(cur)
+        return cur
+
+    def _after_render(self, streams, cur):
+        for ls in streams:
+            if ls is not None and ls != cur:
+                cur.wait_stream(ls)
+
     # ---- pipelined interface
     def submit(self):
         """Render this rank's tiles of the next frame and start its gather (world > 1)."""
@@ -127,14 +155,13 @@ class TileDriver:
             raise RuntimeError("two gathers already in flight: collect first")
         b = self.next_buf
         self.next_buf ^= 1
-        cur = None
+        # the buffer may only be overwritten once the gather that last read it is done: that wait
+        # sits on the current stream (collect_batch), so every renderer's stream joins it first
         if self.lanes:
-            # the buffer may only be overwritten once the gather that last read it is done: that
-            # wait sits on the current stream (collect_batch), so every lane's stream joins it
-            cur = self.torch.cuda.current_stream(self.device)
-            for _, ls in self.lanes:
-                if ls is not None and ls != cur:
-                    ls.wait_stream(cur)
+            streams = [self._stream_of(r, ls) for r, ls in self.lanes]
+        else:
+            streams = [self._stream_of(self.vr)] if self.render_tiles_fn is None else []
+        cur = self._before_render(streams)
         for i in range(n):
             if self.lanes:
                 lane_vr = self.lanes[i % len(self.lanes)][0]
@@ -150,10 +177,7 @@ class TileDriver:
                 self.render_tiles_fn(s.my_tiles, self.local[b][i])
             if self.hit_io is not None:
                 self.merge_hit_image()      # the next frame reads the merged hit image
-        if self.lanes:
-            for _, ls in self.lanes:        # the gather follows every lane's frames
-                if ls is not None and ls != cur:
-                    cur.wait_stream(ls)
+        self._after_render(streams, cur)    # the gather follows every renderer's frames
         glist = [self.staging[b][r] for r in range(s.world)] if s.rank == 0 else None
         work = self.dist.gather(self.local[b], glist, dst=0, async_op=True)
         self.pending.append((b, n, work))
@@ -173,27 +197,21 @@ class TileDriver:
         b = self.next_buf
         self.next_buf ^= 1
         lanes = self.lanes or [(self.vr, None)]
-        cur = self.torch.cuda.current_stream(self.device) if self.lanes else None
-        if cur is not None:
-            for _, ls in lanes:
-                if ls is not None and ls != cur:
-                    ls.wait_stream(cur)
         per = -(-n // len(lanes))
         stride = s.cap * s.th * s.tw
         if self.render_tiles_fn is not None:      # stand-in renderer (CPU tests): frame by frame
             for i in range(n):
                 self.render_tiles_fn(s.my_tiles, self.local[b][i], seed=seeds[i])
             lanes = []
+        streams = [self._stream_of(r, ls) for r, ls in lanes]
+        cur = self._before_render(streams)
         for j, (r, _) in enumerate(lanes):
             lo, hi = j * per, min(n, (j + 1) * per)
             if lo >= hi:
                 break
             r.render_batch(s.W, s.H, seeds[lo:hi], self.local[b][lo].data_ptr(), s.tw, s.th,
                            s.my_tiles, frame_stride=stride)
-        if cur is not None:
-            for _, ls in lanes:
-                if ls is not None and ls != cur:
-                    cur.wait_stream(ls)
+        self._after_render(streams, cur)
         glist = [self.staging[b][r] for r in range(s.world)] if s.rank == 0 else None
         work = self.dist.gather(self.local[b], glist, dst=0, async_op=True)
         self.pending.append((b, n, work))
@@ -238,7 +256,10 @@ class TileDriver:
         s = self.split
         if s.world == 1:
             if self.render_tiles_fn is None:
+                streams = [self._stream_of(self.vr)]
+                cur = self._before_render(streams)
                 self.vr.runRaycast(s.W, s.H, out_dev_ptr=frame.data_ptr())
+                self._after_render(streams, cur)     # `frame` is the caller's, on the current stream
                 return frame
             out = self.torch.zeros((s.n_tiles, s.th, s.tw, 4), dtype=self.torch.float32,
                                    device=self.device)
