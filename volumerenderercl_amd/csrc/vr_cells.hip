@@ -121,7 +121,46 @@ __global__ __launch_bounds__(kThreads) void vr_cell_bounds_kernel(const float2 *
     }
 }
 
+// CellView::bmask: one thread per ESS brick.  Sub-blocks that lie outside the volume are never
+// looked up (sample coordinates are clamped into the volume) and read 0.
+__global__ __launch_bounds__(kThreads) void vr_cell_bmask_kernel(VolView vv, CellView g, int bw, int bh,
+                                                                 int bd, unsigned long long *out)
+{
+    const size_t n = (size_t)bw * bh * bd;
+    const size_t b = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (b >= n) return;
+    const int bx = (int)(b % (size_t)bw), by = (int)((b / (size_t)bw) % (size_t)bh), bz = (int)(b / ((size_t)bw * bh));
+    const int sx = g.bex - 2, sy = g.bey - 2, sz = g.bez - 2;   // log2 of the sub-block edge
+    unsigned long long word = 0;
+    for (int k = 0; k < 4; ++k)
+        for (int j = 0; j < 4; ++j)
+            for (int i = 0; i < 4; ++i) {
+                const int x0 = (bx << g.bex) + (i << sx), y0 = (by << g.bey) + (j << sy), z0 = (bz << g.bez) + (k << sz);
+                if (x0 >= vv.w || y0 >= vv.h || z0 >= vv.d) continue;
+                const int x1 = min(x0 + (1 << sx), vv.w) - 1, y1 = min(y0 + (1 << sy), vv.h) - 1;
+                const int z1 = min(z0 + (1 << sz), vv.d) - 1;
+                bool all = true;
+                for (int cz = z0 >> g.shift; cz <= (z1 >> g.shift); ++cz)
+                    for (int cy = y0 >> g.shift; cy <= (y1 >> g.shift); ++cy)
+                        for (int cx = x0 >> g.shift; cx <= (x1 >> g.shift); ++cx) {
+                            const uint32_t idx = ((uint32_t)cz * (uint32_t)g.cy + (uint32_t)cy) * (uint32_t)g.cx + (uint32_t)cx;
+                            all = all && ((g.empty[idx >> 5] >> (idx & 31u)) & 1u);
+                        }
+                if (all) word |= 1ull << (i + 4 * j + 16 * k);
+            }
+    out[b] = word;
+}
+
 } // namespace
+
+hipError_t vr_launch_cell_bmask(const VolView &vol, const CellView &grid, int bw, int bh, int bd,
+                                unsigned long long *bmask, hipStream_t stream)
+{
+    const size_t n = (size_t)bw * bh * bd;
+    hipLaunchKernelGGL(vr_cell_bmask_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                       stream, vol, grid, bw, bh, bd, bmask);
+    return hipGetLastError();
+}
 
 hipError_t vr_launch_cell_minmax(const VolView &vol, int format, const CellView &grid,
                                  float2 *minmax, hipStream_t stream)

@@ -71,6 +71,12 @@ struct SkipView {
     const uint32_t *bits;
     uint32_t n_words;
     uint32_t in_lds;       // bitmap is staged in LDS by every workgroup
+    // Patch culling in the DDA pre-pass: bit = 1 when some brick within `near_r` bricks (Chebyshev,
+    // per axis) of this one is NOT skipped.  An 8x8 patch whose rays stay -- by a conservative
+    // bound -- inside bricks with bit 0 cannot meet a brick to sample: its rays are finished without
+    // the walk.  nullptr / 0: off.
+    const uint32_t *near_bits;
+    uint32_t near_r;
 };
 
 // One 8x8-pixel patch (= one wave64) of the work queue.
@@ -129,6 +135,10 @@ struct FrameView {
     // reached; live_count counts them) and phase 1 runs on that list, one lane per ray, lanes
     // refilled as rays end (vr_raycast_rays_kernel).  nullptr: the patch list above.
     ContRec *live_rays;
+    // 1: the default modes march the ray list with vr_march_kernel (stepping / dense evaluation /
+    // compositing as stages of a round) instead of the two-phase march; a schedule, not a result
+    uint32_t march;
+    uint32_t march_micro, march_fill;   // tuning (0 = built-in): micro-steps per round, queue fill that ends stage A
     // Phase-2 scheduling: `cost` keeps, per pixel, the phase-2 rounds the pixel's ray needed in the
     // previous frame.  Suspended rays are sorted by it, longest first (counting sort into
     // `order`), so that the longest chains start first and the 16 rays of a group are alike.
@@ -167,6 +177,12 @@ struct CellView {
     const uint32_t *empty;  // 1 bit per cell, same order; nullptr = feature off
     int cx, cy, cz;
     int shift;
+    // The empty bits once more, per ESS brick (the march kernel keeps the words of the bricks a ray
+    // is in in registers): brick (bx, by, bz) of the bw x bh x bd brick grid, x fastest, is cut into
+    // 4 x 4 x 4 sub-blocks of (edge / 4) voxels; bit i + 4 j + 16 k of its word is set when every
+    // cell that overlaps sub-block (i, j, k) is empty.  nullptr: not available (brick edge < 4).
+    const unsigned long long *bmask;
+    int bex, bey, bez;      // log2 of the brick edge per axis (>= 2)
 };
 
 struct DevStats {
@@ -207,6 +223,9 @@ hipError_t vr_launch_cell_minmax(const VolView &vol, int format, const CellView 
 hipError_t vr_launch_cell_bounds(const float2 *minmax, const CellView &grid, float inv_max,
                                  const TfView &tf, float *sparse_scratch, float *bound,
                                  uint32_t *empty_bits, hipStream_t stream);
+// CellView::bmask from CellView::empty for the bw x bh x bd brick grid (grid.bex.. set)
+hipError_t vr_launch_cell_bmask(const VolView &vol, const CellView &grid, int bw, int bh, int bd,
+                                unsigned long long *bmask, hipStream_t stream);
 // the frame launch for a.render.technique
 inline hipError_t vr_launch_frame(const RaycastLaunch &a, hipStream_t stream)
 {
@@ -216,6 +235,9 @@ inline hipError_t vr_launch_frame(const RaycastLaunch &a, hipStream_t stream)
 // skip bitmap from bricks + TF + prefix
 hipError_t vr_launch_skipmap(const BrickView &bricks, int format, float inv_max, const TfView &tf,
                              uint32_t *bits, uint32_t n_words, hipStream_t stream);
+// SkipView::near_bits from the skip bitmap: scratch = 2 bytes per brick
+hipError_t vr_launch_skip_near(const BrickView &bricks, const uint32_t *bits, uint32_t n_words, uint32_t radius,
+                               uint8_t *scratch, uint32_t *near_bits, hipStream_t stream);
 
 hipError_t vr_launch_build_bricks(const VolView &vol, int format, const uint32_t tex[3],
                                   void *bricks_out, hipStream_t stream);

@@ -30,6 +30,7 @@
 //  carry a frame index (vrhip_render_batch).
 //  The per-ray sequence of t values and of fp32 operations is exactly the reference's in every
 //  kernel, so the image is bit-identical whatever the schedule (budget, refill, batch, lists).
+#include "vr_leap.h"
 #include "vr_sampling.h"
 
 namespace {
@@ -737,6 +738,58 @@ VR_DEV void flush_counters(DevStats *stats, uint32_t lane, const unsigned long l
     }
 }
 
+// ------------------------------------------------------------------ patch culling
+
+VR_DEV float wave_max_f(float v)
+{
+    for (int off = 32; off > 0; off >>= 1) v = vmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// True when NO ray of the wave's 8x8 patch can visit a brick that is not skipped (SkipView::near_bits).
+// Every point of every valid ray i, cam_i + t dir_i with t in [tn, tf] (the patch's smallest tnear and
+// largest tfar), lies within rho = max|cam_i - cam_r| + tf max|dir_i - dir_r| of the point with the
+// same t on a reference ray r of the patch; 256 test points on r (four per lane) leave no point of r
+// farther than h / 2 from one of them.  The reference DDA of a ray only visits bricks that touch the
+// ray within one brick (its crossing times are accumulated sums, off by far less than a brick), so
+// all it can visit lies within floor((rho + h / 2) / brick) + 2 bricks of a test point's (clamped) brick.
+// If that is within the radius the bitmap was dilated by and every test point reads 0, every brick
+// any of the rays visits is skipped: the rays end as they started.  Out-of-range cells read the
+// (0, 0) decision, which must be "skip" for any of this to hold.
+VR_DEV bool patch_is_clear(const SkipView &skip, const Grid &g, const RayCtx &c, uint32_t lane)
+{
+    const unsigned long long vm = __ballot(c.valid);
+    if (!vm) return false;                       // (nothing to walk anyway: the normal path writes the pixels)
+    if (skip.bits[skip.n_words] != 0xffffffffu) return false;
+    const int ref = ((vm >> 27) & 1ull) ? 27 : (int)__builtin_ctzll(vm);   // a ray in the middle of the patch, if it has one
+    const f3 rc = mk3(__shfl(c.cam.x, ref, 64), __shfl(c.cam.y, ref, 64), __shfl(c.cam.z, ref, 64));
+    const f3 rd = mk3(__shfl(c.dir.x, ref, 64), __shfl(c.dir.y, ref, 64), __shfl(c.dir.z, ref, 64));
+    const float dc = wave_max_f(c.valid ? len3(sub3(c.cam, rc)) : 0.f);
+    const float dd = wave_max_f(c.valid ? len3(sub3(c.dir, rd)) : 0.f);
+    const float tf = wave_max_f(c.valid ? c.tfar : -3.0e38f);
+    const float tn = -wave_max_f(c.valid ? -c.tnear : -3.0e38f);
+    if (!(tf > tn) || !(tf < 1.0e30f)) return false;
+    const float h = (tf - tn) * (1.0f / 256.0f);
+    const float need = (dc + tf * dd + 0.5f * h) * 1.0001f;
+    const float bl[3] = {g.bl0, g.bl1, g.bl2};
+    const int bres[3] = {g.bw, g.bh, g.bd};
+    // a point within `need` of a test point lies at most floor(need / brick) + 1 bricks from the test
+    // point's brick; one more for bricks the DDA visits next to the ray
+    for (int i = 0; i < 3; ++i)
+        if (!(floorf(need / (2.f * bl[i])) + 2.f <= (float)skip.near_r)) return false;
+    bool live = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float t = tn + ((float)(lane + 64u * (uint32_t)k) + 0.5f) * h;
+        const float p[3] = {rc.x + t * rd.x, rc.y + t * rd.y, rc.z + t * rd.z};
+        int cell[3];
+        for (int i = 0; i < 3; ++i) cell[i] = iclamp((int)floorf((p[i] + 1.f) / (2.f * bl[i])), 0, bres[i] - 1);
+        const uint32_t idx = ((uint32_t)cell[2] * (uint32_t)g.bh + (uint32_t)cell[1]) * (uint32_t)g.bw + (uint32_t)cell[0];
+        live = live || ((skip.near_bits[idx >> 5] >> (idx & 31u)) & 1u);
+    }
+    return __ballot(live) == 0ull;
+}
+
 // ------------------------------------------------------------------ DDA pre-pass
 
 // Most rays of a typical frame cross the volume without ever meeting a brick the ESS bitmap
@@ -766,6 +819,11 @@ __global__ __launch_bounds__(kBlockDim) void vr_dda_prepass_kernel(
     setup_ray<true>(gx, gy, inside, fr, cam, rp, rc, resf, voxLen, grid, c, d, seed);
     const size_t out_index = (size_t)wt.out_base + (size_t)ly * fr.out_stride + lx;
     if (rp.imgEss && image_ess_patch(fr, rp, c, wt, lane, inside, gx, gy, out_index)) return;
+    if (skip.near_bits && patch_is_clear(skip, grid, c, lane)) {
+        // no ray of this patch can meet a brick that is not skipped: what the walk would leave
+        if (inside) write_pixel<true>(fr, rp, c, d, voxLen, gx, gy, out_index);
+        return;
+    }
     fetch_skip_word(skip.bits, grid, d);
     unsigned long long n0 = 0, n1 = 0;
     while (__ballot(d.state == S_BRICK)) dda_step<0>(skip.bits, grid, c, d, n0, n1);
@@ -959,6 +1017,397 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
             after_segment<true>(c, d);
         }
     }
+}
+
+// ------------------------------------------------------------------ decoupled march
+
+// The default march (ESS, no instrumentation, none of the XS extras): stepping, evaluation and
+// compositing are three stages of a round that exchange samples through per-wave LDS queues, so
+// that the expensive part of the frame -- the eight (forty) voxel loads, the transfer-function
+// lookup, opacity correction and shading of a sample -- runs over a DENSE list of the samples
+// that need it, whichever rays they belong to:
+//
+//  A  stepping, one lane per ray, in micro-steps.  A lane in a brick takes one step of the
+//     reference's DDA (dda_step).  A lane in a segment looks at its next sample: the sub-block of
+//     the ESS brick it falls into is looked up in the per-brick empty words (CellView::bmask; the
+//     words of the last two bricks the ray has touched stay in registers, a miss costs one load
+//     that is used in the next micro-step).  In an EMPTY sub-block every sample composites to
+//     exactly nothing, so the whole run of samples up to the sub-block's far side is stepped over
+//     at once: the run's length comes from the ray's texel increments, and the ray parameter after
+//     that many `t += stepSize` (:879) from vr_leap -- the exact bits of the chain of additions,
+//     without the chain.  Otherwise up to kQ samples go to the wave's queue.  Only samples that
+//     are certainly neither the last of their segment (:790) nor of the ray (:868) are handled in
+//     runs (a margin of two steps); the others take the reference's loop one sample at a time.
+//     Nothing in this stage depends on the running alpha: the inner loop can only be left through
+//     its condition with alpha < 0.98, so early ray termination is decided in stage C alone and
+//     at most kQ - 1 samples per ray are evaluated in vain.
+//  B  evaluation, one lane per queued sample: position from the owner ray's (cam, dir, offset)
+//     (ds_bpermute), density, transfer function, gradient + Blinn-Phong where the sample is lit,
+//     opacity correction -- the fp32 sequences of eval_batch, in another lane.
+//  C  compositing, one lane per ray: its results in order (:856, :865-879), ERT, end of ray.
+//
+// Rays come from the pre-pass's list with the DDA state reached there; a lane takes the next ray
+// when 4 * refill_min lanes of its wave are idle.  Exit condition reached by every wave: the list
+// head only grows and every ray ends.
+#ifdef VR_ISA_MARKS   // diagnostic: comments in the -S output that delimit the stages (tools/isa_marks.py)
+#define VR_MARK(x) asm volatile("; VRMARK " x ::: "memory")
+#else
+#define VR_MARK(x)
+#endif
+#ifdef VR_MARCH_STATS   // diagnostic build: what the waves of the march kernel spend their rounds on
+__device__ unsigned long long g_march_stats[16];
+#define VR_MS(i, v) ms_acc[i] += (unsigned long long)(v)
+#else
+#define VR_MS(i, v)
+#endif
+#ifndef VR_MARCH_Q
+#define VR_MARCH_Q 4
+#endif
+#ifndef VR_MARCH_MICRO
+#define VR_MARCH_MICRO 12
+#endif
+#ifndef VR_MARCH_FILL
+#define VR_MARCH_FILL 48
+#endif
+constexpr int kQ = VR_MARCH_Q;             // samples of a ray in flight per round (queue slots lane * kQ + j)
+constexpr int kMicro = VR_MARCH_MICRO;     // micro-steps of stage A per round, at most
+constexpr int kFill = VR_MARCH_FILL;       // stage A ends early once about this many samples are queued
+constexpr int kRunCap = 4096;              // samples stepped over at once, at most
+static_assert(64 * kQ <= 256, "slot ids travel as bytes");
+constexpr int kMarchWaveBytes = 64 * kQ * 4 + 64 * kQ * 16 + 64 * kQ + 64 * kQ * 2;   // t queue, results, slot map, list of opaque samples
+static_assert(kMarchWaveBytes % 16 == 0, "float4 units");
+
+// samples (this one included) whose low-corner texel stays on this side of the sub-block boundary
+// along one axis: ub = texel coordinate of this sample, du = its increment per sample, the
+// sub-block spans [lo, hi).  Good to a texel (the cells carry a one-texel halo for exactly this).
+VR_DEV int run_axis(float ub, float du, float lo, float hi)
+{
+    const float dist = du > 0.f ? hi - ub : ub - lo;
+    const float q = vmax(dist, 0.f) * __builtin_amdgcn_rcpf(fabsf(du));
+    return du == 0.f ? kRunCap : (int)vmin(q, (float)kRunCap) + 1;
+}
+
+template <typename VT, bool SKIP_LDS, bool FP>
+__global__ __launch_bounds__(kBlockDim) VR_OCC void vr_march_kernel(
+    VolView vv, BrickView bricks, TfView tf, SkipView skip, CellView cells, FrameView fr,
+    vrhip_camera_params cam, vrhip_rendering_params rp, vrhip_raycast_params rc)
+{
+    const uint32_t n_rays = *fr.live_count;   // written by the pre-pass (previous kernel on the stream)
+    if (n_rays == 0) return;
+    extern __shared__ float4 s_mem[];
+    // LDS: [results, 4 waves][t queue, 4 waves][slot map, 4 waves][opaque list, 4 waves][tff_n float4][skip words + 1]
+    const uint32_t wv = threadIdx.x >> 6;
+    float4 *s_res = s_mem + wv * (64 * kQ);
+    float *s_t = reinterpret_cast<float *>(s_mem + (kBlockDim / 64) * (64 * kQ)) + wv * (64 * kQ);
+    uint8_t *s_map = reinterpret_cast<uint8_t *>(s_mem + (kBlockDim / 64) * (64 * kQ) + (kBlockDim / 64) * (64 * kQ) / 4) +
+                     wv * (64 * kQ);
+    uint16_t *s_map2 = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(s_mem + (kBlockDim / 64) * (64 * kQ) +
+                                                                                (kBlockDim / 64) * (64 * kQ) / 4) +
+                                                    (kBlockDim / 64) * (64 * kQ)) + wv * (64 * kQ);
+    float4 *s_tff = s_mem + (kBlockDim / 64) * kMarchWaveBytes / 16;
+    uint32_t *s_skip = reinterpret_cast<uint32_t *>(s_tff + tf.tff_n);
+    for (uint32_t i = threadIdx.x; i < tf.tff_n; i += kBlockDim) s_tff[i] = tf.tff[i];
+    if (SKIP_LDS)
+        for (uint32_t i = threadIdx.x; i <= skip.n_words; i += kBlockDim) s_skip[i] = skip.bits[i];
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const int tffn = (int)tf.tff_n;
+    const Vol<VT, 0, FP> vol = make_vol<VT, 0, FP>(vv, nullptr);
+    const f3 resf = mk3(vol.fw, vol.fh, vol.fd);
+    const f3 voxLen = mk3(1.f / vol.fw, 1.f / vol.fh, 1.f / vol.fd);
+    const float refInterval = 1.f / rc.samplingRate;
+    const Grid grid = make_grid(bricks, rc, skip.n_words, true);
+    const uint32_t *sb = SKIP_LDS ? s_skip : skip.bits;
+    const bool use_mask = cells.bmask != nullptr && rp.useLinear != 0;
+    const int sx = cells.bex - 2, sy = cells.bey - 2, sz = cells.bez - 2;   // log2 of the sub-block edge
+    const bool shade_mode = rp.illumType == 1;
+    const uint32_t kRefillLanes = (fr.refill_min ? fr.refill_min : 16u) * 4u;   // idle lanes before a refill
+    const uint32_t march_micro = fr.march_micro ? fr.march_micro : (uint32_t)kMicro;
+    const uint32_t march_fill = fr.march_fill ? fr.march_fill : (uint32_t)kFill;
+
+    unsigned long long n0 = 0, n1 = 0;
+#ifdef VR_MARCH_STATS
+    unsigned long long ms_acc[16] = {0};
+#endif
+    bool have = false, drained = false;
+    uint32_t gx = 0, gy = 0, out_index = 0;
+    // the empty words of the two bricks the ray has touched last (key = packed brick coordinates)
+    uint32_t key0 = 0xffffffffu, key1 = 0xffffffffu;
+    unsigned long long m0 = 0, m1 = 0;
+    float du = 0.f, dv = 0.f, ds = 0.f, inv_step = 0.f;   // texel increments per sample, 1 / stepSize
+    int run_left = 0;   // samples the ray still has in the (not empty) sub-block it was last classified in
+    RayCtx c;
+    RayDyn d;
+    setup_ray<true>(0u, 0u, false, fr, cam, rp, rc, resf, voxLen, grid, c, d, rp.seed);   // S_DONE
+
+    for (;;) {
+        // ---- retire finished rays, take new ones
+        {
+            const bool idle = d.state == S_DONE;
+            const unsigned long long idle_m = __ballot(idle);
+            const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle_m);
+            const bool all_idle = idle_m == ~0ull;
+            if ((!drained && n_idle >= kRefillLanes) || all_idle) {
+                if (idle && have) {
+                    write_pixel<false>(fr, rp, c, d, voxLen, gx, gy, (size_t)out_index);
+                    have = false;
+                }
+                if (!drained) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(fr.queue_head, n_idle);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base + n_idle >= n_rays) drained = true;
+                    if (idle) {
+                        const uint32_t ri = base + (uint32_t)__builtin_popcountll(idle_m & ((1ull << lane) - 1ull));
+                        have = ri < n_rays;
+                        if (have) {
+                            const ContRec rec = fr.live_rays[ri];
+                            gx = rec.pix & 0xffffu;
+                            gy = rec.pix >> 16;
+                            out_index = rec.out_index;
+                            const uint32_t frame_idx = (uint32_t)rec.state >> 8;
+                            setup_ray<true>(gx, gy, true, fr, cam, rp, rc, resf, voxLen, grid, c, d,
+                                            fr.seeds ? fr.seeds[frame_idx] : rp.seed);
+                            d.state = rec.state & 0xff;
+                            d.t = rec.t; d.t_exit = rec.t_exit; d.alpha = rec.alpha;
+                            d.r0 = rec.r0; d.r1 = rec.r1; d.r2 = rec.r2;
+                            d.c0 = rec.cx; d.c1 = rec.cy; d.c2 = rec.cz;
+                            d.tv0 = rec.tv0; d.tv1 = rec.tv1; d.tv2 = rec.tv2;
+                            fetch_skip_word(sb, grid, d);
+                            key0 = key1 = 0xffffffffu;
+                            run_left = 0;
+                            du = (c.dir.x * c.stepSize) * (0.5f * vol.fw);
+                            dv = (c.dir.y * c.stepSize) * (0.5f * vol.fh);
+                            ds = (c.dir.z * c.stepSize) * (0.5f * vol.fd);
+                            inv_step = 1.0f / c.stepSize;
+                        }
+                    }
+                }
+                if (!__ballot(d.state != S_DONE)) {
+                    if (drained) break;
+                    continue;
+                }
+            }
+        }
+
+        VR_MARK("A_begin");
+        VR_MS(0, 1);                                                       // rounds
+        VR_MS(1, __builtin_popcountll(__ballot(d.state != S_DONE)));       // live lanes, summed over rounds
+        // ---- stage A: stepping.  n = samples this ray has queued in this round
+        uint32_t n = 0, queued = 0;
+#pragma unroll 1
+        for (uint32_t iter = 0; iter < march_micro && queued < march_fill; ++iter) {
+            const bool in_brick = d.state == S_BRICK;
+            const bool stepping = d.state == S_SAMPLE && n < (uint32_t)kQ;
+            const bool any_brick = __ballot(in_brick) != 0ull, any_step = __ballot(stepping) != 0ull;
+            if (!any_brick && !any_step) break;
+            VR_MS(2, 1);                                                   // stage-A iterations
+            VR_MS(3, any_brick ? 1 : 0);                                   // ... that ran a DDA step
+            VR_MS(4, __builtin_popcountll(__ballot(in_brick)));            // lanes in it
+            VR_MS(5, any_step ? 1 : 0);                                    // ... that ran a sample micro-step
+            VR_MS(6, __builtin_popcountll(__ballot(stepping)));            // lanes in it
+            if (any_brick) dda_step<0>(sb, grid, c, d, n0, n1);   // (lanes that are not in a brick: no effect)
+            VR_MARK("A_dda_end");
+            if (any_step) {
+                const uint32_t n_before = n;
+                if (stepping) {
+                    if (!(d.t < d.t_exit)) {
+                        // the inner loop ends through its condition (:790): alpha < 0.98 here (an ERT break
+                        // would have ended the ray), so :882 is t >= tfar alone
+                        if (d.t >= c.tfar) d.state = S_DONE;                                             // :882
+                        else if (d.c0 == c.exit0 || d.c1 == c.exit1 || d.c2 == c.exit2) d.state = S_DONE;  // :883
+                        else { d.t = d.t_exit; d.state = S_BRICK; }                                     // :884
+                        run_left = 0;
+                    } else {
+                        // samples 0 .. safe - 1 from here certainly pass :790 and fail :868
+                        const int safe = (int)floorf((vmin(d.t_exit, c.tfar) - d.t) * inv_step) - 2;
+                        bool emit = run_left > 0;       // still inside a sub-block that is not empty
+                        if (!emit) {
+                            bool empty = false, miss = false;
+                            int run = kRunCap;
+                            if (use_mask) {
+                                // low-corner texel of this sample's fetch (:791-793, Vol::linear), good to a texel
+                                const f3 pos = add3(c.cam, scale3(c.dir, d.t - c.offset));
+                                const float ub = (pos.x * 0.5f + 0.5f) * vol.fw - 0.5f;
+                                const float vb = (pos.y * 0.5f + 0.5f) * vol.fh - 0.5f;
+                                const float wb = (pos.z * 0.5f + 0.5f) * vol.fd - 0.5f;
+                                const int x0 = iclamp((int)floorf(ub), 0, vol.w1);
+                                const int y0 = iclamp((int)floorf(vb), 0, vol.h1);
+                                const int z0 = iclamp((int)floorf(wb), 0, vol.d1);
+                                const uint32_t bx = (uint32_t)(x0 >> cells.bex), by = (uint32_t)(y0 >> cells.bey);
+                                const uint32_t bz = (uint32_t)(z0 >> cells.bez);
+                                const uint32_t key = bx | (by << 8) | (bz << 16);
+                                if (key == key0 || key == key1) {
+                                    const unsigned long long m = key == key0 ? m0 : m1;
+                                    const uint32_t bit = (uint32_t)((x0 >> sx) & 3) | ((uint32_t)((y0 >> sy) & 3) << 2) |
+                                                         ((uint32_t)((z0 >> sz) & 3) << 4);
+                                    empty = (m >> bit) & 1ull;
+                                    // all samples whose low-corner texel stays in this sub-block
+                                    run = min(min(run_axis(ub, du, (float)((x0 >> sx) << sx), (float)(((x0 >> sx) + 1) << sx)),
+                                                  run_axis(vb, dv, (float)((y0 >> sy) << sy), (float)(((y0 >> sy) + 1) << sy))),
+                                              run_axis(wb, ds, (float)((z0 >> sz) << sz), (float)(((z0 >> sz) + 1) << sz)));
+                                } else {
+                                    // the word of a brick this ray has not looked at lately: loaded now, used by
+                                    // this lane's next micro-step
+                                    miss = true;
+                                    key1 = key0; m1 = m0;
+                                    key0 = key;
+                                    m0 = cells.bmask[(bz * (uint32_t)grid.bh + by) * (uint32_t)grid.bw + bx];
+                                }
+                            }
+                            if (!miss) {
+                                if (!empty) { emit = true; run_left = run; }
+                                else if (safe >= 1) d.t = vr_leap(d.t, c.stepSize, (uint32_t)min(run, safe));
+                                else if (d.t >= c.tfar) d.state = S_DONE;         // :868 after a no-op :865-867
+                                else d.t = d.t + c.stepSize;                      // :879
+                            }
+                        }
+                        if (emit) {
+                            s_t[lane * kQ + n] = d.t;                             // evaluate this one
+                            ++n;
+                            --run_left;
+                            if (d.t >= c.tfar) d.state = S_DONE;                  // :868: the ray's last sample
+                            else {
+                                d.t = d.t + c.stepSize;                           // :879
+#pragma unroll
+                                for (int j = 1; j < kQ; ++j) {
+                                    // certainly in the segment and not the ray's last; beyond the sub-block's
+                                    // run the next micro-step classifies again
+                                    if (n < (uint32_t)kQ && j < safe && run_left > 0) {
+                                        s_t[lane * kQ + n] = d.t;
+                                        ++n;
+                                        --run_left;
+                                        d.t = d.t + c.stepSize;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+                queued += (uint32_t)__builtin_popcountll(__ballot(n != n_before));
+            }
+        }
+
+        VR_MARK("A_end");
+        // ---- dense list of this round's samples: j-major (sample j of every ray that has one)
+        uint32_t total = 0;
+#pragma unroll
+        for (int j = 0; j < kQ; ++j) {
+            const bool has = n > (uint32_t)j;
+            const unsigned long long m = __ballot(has);
+            if (has)
+                s_map[total + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
+                    (uint8_t)(lane * kQ + j);
+            total += (uint32_t)__builtin_popcountll(m);
+        }
+        VR_MS(7, total);                                                   // samples queued
+        VR_MS(8, (total + 63u) / 64u);                                     // stage-B passes
+        if (total == 0u) continue;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        VR_MARK("B_begin");
+        // ---- stage B1: density and transfer function over the dense list (:791-808, one sample per
+        // lane); the samples with a non-zero opacity -- the only ones of which anything survives the
+        // compositing (op = 1 - powr(1, y) = 0 exactly otherwise) -- go to a second dense list
+        uint32_t total2 = 0;
+        for (uint32_t base = 0; base < total; base += 64u) {
+            const uint32_t e = base + lane;
+            const bool mine = e < total;
+            const uint32_t slot = mine ? (uint32_t)s_map[e] : lane * kQ;
+            const int owner = (int)(slot / kQ);
+            const float ts = mine ? s_t[slot] : 0.f;
+            // the owner ray's invariants (every lane takes part in the exchange)
+            const f3 ocam = mk3(__shfl(c.cam.x, owner, 64), __shfl(c.cam.y, owner, 64), __shfl(c.cam.z, owner, 64));
+            const f3 odir = mk3(__shfl(c.dir.x, owner, 64), __shfl(c.dir.y, owner, 64), __shfl(c.dir.z, owner, 64));
+            const float ooff = __shfl(c.offset, owner, 64);
+            const f3 pos = add3(ocam, scale3(odir, ts - ooff));                         // :791
+            const f3 pk = mk3(pos.x * 0.5f + 0.5f, pos.y * 0.5f + 0.5f, pos.z * 0.5f + 0.5f);   // :793
+            const float dens = rp.useLinear ? vol.linear(pk.x, pk.y, pk.z) : vol.nearest(pk.x, pk.y, pk.z);
+            const float4 tfc = tff_linear(s_tff, tffn, dens);                           // :808
+            const bool need = mine && tfc.w != 0.f;
+            const bool lit = need && shade_mode && tfc.w > 0.1f;                        // :809
+            if (mine) s_res[slot] = need ? tfc : make_float4(0.f, 0.f, 0.f, 0.f);
+            const unsigned long long m = __ballot(need);
+            if (need)
+                s_map2[total2 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
+                    (uint16_t)(slot | (lit ? 0x8000u : 0u));
+            total2 += (uint32_t)__builtin_popcountll(m);
+        }
+        VR_MS(10, total2);
+        VR_MS(11, (total2 + 63u) / 64u);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        VR_MARK("B2_begin");
+        // ---- stage B2: opacity correction, and gradient + Blinn-Phong where the sample is lit
+        // (:809-830, :864), over the list of opaque samples
+        for (uint32_t base = 0; base < total2; base += 64u) {
+            const uint32_t e = base + lane;
+            const bool mine = e < total2;
+            const uint32_t tag = mine ? (uint32_t)s_map2[e] : lane * kQ;
+            const uint32_t slot = tag & 0x7fffu;
+            const bool lit = mine && (tag & 0x8000u);
+            const int owner = (int)(slot / kQ);
+            float4 tfc = s_res[slot];
+            if (__ballot(lit)) {
+                const float ts = s_t[slot];
+                const f3 ocam = mk3(__shfl(c.cam.x, owner, 64), __shfl(c.cam.y, owner, 64), __shfl(c.cam.z, owner, 64));
+                const f3 odir = mk3(__shfl(c.dir.x, owner, 64), __shfl(c.dir.y, owner, 64), __shfl(c.dir.z, owner, 64));
+                const float ooff = __shfl(c.offset, owner, 64);
+                const f3 lgt = mk3(__shfl(c.lgt.x, owner, 64), __shfl(c.lgt.y, owner, 64), __shfl(c.lgt.z, owner, 64));
+                const f3 hv = mk3(__shfl(c.hv.x, owner, 64), __shfl(c.hv.y, owner, 64), __shfl(c.hv.z, owner, 64));
+                const int hvalid = __shfl(c.hvalid ? 1 : 0, owner, 64);
+                if (lit) {
+                    const f3 pos = add3(ocam, scale3(odir, ts - ooff));
+                    const f3 pk = mk3(pos.x * 0.5f + 0.5f, pos.y * 0.5f + 0.5f, pos.z * 0.5f + 0.5f);
+                    const f3 g = vol.neg_gradient(pk.x, pk.y, pk.z);                    // :814
+                    const float ndl = vmax(0.f, dot3(g, lgt));                          // :294-303, :280-291
+                    float sp = hvalid ? vr_powr(vmax(dot3(g, hv), 0.f), 40.f) : 0.0f;
+                    sp = sp * 0.15f;
+                    tfc.x = ((tfc.x * 0.15f) + ((tfc.x * ndl) * 0.7f)) + sp;
+                    tfc.y = ((tfc.y * 0.15f) + ((tfc.y * ndl) * 0.7f)) + sp;
+                    tfc.z = ((tfc.z * 0.15f) + ((tfc.z * ndl) * 0.7f)) + sp;
+                }
+            }
+            if (mine) {
+                tfc.w = 1.f - vr_powr(1.f - tfc.w, refInterval);                        // :864
+                s_res[slot] = tfc;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        VR_MARK("C_begin");
+        // ---- stage C: compositing, in ray order (:856, :865-879)
+        {
+            bool alive = true;
+#pragma unroll
+            for (int j = 0; j < kQ; ++j) {
+                if (alive && n > (uint32_t)j) {
+                    const float4 r = s_res[lane * kQ + j];
+                    const float q0 = (c.env0 - r.x) * r.w, q1 = (c.env1 - r.y) * r.w, q2 = (c.env2 - r.z) * r.w;
+                    const float oma = 1.f - d.alpha;
+                    d.r0 = d.r0 - q0 * oma;
+                    d.r1 = d.r1 - q1 * oma;
+                    d.r2 = d.r2 - q2 * oma;
+                    d.alpha = d.alpha + r.w * oma;
+                    // (double)alpha > 0.98 <=> alpha >= 0.98f (ERT_THRESHOLD, :28): the ray ends here,
+                    // whatever stage A has queued behind this sample
+                    if (d.alpha >= 0.98f) { d.state = S_DONE; alive = false; VR_MS(9, n - 1u - (uint32_t)j); }   // evaluated in vain
+                }
+            }
+        }
+    }
+#ifdef VR_MARCH_STATS
+    if (lane == 0)
+        for (int i = 0; i < 12; ++i)
+            if (i != 9) atomicAdd(&g_march_stats[i], ms_acc[i]);
+    {
+        unsigned long long w = wave_sum(ms_acc[9]);
+        if (lane == 0) atomicAdd(&g_march_stats[9], w);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------ phase 1
@@ -1507,6 +1956,21 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
         frame.live = nullptr;
     }
     hipError_t e;
+    if (ESS && INSTR == 0 && !XS && frame.live && frame.live_rays && frame.march && !a.raycast.contours &&
+        !a.raycast.aerial) {
+        // the decoupled march on the pre-pass's ray list: the whole frame in this one launch
+        auto km = vr_march_kernel<VT, SKIP_LDS, FP>;
+        size_t ldsm = (size_t)(kBlockDim / 64) * kMarchWaveBytes + (size_t)a.tf.tff_n * sizeof(float4);
+        if (SKIP_LDS) ldsm += ((size_t)a.skip.n_words + 1) * sizeof(uint32_t);
+        int nbm = 0;
+        e = prepare_variant(km, ldsm, &nbm, "raycast march", a.num_cus);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(km, dim3(cus * (uint32_t)nbm), block, ldsm, stream, a.vol, a.bricks, a.tf, a.skip,
+                           a.cells, frame, a.cam, a.render, a.raycast);
+        e = hipGetLastError();
+        if (e == hipSuccess && a.mid_event) e = hipEventRecord(a.mid_event, stream);
+        return e;
+    }
     if (ESS && INSTR == 0 && !XS && frame.live && frame.live_rays) {   // phase 1 on the ray list
         auto kr = vr_raycast_rays_kernel<VT, SKIP_LDS, FP>;
         int nbr = 0;
@@ -1568,6 +2032,21 @@ hipError_t launch_typed(const RaycastLaunch &a, hipStream_t stream)
 
 } // namespace
 
+#ifdef VR_MARCH_STATS
+// diagnostic builds only: read (and optionally clear) the march kernel's round statistics
+extern "C" int vrhip_debug_march_stats(unsigned long long out[16], int reset)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_march_stats), 16 * sizeof(unsigned long long)) != hipSuccess)
+        return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_march_stats), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
 #ifdef VR_STAMPS
 // diagnostic builds only: start/end clock of every wave of the last launches
 extern "C" int vrhip_debug_wave_spans(unsigned long long *out /* [2][2][8192] */)
@@ -1610,6 +2089,58 @@ hipError_t vr_launch_raycast(const RaycastLaunch &a, hipStream_t stream)
         e = hipGetLastError();
     }
     return e;
+}
+
+namespace {
+
+// SkipView::near_bits: bytes "brick is not skipped", dilated by `radius` bricks along one axis per
+// launch, then packed to bits (same bit order as the skip bitmap)
+__global__ __launch_bounds__(kBlockDim) void vr_skip_live_kernel(const uint32_t *bits, size_t n, uint8_t *live)
+{
+    const size_t i = (size_t)blockIdx.x * kBlockDim + threadIdx.x;
+    if (i < n) live[i] = ((bits[i >> 5] >> (i & 31u)) & 1u) ? 0 : 1;
+}
+__global__ __launch_bounds__(kBlockDim) void vr_skip_dilate_kernel(const uint8_t *in, uint8_t *out, int bw, int bh,
+                                                                   int bd, int axis, int radius)
+{
+    const size_t n = (size_t)bw * bh * bd;
+    const size_t i = (size_t)blockIdx.x * kBlockDim + threadIdx.x;
+    if (i >= n) return;
+    const int x = (int)(i % (size_t)bw), y = (int)((i / (size_t)bw) % (size_t)bh), z = (int)(i / ((size_t)bw * bh));
+    const int pos = axis == 0 ? x : axis == 1 ? y : z, len = axis == 0 ? bw : axis == 1 ? bh : bd;
+    const size_t stride = axis == 0 ? 1 : axis == 1 ? (size_t)bw : (size_t)bw * bh;
+    uint8_t v = 0;
+    for (int k = max(pos - radius, 0); k <= min(pos + radius, len - 1); ++k) v |= in[i + (size_t)(k - pos) * stride];
+    out[i] = v;
+}
+__global__ __launch_bounds__(kBlockDim) void vr_skip_pack_kernel(const uint8_t *live, size_t n, uint32_t *bits,
+                                                                 uint32_t n_words)
+{
+    const size_t i = (size_t)blockIdx.x * kBlockDim + threadIdx.x;
+    const unsigned long long m = __ballot(i < n && live[i] != 0);
+    if ((threadIdx.x & 63) == 0) {
+        const size_t w = (i >> 6) * 2;
+        if (w < n_words) bits[w] = (uint32_t)m;
+        if (w + 1 < n_words) bits[w + 1] = (uint32_t)(m >> 32);
+    }
+}
+
+} // namespace
+
+hipError_t vr_launch_skip_near(const BrickView &bricks, const uint32_t *bits, uint32_t n_words, uint32_t radius,
+                               uint8_t *scratch, uint32_t *near_bits, hipStream_t stream)
+{
+    const size_t n = (size_t)bricks.bw * bricks.bh * bricks.bd;
+    dim3 grid((unsigned)((n + kBlockDim - 1) / kBlockDim)), block(kBlockDim);
+    uint8_t *a = scratch, *b = scratch + n;
+    hipLaunchKernelGGL(vr_skip_live_kernel, grid, block, 0, stream, bits, n, a);
+    for (int axis = 0; axis < 3; ++axis) {
+        hipLaunchKernelGGL(vr_skip_dilate_kernel, grid, block, 0, stream, (const uint8_t *)a, b, bricks.bw, bricks.bh,
+                           bricks.bd, axis, (int)radius);
+        uint8_t *t = a; a = b; b = t;
+    }
+    hipLaunchKernelGGL(vr_skip_pack_kernel, grid, block, 0, stream, (const uint8_t *)a, n, near_bits, n_words);
+    return hipGetLastError();
 }
 
 hipError_t vr_launch_skipmap(const BrickView &bricks, int format, float inv_max, const TfView &tf,

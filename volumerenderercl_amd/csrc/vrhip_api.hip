@@ -61,10 +61,16 @@ struct vrhip_renderer {
     uint32_t *skip_bits = nullptr;
     uint32_t skip_words = 0, skip_cap = 0;
     bool skip_dirty = true;
+    // patch culling of the DDA pre-pass: the skip bitmap dilated by cull_radius bricks (SkipView::near_bits)
+    uint32_t *near_bits = nullptr;
+    uint8_t *near_scratch = nullptr;
+    uint32_t cull_radius = 4;         // VRHIP_CULL_RADIUS (bricks; 0 = no patch culling)
 
     // cell grid of the current timestep + TF (CellView, vr_internal.h): opacity bound for the
     // path tracer, empty bits for the ray caster
-    CellView cells = {nullptr, nullptr, 0, 0, 0, 3};
+    CellView cells = {nullptr, nullptr, 0, 0, 0, 3, nullptr, 0, 0, 0};
+    unsigned long long *cell_bmask = nullptr;   // CellView::bmask (per ESS brick)
+    size_t bmask_cap = 0;
     float *cell_bound = nullptr;
     uint32_t *cell_empty = nullptr;
     float *cell_sparse = nullptr;  // 13 x 4096 floats of scratch for the TF range-max table
@@ -93,6 +99,8 @@ struct vrhip_renderer {
     uint32_t *order = nullptr;        // sorted permutation of the suspended rays
     ContRec *live_rays = nullptr;     // pre-pass output: live rays with their DDA state (phase 1's list)
     bool ray_list = true;             // VRHIP_NO_RAYLIST=1: phase 1 walks the live patches instead
+    bool march = false;               // VRHIP_MARCH=1: vr_march_kernel instead of the two-phase march (measured, not faster)
+    uint32_t march_micro = 0, march_fill = 0;   // VRHIP_MARCH_MICRO / VRHIP_MARCH_FILL (0 = built-in)
     uint32_t *seeds_dev = nullptr;    // kMaxBatchFrames jitter seeds of a batch of frames
     bool sort_cont = true;            // VRHIP_NO_SORT=1 disables
     LiveTile *live = nullptr;         // DDA pre-pass output: patches with rays that sample
@@ -450,12 +458,21 @@ int ensure_skipmap(vrhip_renderer *r)
         if (r->skip_bits) VR_HIP(r, hipFree(r->skip_bits));
         r->skip_bits = nullptr;
         VR_HIP(r, hipMalloc((void **)&r->skip_bits, ((size_t)words + 1) * sizeof(uint32_t)));
+        if (r->near_bits) VR_HIP(r, hipFree(r->near_bits));
+        if (r->near_scratch) VR_HIP(r, hipFree(r->near_scratch));
+        r->near_bits = nullptr;
+        r->near_scratch = nullptr;
+        VR_HIP(r, hipMalloc((void **)&r->near_bits, ((size_t)words + 1) * sizeof(uint32_t)));
+        VR_HIP(r, hipMalloc((void **)&r->near_scratch, 2 * n));
         r->skip_cap = words + 1;
     }
     r->skip_words = words;
     VR_HIP(r, vr_launch_skipmap(make_brick_view(r, r->vols[r->timestep].bricks), r->format,
                                 inv_max_of(r->format), make_tf_view(r), r->skip_bits, words,
                                 r->stream));
+    if (r->cull_radius)
+        VR_HIP(r, vr_launch_skip_near(make_brick_view(r, r->vols[r->timestep].bricks), r->skip_bits, words,
+                                      r->cull_radius, r->near_scratch, r->near_bits, r->stream));
     r->skip_dirty = false;
     return VRHIP_OK;
 }
@@ -496,6 +513,33 @@ int ensure_cells(vrhip_renderer *r)
                                     r->cell_sparse, r->cell_bound, r->cell_empty, r->stream));
     g.bound = r->cell_bound;
     g.empty = r->cell_empty;
+    // the empty bits per ESS brick, for the march kernel (ESS bricks of >= 4 voxels per axis)
+    g.bmask = nullptr;
+    g.bex = g.bey = g.bez = 0;
+    if (r->bricks_valid) {
+        int lg[3];
+        bool ok = true;
+        for (int i = 0; i < 3; ++i) {
+            lg[i] = 0;
+            while ((1u << lg[i]) < r->brick_edge[i]) ++lg[i];
+            ok = ok && lg[i] >= 2 && r->brick_tex[i] <= 256u;
+        }
+        if (ok) {
+            const size_t nb = (size_t)r->brick_tex[0] * r->brick_tex[1] * r->brick_tex[2];
+            if (nb > r->bmask_cap) {
+                VR_HIP(r, hipStreamSynchronize(r->stream));
+                if (r->cell_bmask) VR_HIP(r, hipFree(r->cell_bmask));
+                r->cell_bmask = nullptr;
+                r->bmask_cap = 0;
+                VR_HIP(r, hipMalloc((void **)&r->cell_bmask, nb * sizeof(unsigned long long)));
+                r->bmask_cap = nb;
+            }
+            g.bex = lg[0]; g.bey = lg[1]; g.bez = lg[2];
+            VR_HIP(r, vr_launch_cell_bmask(make_vol_view(r, s.dev), g, (int)r->brick_tex[0], (int)r->brick_tex[1],
+                                           (int)r->brick_tex[2], r->cell_bmask, r->stream));
+            g.bmask = r->cell_bmask;
+        }
+    }
     r->cells = g;
     r->pt_dirty = false;
     return VRHIP_OK;
@@ -595,6 +639,8 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
     a->skip.n_words = r->skip_words;
     a->skip.in_lds = ((size_t)r->skip_words + 1) * sizeof(uint32_t) <= kSkipLdsMaxBytes ? 1u : 0u;
     if (getenv("VRHIP_SKIP_GLOBAL")) a->skip.in_lds = 0;   // experiments: bitmap from L2/HBM
+    a->skip.near_bits = r->cull_radius ? r->near_bits : nullptr;
+    a->skip.near_r = r->cull_radius;
     a->frame.W = width;
     a->frame.H = height;
     // padded NDRange of the reference (volumerendercl.cpp:513-514): a full extra group
@@ -612,6 +658,9 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
     a->frame.refill_min = r->refill_min;
     a->frame.live = r->prepass ? r->live : nullptr;
     a->frame.live_rays = (r->prepass && r->ray_list) ? r->live_rays : nullptr;
+    a->frame.march = r->march ? 1u : 0u;
+    a->frame.march_micro = r->march_micro;
+    a->frame.march_fill = r->march_fill;
     a->frame.live_count = r->queue_head + 3;
     a->frame.cost = r->sort_cont ? r->cost : nullptr;
     a->frame.order = r->sort_cont && r->cost ? r->order : nullptr;
@@ -637,7 +686,7 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
     a->cells = r->cells;
     if (!r->pt_cull) a->cells.bound = nullptr;
     // the empty bits are those of TF(channel 0): not what a CL_RG / CL_RGBA sample's opacity is
-    if (!r->skip_empty || r->channels > 1) a->cells.empty = nullptr;
+    if (!r->skip_empty || r->channels > 1) { a->cells.empty = nullptr; a->cells.bmask = nullptr; }
     a->format = r->format;
     a->use_ess = r->use_ess ? 1 : 0;
     a->instr = r->stats_enabled ? 1 : 0;
@@ -783,6 +832,13 @@ int vrhip_create(int device_id, vrhip_renderer **out)
     if (const char *b = getenv("VRHIP_ROUND_BUDGET")) r->round_budget = (uint32_t)atoi(b);   // tuning
     if (getenv("VRHIP_NO_PREPASS")) r->prepass = false;        // experiments: phase 1 walks every patch
     if (getenv("VRHIP_NO_RAYLIST")) r->ray_list = false;       // experiments: phase 1 on live patches
+    if (getenv("VRHIP_MARCH")) r->march = true;                // experiments / A-B: the decoupled march kernel
+    if (const char *e = getenv("VRHIP_CULL_RADIUS")) {
+        const int v = atoi(e);
+        if (v >= 0 && v <= 64) r->cull_radius = (uint32_t)v;
+    }
+    if (const char *e = getenv("VRHIP_MARCH_MICRO")) r->march_micro = (uint32_t)atoi(e);
+    if (const char *e = getenv("VRHIP_MARCH_FILL")) r->march_fill = (uint32_t)atoi(e);
     if (getenv("VRHIP_NO_SORT")) r->sort_cont = false;         // experiments: phase 2 in append order
     if (getenv("VRHIP_PT_NO_CULL")) r->pt_cull = false;        // experiments: no opacity-bound culling
     if (getenv("VRHIP_NO_EMPTY_SKIP")) r->skip_empty = false;  // experiments: no empty-run skipping
@@ -824,9 +880,12 @@ void vrhip_destroy(vrhip_renderer *r)
     if (r->order) (void)hipFree(r->order);
     if (r->live_rays) (void)hipFree(r->live_rays);
     if (r->skip_bits) (void)hipFree(r->skip_bits);
+    if (r->near_bits) (void)hipFree(r->near_bits);
+    if (r->near_scratch) (void)hipFree(r->near_scratch);
     if (r->cell_bound) (void)hipFree(r->cell_bound);
     if (r->cell_empty) (void)hipFree(r->cell_empty);
     if (r->cell_sparse) (void)hipFree(r->cell_sparse);
+    if (r->cell_bmask) (void)hipFree(r->cell_bmask);
     if (r->ev0) (void)hipEventDestroy(r->ev0);
     if (r->ev1) (void)hipEventDestroy(r->ev1);
     if (r->evm) (void)hipEventDestroy(r->evm);
