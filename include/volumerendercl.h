@@ -92,7 +92,8 @@ public:
     void loadSyntheticVolume(const std::string &kind, unsigned int res, DatRawReader::data_format f);
     // Image tiles: compact device buffer [n][tile_h][tile_w][4].
     void renderTiles(size_t width, size_t height, size_t tile_w, size_t tile_h,
-                     const std::vector<unsigned int> &tile_ids, float *out_tiles_dev);
+                     const std::vector<unsigned int> &tile_ids, float *out_tiles_dev,
+                     bool advanceIteration = false);   // true: the frame counts for the running mean (:540)
     void setSeed(unsigned int seed);   // pin the per-frame jitter seed
     void clearSeed();                  // back to the std::mt19937 sequence
     vrhip_renderer *handle() { return _r; }

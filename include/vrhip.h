@@ -208,6 +208,14 @@ int vrhip_get_image_ess(vrhip_renderer *r, uint32_t width, uint32_t height, uint
                         uint8_t *hit_out);
 int vrhip_set_image_ess(vrhip_renderer *r, uint32_t width, uint32_t height, const uint8_t *hit_in,
                         const uint8_t *hit_out);
+/* Image-tile gather, root side: the frame from the gathered tiles.  `staging_dev` holds
+ * tile slots of tile_w x tile_h RGBA float pixels (the peers' blocks as received, one after the
+ * other); slot_of_tile_dev[t] is the slot of tile t (tiles numbered row-major over the frame).
+ * One thread per pixel, enqueued on the renderer's stream; frame_dev = width x height x 4 floats. */
+int vrhip_assemble_frame(vrhip_renderer *r, const float *staging_dev, const uint32_t *slot_of_tile_dev,
+                         uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h,
+                         float *frame_dev);
+
 /* A batch of n_frames <= 32 INDEPENDENT frames -- same camera and parameters, frame f with jitter
  * seed seeds[f] (rendering_params.seed is not used) -- in ONE set of launches: the work queue holds
  * every patch once per frame, so a small tile share still fills the GPU and the latency chain of

@@ -175,6 +175,7 @@ def test_empty_skipping_is_exact(vr, monkeypatch):
     table = common.tffs()["default"]
     W, H = 128, 96
     outs = []
+    monkeypatch.setenv("VRHIP_EMPTY_SKIP", "1")      # (by default only where the ESS bricks are >= 32 voxels)
     for env in (None, "1"):
         if env:
             monkeypatch.setenv("VRHIP_NO_EMPTY_SKIP", env)
@@ -195,6 +196,52 @@ def test_empty_skipping_is_exact(vr, monkeypatch):
         assert outs[i][1] == outs[i + 2][1]
     np.testing.assert_array_equal(outs[1][0], ref)
     assert outs[1][1] == rstats
+
+
+@pytest.mark.parametrize("env", [{"VRHIP_CULL_RADIUS": "0"}, {"VRHIP_CULL_RADIUS": "12"},
+                                 {"VRHIP_MARCH": "1"}, {"VRHIP_MARCH": "1", "VRHIP_MARCH_MICRO": "1"},
+                                 {"VRHIP_MARCH_MICRO": "3"}, {"VRHIP_EMPTY_SKIP": "1", "VRHIP_MARCH_MICRO": "6"}])
+def test_schedules_and_culling_do_not_change_pixels(vr, monkeypatch, env):
+    """Scheduling devices of round 2 -- patch culling in the DDA pre-pass (off / wide radius), the
+    decoupled march kernel (vr_march_kernel: per-brick empty words, exact leaps of the t chain with
+    vr_leap, dense evaluation queues), leap stepping inside the two-phase kernels -- on a 256^3 field
+    with large empty regions, bricks of 4 voxels, three views, two seeds: bit-identical to the
+    default schedule's frames and equal to the oracle's."""
+    res = (256, 256, 256)
+    vol = vro.synth_volume("shells", list(res), UCHAR)
+    vol[:, :, :96] = 0            # a large empty slab the culling can work with
+    tff = common.tffs()["default"]
+    W, H = 200, 152
+    frames = {}
+    for name, e in (("default", {"VRHIP_EMPTY_SKIP": "1"}), ("variant", dict(env, VRHIP_EMPTY_SKIP="1"))):
+        for k, v in e.items():
+            monkeypatch.setenv(k, v)
+        r2 = VolumeRenderCL()
+        r2.initialize()
+        try:
+            r2.loadVolumeArrays([vol], UCHAR)
+            r2.setTransferFunction(tff)
+            for view in ("rot30", "close", "inside"):
+                r2.updateView(common.views()[view])
+                for seed in (SEED, 581869302):
+                    r2.setSeed(seed)
+                    r2.setIteration(0)
+                    frames[(name, view, seed)] = r2.runRaycastNoGL(W, H)
+            if name == "default":
+                r2.updateView(common.views()["rot30"])
+                r2.setSeed(SEED)
+                r2.setIteration(0)
+                cam, rp, rc, pt = common.to_oracle_params(*r2.params())
+                rp.seed, rp.iteration = SEED, 0
+                ref, _, _ = vro.render_tile(vol, UCHAR, tff, cam, rp, rc, pt, W=W, H=H)
+        finally:
+            r2.close()
+        for k in e:
+            monkeypatch.delenv(k, raising=False)
+    np.testing.assert_array_equal(frames[("default", "rot30", SEED)], ref)
+    for (name, view, seed), img in frames.items():
+        if name == "variant":
+            np.testing.assert_array_equal(img, frames[("default", view, seed)], err_msg="%s %s" % (view, seed))
 
 
 def test_pathtrace_culling_is_exact(vr, monkeypatch):
@@ -458,6 +505,35 @@ def test_cpp_host_cli_matches_oracle(tmp_path):
     rc.brickRes[:] = brf + [0]
     ref, _, _ = vro.render_tile(vol, vro.UCHAR, tff, cam, rp, rc, W=W, H=H)
     assert np.abs(got - ref).max() <= TOL
+
+
+@pytest.mark.parametrize("args,frames", [(["--ranks", "1"], 1), (["--ranks", "3", "--loopback", "--tile", "32"], 1),
+                                         (["--ranks", "2", "--loopback", "--tile", "16"], 3),
+                                         (["--ranks", "4", "--loopback", "--tile", "48", "--pathtrace"], 2)])
+def test_cpp_host_tile_ranks_equal_single_renderer(tmp_path, args, frames):
+    """vrhip_render --ranks N (csrc/host/tilegather.cpp): one renderer per rank with the whole
+    volume, interleaved tiles, gather to rank 0 (RCCL send/recv between GPUs; `--loopback` keeps
+    every rank on this box's one GPU and moves the tiles by device copies), one assembly kernel.
+    The written frame -- also the running mean over several frames with the mt19937 seed stream --
+    equals the single renderer's bit for bit."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "volumerenderercl_amd", "vrhip_render")
+    W, H = 200, 136        # not a multiple of the tile sizes
+    base = [exe, "--synth", "shells", "96", "USHORT", "--size", str(W), str(H), "--rotate", "1", "1", "0", "30",
+            "--frames", str(frames)]
+    extra = [a for a in args if a == "--pathtrace"]
+    outs = []
+    for name, more in (("single", extra), ("ranks", args)):
+        out = str(tmp_path / name)
+        res = subprocess.run(base + more + ["--out", out], capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr
+        outs.append(np.fromfile(out + ".rgba.f32", dtype=np.float32).reshape(H, W, 4))
+        if name == "ranks":
+            assert '"ranks": %s' % args[1] in res.stdout
+    assert np.isfinite(outs[0]).all() and outs[0].std() > 0
+    np.testing.assert_array_equal(outs[0], outs[1])
 
 
 def test_cpp_host_cli_pathtrace_matches_oracle(tmp_path):

@@ -1,0 +1,45 @@
+// tilegather.h -- image-tile decomposition of one frame over the GPUs of a node for the headless
+// C++ host (the reference is single-GPU, volumerendercl.cpp:140).  One process, one
+// renderer per GPU (volume replicated), tiles dealt to the ranks in a diagonal interleave; every rank
+// renders its tiles into a compact device buffer and rank 0 receives them over RCCL point to point
+// (ncclGroupStart; ncclRecv from every peer on the root | ncclSend on the peers; ncclGroupEnd -- xGMI
+// is point to point, so the root's links carry one peer each) and assembles the frame with one kernel.
+#pragma once
+#include <cstddef>
+#include <string>
+#include <vector>
+
+class VolumeRenderCL;
+
+class TileGather
+{
+public:
+    // ranks[r] renders on HIP device devices[r].  loopback: no RCCL -- the peers' tiles reach the root
+    // by device-to-device copies (every rank on ONE device: rehearsal of everything but the transport).
+    TileGather(const std::vector<VolumeRenderCL *> &ranks, const std::vector<int> &devices, size_t width,
+               size_t height, size_t tile, bool loopback);
+    ~TileGather();
+    TileGather(const TileGather &) = delete;
+    TileGather &operator=(const TileGather &) = delete;
+
+    // One frame: every rank renders its tiles (advancing its running mean), gather, assembly, copy
+    // to `out` (width * height * 4 floats, row 0 = top).  Returns the seconds from the first launch to
+    // the assembled frame on the root (host clock, streams synchronised).
+    double renderFrame(std::vector<float> &out);
+
+    size_t tilesOf(size_t rank) const { return _tiles[rank].size(); }
+    std::string transport() const { return _loopback ? "loopback (device copies)" : "RCCL send/recv"; }
+
+private:
+    std::vector<VolumeRenderCL *> _ranks;
+    std::vector<int> _devices;
+    size_t _W, _H, _tile, _tiles_x, _tiles_y, _cap;
+    bool _loopback;
+    std::vector<std::vector<unsigned int>> _tiles;   // tile ids per rank
+    std::vector<float *> _local;                     // per rank: its tiles (rank 0: block 0 of the staging)
+    float *_staging = nullptr;                       // root: ranks x cap tile slots
+    unsigned int *_slot_of_tile = nullptr;           // root: tile id -> slot
+    float *_frame = nullptr;                         // root: assembled frame
+    std::vector<void *> _streams;
+    std::vector<void *> _comms;                      // ncclComm_t per rank
+};

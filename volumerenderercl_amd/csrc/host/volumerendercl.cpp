@@ -136,13 +136,15 @@ void VolumeRenderCL::runRaycastNoGL(const size_t width, const size_t height,
 }
 
 void VolumeRenderCL::renderTiles(size_t width, size_t height, size_t tile_w, size_t tile_h,
-                                 const std::vector<unsigned int> &tile_ids, float *out_tiles_dev)
+                                 const std::vector<unsigned int> &tile_ids, float *out_tiles_dev,
+                                 bool advanceIteration)
 {
     if (!_volLoaded) return;
     beginFrame();
     check("renderTiles", vrhip_render_tiles(_r, uint32_t(width), uint32_t(height), uint32_t(tile_w),
                                             uint32_t(tile_h), tile_ids.data(),
                                             uint32_t(tile_ids.size()), out_tiles_dev));
+    if (advanceIteration) _rendering_params.iteration++;
 }
 
 size_t VolumeRenderCL::loadVolumeData(const DatRawReader::Properties volumeFileProps)   // :765-805

@@ -18,6 +18,9 @@
 #include <string>
 #include <vector>
 
+#include <memory>
+
+#include "tilegather.h"
 #include "volumerendercl.h"
 
 namespace {
@@ -180,6 +183,9 @@ void write_ppm(const std::string &path, const std::vector<float> &rgba, size_t w
         "         [--state FILE.json] [--tf-stops FILE.tff]   (files saved by the reference GUI)\n"
         "         [--contours] [--aerial] [--ao] [--show-ess] [--img-ess]   (--img-ess: state carried over --frames)\n"
         "         [--env FILE.hdr]                 (createEnvironmentMap: Radiance RGBE environment map)\n"
+        "         [--ranks N [--tile T] [--loopback]]   (image tiles over N GPUs, devices D .. D+N-1, volume\n"
+        "                                           replicated, RCCL gather to the first; --loopback: N\n"
+        "                                           renderers on device D, device copies instead of RCCL)\n"
         "writes PREFIX.rgba.f32 (W*H*4 float32, row 0 = top), PREFIX.ppm and prints one JSON line\n";
     std::exit(2);
 }
@@ -200,7 +206,9 @@ int main(int argc, char **argv)
     bool contours = false, aerial = false, use_ao_flag = false, show_ess_flag = false, img_ess = false;
     std::array<float, 16> view{};
     unsigned illum = 1, seed = 0;
-    int frames = 1, device = 0;
+    int frames = 1, device = 0, ranks = 0;
+    size_t tile = 64;
+    bool loopback = false;
     double rate = 1.5;
     std::array<float, 4> bg = {{1, 1, 1, 1}};
 
@@ -240,14 +248,18 @@ int main(int argc, char **argv)
         else if (a == "--env") { need(i, 1); env_file = argv[++i]; }
         else if (a == "--extinction") { need(i, 1); extinction = std::atof(argv[++i]); }
         else if (a == "--device") { need(i, 1); device = std::atoi(argv[++i]); }
+        else if (a == "--ranks") { need(i, 1); ranks = std::atoi(argv[++i]); }
+        else if (a == "--tile") { need(i, 1); tile = size_t(std::atol(argv[++i])); }
+        else if (a == "--loopback") loopback = true;
         else if (a == "--out") { need(i, 1); out = argv[++i]; }
         else usage();
     }
     if ((dat.empty() && synth_kind.empty()) || (out.empty() && !downsample)) usage();
 
     try {
-        VolumeRenderCL vr;
-        vr.initialize(false, false, VENDOR_ANY, std::to_string(device));
+        // everything the front end sets on a renderer; returns false when there is no frame to render
+        auto setup = [&](VolumeRenderCL &vr, int dev) -> bool {
+        vr.initialize(false, false, VENDOR_ANY, std::to_string(dev));
         if (!dat.empty()) {
             DatRawReader::Properties p;
             p.dat_file_name = dat;
@@ -260,7 +272,7 @@ int main(int argc, char **argv)
         if (downsample) {   // volumeDownsampling (volumerendercl.cpp:238-341) and nothing else
             const std::string base = vr.volumeDownsampling(0, downsample);
             std::printf("{\"downsampled\": \"%s\"}\n", base.c_str());
-            return 0;
+            return false;
         }
         bool use_ao = use_ao_flag, show_box = show_ess_flag;
         if (!state_file.empty()) {   // what the GUI's widgets would forward after loadCamState
@@ -304,7 +316,41 @@ int main(int argc, char **argv)
         if (pin) vr.setSeed(seed);
         vr.updateOutputImg(W, H, 0);
         vr.updateView(have_view ? view : view_matrix(q, tr));
+        return true;
+        };
 
+        if (ranks > 0) {
+            // image-tile decomposition over `ranks` GPUs: one renderer per rank, every
+            // one with the whole volume and the same settings; jitter seeds follow the same
+            // default-seeded mt19937 sequence in every renderer, frame by frame
+            if (img_ess) throw std::runtime_error("image-order ESS state crosses tile borders: not with --ranks");
+            std::vector<std::unique_ptr<VolumeRenderCL>> vrs;
+            std::vector<VolumeRenderCL *> ptrs;
+            std::vector<int> devs;
+            for (int r = 0; r < ranks; ++r) {
+                vrs.emplace_back(new VolumeRenderCL());
+                devs.push_back(loopback ? device : device + r);
+                if (!setup(*vrs.back(), devs.back())) return 0;
+                ptrs.push_back(vrs.back().get());
+            }
+            TileGather tg(ptrs, devs, W, H, tile, loopback);
+            std::vector<float> frame;
+            double secs = 0.0;
+            for (int f = 0; f < frames; ++f) secs += tg.renderFrame(frame);
+            std::ofstream raw(out + ".rgba.f32", std::ios::binary);
+            raw.write(reinterpret_cast<const char *>(frame.data()), std::streamsize(frame.size() * sizeof(float)));
+            write_ppm(out + ".ppm", frame, W, H);
+            auto res = vrs[0]->getResolution();
+            std::printf("{\"device\": \"%s\", \"volume\": [%u, %u, %u], \"width\": %zu, \"height\": %zu, "
+                        "\"frames\": %d, \"ranks\": %d, \"tile\": %zu, \"transport\": \"%s\", "
+                        "\"frame_ms\": %.4f, \"out\": \"%s.rgba.f32\"}\n",
+                        vrs[0]->getCurrentDeviceName().c_str(), res[0], res[1], res[2], W, H, frames, ranks, tile,
+                        tg.transport().c_str(), secs / frames * 1e3, out.c_str());
+            return 0;
+        }
+
+        VolumeRenderCL vr;
+        if (!setup(vr, device)) return 0;
         std::vector<float> frame;
         double kernel_s = 0.0;
         for (int f = 0; f < frames; ++f) {

@@ -514,6 +514,104 @@ VR_DEV bool lookahead_pays(bool sampling, bool guess_empty)
     return n_g > 0 && 2 * n_g >= n_s;
 }
 
+// ---- stepping over empty space in O(1) per run (CellView::bmask + vr_leap)
+//
+// A ray in a segment looks at its next sample: the sub-block of the ESS brick it falls into is looked
+// up in the per-brick empty words (the words of the last two bricks the ray has touched stay in
+// registers; a miss costs one load that is used by the lane's next step).  In an EMPTY sub-block every
+// sample composites to exactly nothing (:864-879 with opacity 0), so the whole run of samples up to
+// the sub-block's far side is stepped over at once: its length comes from the ray's texel increments
+// (good to a texel: the cells carry a one-texel halo for exactly this), and the ray parameter after
+// that many `t += stepSize` (:879) from vr_leap -- the exact bits of the chain of additions, without
+// the chain.  Only samples that are certainly neither the last of their segment (:790) nor of the
+// ray (:868) are handled in runs (a margin of two steps); the others take the reference's loop one
+// sample at a time.
+constexpr int kRunCap = 4096;              // samples stepped over at once, at most
+#ifndef VR_LEAP_ITERS
+#define VR_LEAP_ITERS 6
+#endif
+constexpr int kLeapIters = VR_LEAP_ITERS;  // leap steps (+ DDA steps) per round before the evaluation batch
+
+struct LeapCache {
+    uint32_t key0, key1;            // packed brick coordinates of the cached words (0xffffffff: none)
+    unsigned long long m0, m1;
+    float du, dv, ds, inv_step;     // texel increments per sample, 1 / stepSize
+};
+
+VR_DEV void leap_reset(LeapCache &lc, const RayCtx &c, float fw, float fh, float fd)
+{
+    lc.key0 = lc.key1 = 0xffffffffu;
+    lc.m0 = lc.m1 = 0ull;
+    lc.du = (c.dir.x * c.stepSize) * (0.5f * fw);
+    lc.dv = (c.dir.y * c.stepSize) * (0.5f * fh);
+    lc.ds = (c.dir.z * c.stepSize) * (0.5f * fd);
+    lc.inv_step = 1.0f / c.stepSize;
+}
+
+// samples (this one included) whose low-corner texel stays on this side of the sub-block boundary
+// along one axis: ub = texel coordinate of this sample, du = its increment per sample, the
+// sub-block spans [lo, hi)
+VR_DEV int run_axis(float ub, float du, float lo, float hi)
+{
+    const float dist = du > 0.f ? hi - ub : ub - lo;
+    const float q = vmax(dist, 0.f) * __builtin_amdgcn_rcpf(fabsf(du));
+    return du == 0.f ? kRunCap : (int)vmin(q, (float)kRunCap) + 1;
+}
+
+// One step of a lane that is in a segment (S_SAMPLE).  Returns true when the ray now stands at a
+// sample that has to be evaluated (t < t_exit, not known to be empty); otherwise it has moved on:
+// over a run of empty samples, over one sample, out of its segment (after_segment), or it waits for
+// a word it has just asked for.  `taken` counts the samples stepped over (instrumented variants).
+template <bool ESS, typename V>
+VR_DEV bool leap_step(const CellView &cells, const V &vol, const Grid &grid, const RayCtx &c, RayDyn &d,
+                      LeapCache &lc, bool count, unsigned long long &taken)
+{
+    if (!(d.t < d.t_exit)) {
+        after_segment<ESS>(c, d);
+        return false;
+    }
+    const int sx = cells.bex - 2, sy = cells.bey - 2, sz = cells.bez - 2;   // log2 of the sub-block edge
+    // low-corner texel of this sample's fetch (:791-793, Vol::linear), good to a texel
+    const f3 pos = add3(c.cam, scale3(c.dir, d.t - c.offset));
+    const float ub = (pos.x * 0.5f + 0.5f) * vol.fw - 0.5f;
+    const float vb = (pos.y * 0.5f + 0.5f) * vol.fh - 0.5f;
+    const float wb = (pos.z * 0.5f + 0.5f) * vol.fd - 0.5f;
+    const int x0 = iclamp((int)floorf(ub), 0, vol.w1);
+    const int y0 = iclamp((int)floorf(vb), 0, vol.h1);
+    const int z0 = iclamp((int)floorf(wb), 0, vol.d1);
+    const uint32_t bx = (uint32_t)(x0 >> cells.bex), by = (uint32_t)(y0 >> cells.bey), bz = (uint32_t)(z0 >> cells.bez);
+    const uint32_t key = bx | (by << 8) | (bz << 16);
+    if (key != lc.key0 && key != lc.key1) {
+        // the word of a brick this ray has not looked at lately: asked for now, used by the next step
+        lc.key1 = lc.key0; lc.m1 = lc.m0;
+        lc.key0 = key;
+        lc.m0 = cells.bmask[(bz * (uint32_t)grid.bh + by) * (uint32_t)grid.bw + bx];
+        return false;
+    }
+    const unsigned long long m = key == lc.key0 ? lc.m0 : lc.m1;
+    const uint32_t bit = (uint32_t)((x0 >> sx) & 3) | ((uint32_t)((y0 >> sy) & 3) << 2) | ((uint32_t)((z0 >> sz) & 3) << 4);
+    if (!((m >> bit) & 1ull)) return true;
+    // samples 0 .. safe - 1 from here certainly pass :790 and fail :868
+    const int safe = (int)floorf((vmin(d.t_exit, c.tfar) - d.t) * lc.inv_step) - 2;
+    if (safe >= 1) {
+        // all samples whose low-corner texel stays in this sub-block
+        const int run = min(min(run_axis(ub, lc.du, (float)((x0 >> sx) << sx), (float)(((x0 >> sx) + 1) << sx)),
+                                run_axis(vb, lc.dv, (float)((y0 >> sy) << sy), (float)(((y0 >> sy) + 1) << sy))),
+                            min(run_axis(wb, lc.ds, (float)((z0 >> sz) << sz), (float)(((z0 >> sz) + 1) << sz)), safe));
+        d.t = vr_leap(d.t, c.stepSize, (uint32_t)run);
+        if (count) taken += (unsigned long long)run;
+#ifdef VR_RAYLEN
+        d.nsmp += (uint32_t)run;
+#endif
+    } else {
+        if (count) taken++;
+        VR_RAYLEN_INC(d);
+        if (d.t >= c.tfar) d.state = S_DONE;      // :868 after a no-op :865-867
+        else d.t = d.t + c.stepSize;              // :879
+    }
+    return false;
+}
+
 // One front-to-back compositing step (:865-879) with the sample's colour*opacity (q0..q2),
 // opacity qo and ray parameter ti.
 VR_DEV void composite(const RayCtx &c, RayDyn &d, float q0, float q1, float q2, float qo, float ti)
@@ -899,6 +997,9 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
     const Grid grid = make_grid(bricks, rc, skip.n_words, true);
     const uint32_t *sb = SKIP_LDS ? s_skip : skip.bits;
     const bool skip_empty = cells.empty != nullptr && rp.useLinear != 0;
+    // (opt-in, VRHIP_MARCH_MICRO = leap steps per round: measured no faster than the lookahead below)
+    const bool use_mask = skip_empty && cells.bmask != nullptr && fr.march_micro != 0;
+    const uint32_t leap_iters = fr.march_micro;
     const uint32_t budget = fr.round_budget ? fr.round_budget : 0xffffffffu;
     const uint32_t kRefillLanes = (fr.refill_min ? fr.refill_min : 16u) * 4u;   // idle lanes before a refill
 
@@ -906,6 +1007,8 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
     bool have = false, drained = false;
     uint32_t gx = 0, gy = 0, out_index = 0, my_rounds = 0, frame_idx = 0;
     bool guess_empty = true;
+    LeapCache lc;
+    lc.key0 = lc.key1 = 0xffffffffu; lc.m0 = lc.m1 = 0ull; lc.du = lc.dv = lc.ds = lc.inv_step = 0.f;
     RayCtx c;
     RayDyn d;
     setup_ray<true>(0u, 0u, false, fr, cam, rp, rc, resf, voxLen, grid, c, d, rp.seed);   // S_DONE
@@ -945,6 +1048,7 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
                             fetch_skip_word(sb, grid, d);
                             my_rounds = 0;
                             guess_empty = true;
+                            leap_reset(lc, c, vol.fw, vol.fh, vol.fd);
                         }
                     }
                 }
@@ -989,7 +1093,18 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
         }
         if (__ballot(d.state == S_SAMPLE)) my_rounds += d.state == S_SAMPLE ? 1u : 0u;
         bool more_empty = false;
-        if (skip_empty && lookahead_pays(d.state == S_SAMPLE, guess_empty)) {
+        if (use_mask) {
+            // steps over runs of empty samples (leap_step) until the ray stands at a sample to evaluate;
+            // rays that leave their segment go on with the DDA in the same pass
+            bool ready = false;
+            for (uint32_t it = 0; it < leap_iters; ++it) {
+                const bool act = d.state == S_SAMPLE && !ready;
+                if (!__ballot(act)) break;
+                if (act) ready = leap_step<true>(cells, vol, grid, c, d, lc, false, n0);
+                if (__ballot(d.state == S_BRICK)) dda_step<0>(sb, grid, c, d, n0, n1);
+            }
+            more_empty = !ready;
+        } else if (skip_empty && lookahead_pays(d.state == S_SAMPLE, guess_empty)) {
             if (d.state == S_SAMPLE) {
                 const uint32_t em = empty_mask<VT, 0, kLook1>(cells, vol, c, d.t);
                 more_empty = skip_empty_run(em, c, d, false, n0);
@@ -1072,20 +1187,9 @@ __device__ unsigned long long g_march_stats[16];
 constexpr int kQ = VR_MARCH_Q;             // samples of a ray in flight per round (queue slots lane * kQ + j)
 constexpr int kMicro = VR_MARCH_MICRO;     // micro-steps of stage A per round, at most
 constexpr int kFill = VR_MARCH_FILL;       // stage A ends early once about this many samples are queued
-constexpr int kRunCap = 4096;              // samples stepped over at once, at most
 static_assert(64 * kQ <= 256, "slot ids travel as bytes");
 constexpr int kMarchWaveBytes = 64 * kQ * 4 + 64 * kQ * 16 + 64 * kQ + 64 * kQ * 2;   // t queue, results, slot map, list of opaque samples
 static_assert(kMarchWaveBytes % 16 == 0, "float4 units");
-
-// samples (this one included) whose low-corner texel stays on this side of the sub-block boundary
-// along one axis: ub = texel coordinate of this sample, du = its increment per sample, the
-// sub-block spans [lo, hi).  Good to a texel (the cells carry a one-texel halo for exactly this).
-VR_DEV int run_axis(float ub, float du, float lo, float hi)
-{
-    const float dist = du > 0.f ? hi - ub : ub - lo;
-    const float q = vmax(dist, 0.f) * __builtin_amdgcn_rcpf(fabsf(du));
-    return du == 0.f ? kRunCap : (int)vmin(q, (float)kRunCap) + 1;
-}
 
 template <typename VT, bool SKIP_LDS, bool FP>
 __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_march_kernel(
@@ -1648,6 +1752,11 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
     const uint32_t *sb = SKIP_LDS ? s_skip : skip.bits;
     const bool skip_empty = INSTR != 2 && cells.empty != nullptr && rp.useLinear != 0 &&
                             !(XS && rp.illumType == 4);
+    // (opt-in, VRHIP_MARCH_MICRO = leap steps per round: measured no faster than the lookahead below)
+    const bool use_mask = skip_empty && cells.bmask != nullptr && fr.march_micro != 0;
+    const uint32_t leap_iters = fr.march_micro;
+    LeapCache lc;
+    lc.key0 = lc.key1 = 0xffffffffu; lc.m0 = lc.m1 = 0ull; lc.du = lc.dv = lc.ds = lc.inv_step = 0.f;
     // Rays are handed out one by one from the sorted list: when `refill_min` ray slots (quads) of
     // the wave are idle they retire their rays and take the next ones (their set-up runs
     // together).  With the default, 16, a wave refills when all its rays are done, but draws as
@@ -1716,6 +1825,7 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
                             if (ESS) fetch_skip_word(sb, grid, d);
                             my_rounds = 0;
                             guess_empty = true;
+                            leap_reset(lc, c, vol.fw, vol.fh, vol.fd);
                         }
                     }
                 }
@@ -1752,7 +1862,20 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
             if (my_rounds >= VR_CAP_ROUNDS) d.state = S_DONE;
 #endif
             bool more_empty = false;
-            if (skip_empty && lookahead_pays(d.state == S_SAMPLE, guess_empty)) {
+            if (use_mask) {
+                // (the four lanes of a ray hold the same state and cache and take the same steps)
+                bool ready = false;
+                for (uint32_t it = 0; it < leap_iters; ++it) {
+                    const bool act = d.state == S_SAMPLE && !ready;
+                    if (!__ballot(act)) break;
+                    if (act) ready = leap_step<ESS>(cells, vol, grid, c, d, lc, count, c_taken);
+                    if (ESS && __ballot(d.state == S_BRICK)) {
+                        if (count) dda_step<INSTR>(sb, grid, c, d, c_bricks, c_skipped);
+                        else dda_step<0>(sb, grid, c, d, dummy0, dummy1);
+                    }
+                }
+                more_empty = !ready;
+            } else if (skip_empty && lookahead_pays(d.state == S_SAMPLE, guess_empty)) {
                 if (d.state == S_SAMPLE) {
                     // the four lanes of a ray hold the same state and take the same decisions;
                     // lane `slot` looks at samples [kLook2 * slot, kLook2 * (slot + 1)) of the run

@@ -78,6 +78,7 @@ struct vrhip_renderer {
     bool pt_dirty = true;          // cells out of date (volume, timestep or TF changed)
     bool pt_cull = true;           // VRHIP_PT_NO_CULL=1 disables the path tracer's culling
     bool skip_empty = true;        // VRHIP_NO_EMPTY_SKIP=1 disables the ray caster's empty runs
+    bool skip_empty_force = false; // VRHIP_EMPTY_SKIP=1: also where it is not expected to pay (see ray_skip_empty)
 
     vrhip_camera_params cam;
     vrhip_rendering_params render;
@@ -292,6 +293,17 @@ TfView make_tf_view(const vrhip_renderer *r)
     t.prefix = r->prefix;
     t.prefix_n = r->prefix_n;
     return t;
+}
+
+// Does the ray caster step over empty cells (CellView::empty)?  The cells are 8 voxels wide; where the
+// ESS bricks are not much larger the brick skipping has done the work already and the lookahead only
+// costs: measured on MI355X +6 % frame time at 1024^3 (bricks of 16) and 256^3 (bricks of 4), -25 % at
+// 2048^3 (bricks of 32).  Without ESS bricks the cells are all there is.
+bool ray_skip_empty(const vrhip_renderer *r)
+{
+    if (!r->skip_empty || r->channels > 1) return false;
+    if (r->skip_empty_force || !r->use_ess || !r->bricks_valid) return true;
+    return std::max(r->brick_edge[0], std::max(r->brick_edge[1], r->brick_edge[2])) >= 32u;
 }
 
 int set_device(const vrhip_renderer *r)
@@ -686,7 +698,7 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
     a->cells = r->cells;
     if (!r->pt_cull) a->cells.bound = nullptr;
     // the empty bits are those of TF(channel 0): not what a CL_RG / CL_RGBA sample's opacity is
-    if (!r->skip_empty || r->channels > 1) { a->cells.empty = nullptr; a->cells.bmask = nullptr; }
+    if (!ray_skip_empty(r)) { a->cells.empty = nullptr; a->cells.bmask = nullptr; }
     a->format = r->format;
     a->use_ess = r->use_ess ? 1 : 0;
     a->instr = r->stats_enabled ? 1 : 0;
@@ -738,7 +750,7 @@ int prepare_render(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t 
         rc = ensure_footprint(r);
         if (rc) return rc;
     }
-    if (r->render.technique == 1 ? r->pt_cull : r->skip_empty) {
+    if (r->render.technique == 1 ? r->pt_cull : ray_skip_empty(r)) {
         rc = ensure_cells(r);
         if (rc) return rc;
     }
@@ -795,6 +807,16 @@ int count_touched_impl(vrhip_renderer *r, uint32_t width, uint32_t height, uint3
     return VRHIP_OK;
 }
 
+__global__ __launch_bounds__(256) void vr_assemble_kernel(const float4 *staging, const uint32_t *slot_of_tile,
+                                                          uint32_t W, uint32_t H, uint32_t tw, uint32_t th,
+                                                          uint32_t tiles_x, float4 *frame)
+{
+    const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const uint32_t slot = slot_of_tile[(y / th) * tiles_x + x / tw];
+    frame[(size_t)y * W + x] = staging[((size_t)slot * th + (y % th)) * tw + (x % tw)];
+}
+
 } // namespace
 
 extern "C" {
@@ -842,6 +864,7 @@ int vrhip_create(int device_id, vrhip_renderer **out)
     if (getenv("VRHIP_NO_SORT")) r->sort_cont = false;         // experiments: phase 2 in append order
     if (getenv("VRHIP_PT_NO_CULL")) r->pt_cull = false;        // experiments: no opacity-bound culling
     if (getenv("VRHIP_NO_EMPTY_SKIP")) r->skip_empty = false;  // experiments: no empty-run skipping
+    if (getenv("VRHIP_EMPTY_SKIP")) r->skip_empty_force = true;   // ... or everywhere
     if (getenv("VRHIP_NO_FOOTPRINT")) r->use_fp = false;       // plain volume layout only
     if (const char *e = getenv("VRHIP_REFILL_MIN")) {
         const int v = atoi(e);
@@ -913,6 +936,22 @@ int vrhip_set_stream(vrhip_renderer *r, void *hip_stream, int use_own)
     if (set_device(r)) return VRHIP_ERR_HIP;
     VR_HIP(r, hipStreamSynchronize(r->stream));
     r->stream = use_own ? r->own_stream : (hipStream_t)hip_stream;
+    return VRHIP_OK;
+}
+
+int vrhip_assemble_frame(vrhip_renderer *r, const float *staging_dev, const uint32_t *slot_of_tile_dev,
+                         uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h,
+                         float *frame_dev)
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    VR_REQUIRE(r, staging_dev && slot_of_tile_dev && frame_dev && width && height && tile_w && tile_h,
+               VRHIP_ERR_INVALID, "vrhip_assemble_frame: invalid argument");
+    if (set_device(r)) return VRHIP_ERR_HIP;
+    const uint32_t tiles_x = (width + tile_w - 1) / tile_w;
+    hipLaunchKernelGGL(vr_assemble_kernel, dim3((width + 63) / 64, (height + 3) / 4), dim3(256), 0, r->stream,
+                       (const float4 *)staging_dev, slot_of_tile_dev, width, height, tile_w, tile_h, tiles_x,
+                       (float4 *)frame_dev);
+    VR_HIP(r, hipGetLastError());
     return VRHIP_OK;
 }
 
