@@ -138,6 +138,7 @@ struct FrameView {
     // 1: the default modes march the ray list with vr_march_kernel (stepping / dense evaluation /
     // compositing as stages of a round) instead of the two-phase march; a schedule, not a result
     uint32_t march;
+    uint32_t lds_stage;   // experiment (VRHIP_LDS_STAGE): 1 = patch kernel with LDS-staged voxel boxes, 2 = same without
     uint32_t march_micro, march_fill;   // tuning (0 = built-in): micro-steps per round, queue fill that ends stage A
     // Phase-2 scheduling: `cost` keeps, per pixel, the phase-2 rounds the pixel's ray needed in the
     // previous frame.  Suspended rays are sorted by it, longest first (counting sort into

@@ -30,6 +30,8 @@
 //  carry a frame index (vrhip_render_batch).
 //  The per-ray sequence of t values and of fp32 operations is exactly the reference's in every
 //  kernel, so the image is bit-identical whatever the schedule (budget, refill, batch, lists).
+#include <algorithm>
+
 #include "vr_leap.h"
 #include "vr_sampling.h"
 
@@ -234,8 +236,8 @@ constexpr int kStageF4 = (kBlockDim / 64) * kStageFloatsPerWave / 4;   // float4
 // same fp32 operations as before, in another lane.
 // FP: the kernel variant that reads the footprint volume (VolView::fp) instead of the plain
 // layout -- default kernels only (no instrumentation, no XS extras); see launch_typed.
-template <typename VT, int INSTR, bool XS, bool FP>
-VR_DEV void eval_batch(const Vol<VT, INSTR, FP> &vol, const float4 *s_tff, int tffn, float *s_stage,
+template <typename VT, int INSTR, bool XS, bool FP, typename V>
+VR_DEV void eval_batch(const V &vol, const float4 *s_tff, int tffn, float *s_stage,
                        const RayCtx &c, const vrhip_rendering_params &rp,
                        const vrhip_raycast_params &rcp, float refInterval,
                        const float (&tk)[kBatch], const bool (&vk)[kBatch], float (&p0)[kBatch],
@@ -791,10 +793,10 @@ VR_DEV void write_pixel(const FrameView &fr, const vrhip_rendering_params &rp, c
         fr.hit_any[(size_t)(gy >> 3) * fr.hit_w + (gx >> 3)] = 1;
 }
 
-template <typename VT, int INSTR, bool FP>
-VR_DEV Vol<VT, INSTR, FP> make_vol(const VolView &vv, uint32_t *touched)
+template <typename VT, int INSTR, bool FP, bool LS = false>
+VR_DEV Vol<VT, INSTR, FP, LS> make_vol(const VolView &vv, uint32_t *touched)
 {
-    Vol<VT, INSTR, FP> vol;
+    Vol<VT, INSTR, FP, LS> vol;
     vol.p = (const VT *)vv.data;
     vol.w1 = vv.w - 1; vol.h1 = vv.h - 1; vol.d1 = vv.d - 1;
     vol.fw = vv.fw; vol.fh = vv.fh; vol.fd = vv.fd;
@@ -1692,6 +1694,165 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_kernel(
     }
 }
 
+// ------------------------------------------------------------------ LDS brick staging (experiment)
+
+// north_star names "the 3-D scalar field staged as LDS bricks for coalesced HBM reads".  This is
+// that mechanism, built to be measured against the production path ("LDS staging"):
+// the patch kernel (one wave = one 8x8 patch, whose rays stay together), single phase, UCHAR,
+// default modes.  Before every evaluation batch the wave takes the box of voxels the batch's
+// fetches can touch; when it is not inside the staged box any more, the wave re-stages
+// kStageEdge^3 voxels ((kStageEdge / 4)^3 micro-bricks = whole 64-byte lines, loaded with 16-byte
+// accesses) positioned so that the rays have the most room ahead, and the batch reads its voxels
+// from LDS.  LS = false: the same kernel without the staging (the A/B's other arm).
+template <bool LS>
+__global__ __launch_bounds__(kBlockDim) void vr_raycast_staged_kernel(
+    VolView vv, BrickView bricks, TfView tf, SkipView skip, CellView cells, FrameView fr,
+    vrhip_camera_params cam, vrhip_rendering_params rp, vrhip_raycast_params rc)
+{
+    typedef uint8_t VT;
+    extern __shared__ float4 s_mem[];
+    // LDS: [gradient staging, 4 waves][tff_n float4][boxes, 4 waves]
+    float *s_stage = reinterpret_cast<float *>(s_mem) + (threadIdx.x >> 6) * kStageFloatsPerWave;
+    float4 *s_tff = s_mem + kStageF4;
+    constexpr int kBoxBytes = (kStageEdge * kStageEdge * kStageEdge + 15) / 16 * 16;
+    uint8_t *s_box = reinterpret_cast<uint8_t *>(s_tff + tf.tff_n) + (threadIdx.x >> 6) * kBoxBytes;
+    for (uint32_t i = threadIdx.x; i < tf.tff_n; i += kBlockDim) s_tff[i] = tf.tff[i];
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const int tffn = (int)tf.tff_n;
+    Vol<VT, 0, false, LS> vol = make_vol<VT, 0, false, LS>(vv, nullptr);
+    vol.lds = (const __attribute__((address_space(3))) VT *)s_box;
+    const f3 resf = mk3(vol.fw, vol.fh, vol.fd);
+    const f3 voxLen = mk3(1.f / vol.fw, 1.f / vol.fh, 1.f / vol.fd);
+    const float refInterval = 1.f / rc.samplingRate;
+    const Grid grid = make_grid(bricks, rc, skip.n_words, true);
+    const uint32_t *sb = skip.bits;
+    const bool skip_empty = cells.empty != nullptr && rp.useLinear != 0;
+    unsigned long long n0 = 0, n1 = 0;
+
+    uint32_t q_next = 0;
+    if (lane == 0) q_next = atomicAdd(fr.queue_head, 1u);
+    for (;;) {
+        const uint32_t q = __builtin_amdgcn_readfirstlane(q_next);
+        if (q >= fr.n_wave_tiles) break;
+        const WaveTile wt = fr.queue[q];
+        if (lane == 0) q_next = atomicAdd(fr.queue_head, 1u);
+        const uint32_t lx = lane & 7u, ly = lane >> 3;
+        const uint32_t gx = (uint32_t)wt.tx8 * 8u + lx, gy = wt_row(wt) * 8u + ly;
+        const uint32_t seed = fr.seeds ? fr.seeds[wt_frame(wt)] : rp.seed;
+        const bool inside = gx < fr.W && gy < fr.H;
+        RayCtx c;
+        RayDyn d;
+        setup_ray<true>(gx, gy, inside, fr, cam, rp, rc, resf, voxLen, grid, c, d, seed);
+        fetch_skip_word(sb, grid, d);
+        vol.staged = false;
+        bool guess_empty = true;
+        for (;;) {
+            for (int it = 0;; ++it) {
+                if (!__ballot(d.state == S_BRICK)) break;
+                if (it >= kMaxBrickSteps && __ballot(d.state == S_SAMPLE)) break;
+                dda_step<0>(sb, grid, c, d, n0, n1);
+            }
+            if (!__ballot(d.state != S_DONE)) break;
+            bool more_empty = false;
+            if (skip_empty && lookahead_pays(d.state == S_SAMPLE, guess_empty)) {
+                if (d.state == S_SAMPLE) {
+                    const uint32_t em = empty_mask<VT, 0, kLook1>(cells, vol, c, d.t);
+                    more_empty = skip_empty_run(em, c, d, false, n0);
+                    guess_empty = (em & 1u) != 0u;
+                    after_segment<true>(c, d);
+                }
+            }
+            const bool evalr = d.state == S_SAMPLE && !more_empty;
+            if (LS && __ballot(evalr)) {
+                // box of the low-corner texels of the batch's fetches (the ray is straight: its two end
+                // samples bound the others), widened by the gradient's taps (-1 .. +2)
+                int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-(1 << 30), -(1 << 30), -(1 << 30)};
+                if (evalr) {
+                    for (int e = 0; e < 2; ++e) {
+                        const float te = e ? d.t + (float)(kBatch - 1) * c.stepSize : d.t;
+                        const f3 pos = add3(c.cam, scale3(c.dir, te - c.offset));
+                        const int t3[3] = {iclamp((int)floorf((pos.x * 0.5f + 0.5f) * vol.fw - 0.5f), 0, vol.w1),
+                                           iclamp((int)floorf((pos.y * 0.5f + 0.5f) * vol.fh - 0.5f), 0, vol.h1),
+                                           iclamp((int)floorf((pos.z * 0.5f + 0.5f) * vol.fd - 0.5f), 0, vol.d1)};
+                        for (int i = 0; i < 3; ++i) { lo[i] = min(lo[i], t3[i] - 2); hi[i] = max(hi[i], t3[i] + 3); }
+                    }
+                }
+                for (int i = 0; i < 3; ++i)
+                    for (int off = 32; off > 0; off >>= 1) {
+                        lo[i] = min(lo[i], __shfl_xor(lo[i], off, 64));
+                        hi[i] = max(hi[i], __shfl_xor(hi[i], off, 64));
+                    }
+                const int o3[3] = {vol.ox, vol.oy, vol.oz};
+                bool covered = vol.staged, fits = true;
+                for (int i = 0; i < 3; ++i) {
+                    covered = covered && lo[i] >= o3[i] && hi[i] < o3[i] + kStageEdge;
+                    fits = fits && hi[i] - lo[i] < kStageEdge - 3;
+                }
+                if (!covered) {
+                    vol.staged = false;
+                    if (fits) {
+                        // room ahead: the box starts at the batch's near side along the way the rays go
+                        const int m = (int)__builtin_ctzll(__ballot(evalr));
+                        const float dm[3] = {__shfl(c.dir.x, m, 64), __shfl(c.dir.y, m, 64), __shfl(c.dir.z, m, 64)};
+                        int o[3];
+                        for (int i = 0; i < 3; ++i) {
+                            o[i] = dm[i] >= 0.f ? (lo[i] & ~3) : ((hi[i] - kStageEdge + 4) & ~3);
+                            o[i] = max(o[i], -4);
+                        }
+                        constexpr int nb = kStageEdge / 4;
+                        const VT *gp = (const VT *)vv.data;
+                        __builtin_amdgcn_wave_barrier();
+                        for (int b = (int)lane; b < nb * nb * nb; b += 64) {
+                            const int bxi = b % nb, byi = (b / nb) % nb, bzi = b / (nb * nb);
+                            const int mx = (o[0] >> 2) + bxi, my = (o[1] >> 2) + byi, mz = (o[2] >> 2) + bzi;
+                            if (mx < 0 || my < 0 || mz < 0 || mx >= (int)vv.nbx || my >= (int)vv.nby || mz >= (int)vv.nbz)
+                                continue;   // outside the volume: never read (fetch indices are clamped into it)
+                            const uint4 *line = reinterpret_cast<const uint4 *>(
+                                gp + ((unsigned long long)mz * vv.zstride + (unsigned long long)my * vv.ystride +
+                                      (unsigned long long)mx * 64ull));
+#pragma unroll
+                            for (int zz = 0; zz < 4; ++zz) {
+                                const uint4 v = line[zz];   // one z slice of the micro-brick: 4 rows of 4 voxels
+                                uint8_t *row = s_box + ((bzi * 4 + zz) * kStageEdge + byi * 4) * kStageEdge + bxi * 4;
+                                *reinterpret_cast<uint32_t *>(row) = v.x;
+                                *reinterpret_cast<uint32_t *>(row + kStageEdge) = v.y;
+                                *reinterpret_cast<uint32_t *>(row + 2 * kStageEdge) = v.z;
+                                *reinterpret_cast<uint32_t *>(row + 3 * kStageEdge) = v.w;
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        vol.ox = o[0]; vol.oy = o[1]; vol.oz = o[2];
+                        vol.staged = true;
+                    }
+                }
+            }
+            if (evalr) {
+                float tk[kBatch];
+                bool vk[kBatch], litk[kBatch];
+                tk[0] = d.t;
+                vk[0] = d.t < d.t_exit;
+#pragma unroll
+                for (int k = 1; k < kBatch; ++k) {
+                    tk[k] = tk[k - 1] + c.stepSize;
+                    vk[k] = vk[k - 1] && !(tk[k - 1] >= c.tfar) && (tk[k] < d.t_exit);
+                }
+                float p0[kBatch], p1[kBatch], p2[kBatch], opk[kBatch];
+                eval_batch<VT, 0, false, false>(vol, s_tff, tffn, s_stage, c, rp, rc, refInterval, tk, vk, p0, p1, p2,
+                                                opk, litk);
+#pragma unroll
+                for (int k = 0; k < kBatch; ++k)
+                    if (vk[k] && d.state == S_SAMPLE) composite(c, d, p0[k], p1[k], p2[k], opk[k], tk[k]);
+                if (vk[kBatch - 1]) guess_empty = opk[kBatch - 1] == 0.f;
+                after_segment<true>(c, d);
+            }
+        }
+        if (inside) write_pixel<false>(fr, rp, c, d, voxLen, gx, gy, (size_t)wt.out_base + (size_t)ly * fr.out_stride + lx);
+    }
+}
+
 // ------------------------------------------------------------------ phase 2
 
 // composite the kBatch samples evaluated by lane O of every quad, in order
@@ -2124,6 +2285,31 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
     return hipGetLastError();
 }
 
+// LDS brick staging experiment (FrameView::lds_stage: 1 = staged, 2 = the same kernel without staging)
+hipError_t launch_staged(const RaycastLaunch &a, hipStream_t stream)
+{
+    constexpr size_t box = (size_t)(kStageEdge * kStageEdge * kStageEdge + 15) / 16 * 16;
+    const size_t lds = (size_t)kStageF4 * sizeof(float4) + (size_t)a.tf.tff_n * sizeof(float4) + (kBlockDim / 64) * box;
+    const uint32_t cus = (uint32_t)(a.num_cus > 0 ? a.num_cus : 256);
+    const uint32_t want = (a.frame.n_wave_tiles + 3u) / 4u;
+    int nb = 0;
+    hipError_t e;
+    if (a.frame.lds_stage == 1) {
+        e = prepare_variant(vr_raycast_staged_kernel<true>, lds, &nb, "raycast staged (LDS boxes)", a.num_cus);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(vr_raycast_staged_kernel<true>, dim3(std::min(want, cus * (uint32_t)nb)), dim3(kBlockDim), lds,
+                           stream, a.vol, a.bricks, a.tf, a.skip, a.cells, a.frame, a.cam, a.render, a.raycast);
+    } else {
+        e = prepare_variant(vr_raycast_staged_kernel<false>, lds, &nb, "raycast staged (off)", a.num_cus);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(vr_raycast_staged_kernel<false>, dim3(std::min(want, cus * (uint32_t)nb)), dim3(kBlockDim), lds,
+                           stream, a.vol, a.bricks, a.tf, a.skip, a.cells, a.frame, a.cam, a.render, a.raycast);
+    }
+    e = hipGetLastError();
+    if (e == hipSuccess && a.mid_event) e = hipEventRecord(a.mid_event, stream);
+    return e;
+}
+
 template <typename VT>
 hipError_t launch_typed(const RaycastLaunch &a, hipStream_t stream)
 {
@@ -2132,6 +2318,9 @@ hipError_t launch_typed(const RaycastLaunch &a, hipStream_t stream)
     // code and registers do not tax the default ones
     const bool xs = a.render.illumType >= 2 || a.raycast.useAO != 0 || a.render.showEss != 0 ||
                     a.render.imgEss != 0 || a.vol.channels > 1;
+    if (a.frame.lds_stage && !xs && a.instr == 0 && a.use_ess && sizeof(VT) == 1 && !a.raycast.contours &&
+        !a.raycast.aerial && a.frame.n_wave_tiles)
+        return launch_staged(a, stream);
     // the default kernels read the footprint volume when the host has provided one for this frame
     if (!xs && a.instr == 0 && a.vol.fp) {
         if (!a.use_ess) return launch_variant<VT, false, 0, false, false, true>(a, stream);

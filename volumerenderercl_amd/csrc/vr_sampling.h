@@ -72,9 +72,17 @@ template <> struct FpEntry<float> {
     }
 };
 
-template <typename VT, int INSTR, bool FP = false>
+// LS (experiment, vr_raycast_staged_kernel): a box of kStageEdge^3 voxels around the wave's rays is
+// staged in LDS (x fastest, origin (ox, oy, oz), a multiple of 4) and fetches whose voxels all lie
+// inside it are served from there; the others go to HBM / L2 as usual.  Same voxels, same blend.
+constexpr int kStageEdge = 20;
+
+template <typename VT, int INSTR, bool FP = false, bool LS = false>
 struct Vol {
     const VT *p;
+    const __attribute__((address_space(3))) VT *lds = nullptr;   // LS: this wave's box in LDS
+    bool staged = false;            // LS: the box holds the voxels [o, o + kStageEdge)^3
+    int ox = 0, oy = 0, oz = 0;
     int w1, h1, d1;   // res - 1
     float fw, fh, fd;
     float inv_max;
@@ -156,6 +164,17 @@ struct Vol {
         int x0 = iclamp(ix, 0, w1), x1 = iclamp(ix + 1, 0, w1);
         int y0 = iclamp(iy, 0, h1), y1 = iclamp(iy + 1, 0, h1);
         int z0 = iclamp(iz, 0, d1), z1 = iclamp(iz + 1, 0, d1);
+        if (LS && staged && (uint32_t)(x0 - ox) < (uint32_t)kStageEdge && (uint32_t)(x1 - ox) < (uint32_t)kStageEdge &&
+            (uint32_t)(y0 - oy) < (uint32_t)kStageEdge && (uint32_t)(y1 - oy) < (uint32_t)kStageEdge &&
+            (uint32_t)(z0 - oz) < (uint32_t)kStageEdge && (uint32_t)(z1 - oz) < (uint32_t)kStageEdge) {
+            const int bx0 = x0 - ox, bx1 = x1 - ox, by0 = (y0 - oy) * kStageEdge, by1 = (y1 - oy) * kStageEdge;
+            const int bz0 = (z0 - oz) * (kStageEdge * kStageEdge), bz1 = (z1 - oz) * (kStageEdge * kStageEdge);
+            float c00 = lerpf((float)lds[bz0 + by0 + bx0], (float)lds[bz0 + by0 + bx1], a);
+            float c10 = lerpf((float)lds[bz0 + by1 + bx0], (float)lds[bz0 + by1 + bx1], a);
+            float c01 = lerpf((float)lds[bz1 + by0 + bx0], (float)lds[bz1 + by0 + bx1], a);
+            float c11 = lerpf((float)lds[bz1 + by1 + bx0], (float)lds[bz1 + by1 + bx1], a);
+            return lerpf(lerpf(c00, c10, b), lerpf(c01, c11, b), c) * inv_max;
+        }
         const uint32_t xo0 = xoff(x0), xo1 = xoff(x1), yo0 = yoff(y0), yo1 = yoff(y1);
         const unsigned long long zo0 = zoff(z0), zo1 = zoff(z1);
         float v000 = raw(xo0, yo0, zo0, x0, y0, z0), v100 = raw(xo1, yo0, zo0, x1, y0, z0);
@@ -207,16 +226,24 @@ struct Vol {
         int X[4], Y[4], Z[4];
         uint32_t xo[4], yo[4];
         unsigned long long zo[4];
+        bool in_box = LS && staged;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             X[k] = iclamp(ix - 1 + k, 0, w1);
             Y[k] = iclamp(iy - 1 + k, 0, h1);
             Z[k] = iclamp(iz - 1 + k, 0, d1);
-            xo[k] = xoff(X[k]);
-            yo[k] = yoff(Y[k]);
-            zo[k] = zoff(Z[k]);
+            if (LS)
+                in_box = in_box && (uint32_t)(X[k] - ox) < (uint32_t)kStageEdge && (uint32_t)(Y[k] - oy) < (uint32_t)kStageEdge &&
+                         (uint32_t)(Z[k] - oz) < (uint32_t)kStageEdge;
         }
-#define VR_L(xi, yi, zi) raw(xo[xi], yo[yi], zo[zi], X[xi], Y[yi], Z[zi])
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // (staged box: plain offsets into the wave's LDS copy; else the micro-brick layout)
+            xo[k] = in_box ? (uint32_t)(X[k] - ox) : xoff(X[k]);
+            yo[k] = in_box ? (uint32_t)((Y[k] - oy) * kStageEdge) : yoff(Y[k]);
+            zo[k] = in_box ? (unsigned long long)((Z[k] - oz) * (kStageEdge * kStageEdge)) : zoff(Z[k]);
+        }
+#define VR_L(xi, yi, zi) (in_box ? (float)lds[(uint32_t)zo[zi] + yo[yi] + xo[xi]] : raw(xo[xi], yo[yi], zo[zi], X[xi], Y[yi], Z[zi]))
 #define VR_R(yi, zi) lerpf(VR_L(1, yi, zi), VR_L(2, yi, zi), a)   /* texels (x0, x1)   */
 #define VR_M(yi, zi) lerpf(VR_L(0, yi, zi), VR_L(1, yi, zi), a)   /* texels (x0-1, x0) */
 #define VR_P(yi, zi) lerpf(VR_L(2, yi, zi), VR_L(3, yi, zi), a)   /* texels (x1, x1+1) */

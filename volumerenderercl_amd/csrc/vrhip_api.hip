@@ -101,6 +101,7 @@ struct vrhip_renderer {
     ContRec *live_rays = nullptr;     // pre-pass output: live rays with their DDA state (phase 1's list)
     bool ray_list = true;             // VRHIP_NO_RAYLIST=1: phase 1 walks the live patches instead
     bool march = false;               // VRHIP_MARCH=1: vr_march_kernel instead of the two-phase march (measured, not faster)
+    uint32_t lds_stage = 0;           // VRHIP_LDS_STAGE=1|2: the LDS brick staging experiment (vr_raycast_staged_kernel)
     uint32_t march_micro = 0, march_fill = 0;   // VRHIP_MARCH_MICRO / VRHIP_MARCH_FILL (0 = built-in)
     uint32_t *seeds_dev = nullptr;    // kMaxBatchFrames jitter seeds of a batch of frames
     bool sort_cont = true;            // VRHIP_NO_SORT=1 disables
@@ -430,7 +431,7 @@ int ensure_footprint(vrhip_renderer *r)
 {
     r->fp_active = false;
     const vrhip_rendering_params &rp = r->render;
-    if (!r->use_fp || r->channels > 1 || r->stats_enabled || rp.technique != 0 || rp.illumType >= 2 ||
+    if (!r->use_fp || r->lds_stage || r->channels > 1 || r->stats_enabled || rp.technique != 0 || rp.illumType >= 2 ||
         r->raycast.useAO || rp.showEss || rp.imgEss)
         return VRHIP_OK;   // (the launcher uses it in the default kernels only)
     const VolView v = make_vol_view(r, r->vols[r->timestep].dev);
@@ -671,6 +672,7 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
     a->frame.live = r->prepass ? r->live : nullptr;
     a->frame.live_rays = (r->prepass && r->ray_list) ? r->live_rays : nullptr;
     a->frame.march = r->march ? 1u : 0u;
+    a->frame.lds_stage = r->lds_stage;
     a->frame.march_micro = r->march_micro;
     a->frame.march_fill = r->march_fill;
     a->frame.live_count = r->queue_head + 3;
@@ -855,6 +857,7 @@ int vrhip_create(int device_id, vrhip_renderer **out)
     if (getenv("VRHIP_NO_PREPASS")) r->prepass = false;        // experiments: phase 1 walks every patch
     if (getenv("VRHIP_NO_RAYLIST")) r->ray_list = false;       // experiments: phase 1 on live patches
     if (getenv("VRHIP_MARCH")) r->march = true;                // experiments / A-B: the decoupled march kernel
+    if (const char *e = getenv("VRHIP_LDS_STAGE")) r->lds_stage = (uint32_t)atoi(e);
     if (const char *e = getenv("VRHIP_CULL_RADIUS")) {
         const int v = atoi(e);
         if (v >= 0 && v <= 64) r->cull_radius = (uint32_t)v;
