@@ -208,6 +208,13 @@ int vrhip_get_image_ess(vrhip_renderer *r, uint32_t width, uint32_t height, uint
                         uint8_t *hit_out);
 int vrhip_set_image_ess(vrhip_renderer *r, uint32_t width, uint32_t height, const uint8_t *hit_in,
                         const uint8_t *hit_out);
+/* The cell grid behind empty-run skipping and the path tracer's culling (no reference counterpart;
+ * DESIGN.md "Kernels"): per cell of 2^shift voxels the (min, max) of the raw voxel values a fetch in
+ * or within one texel of the cell can read, as pairs of floats, x fastest.  Builds the grid of the
+ * current time step if need be.  out == NULL: dims / shift only.  For tests. */
+int vrhip_download_cells(vrhip_renderer *r, float *out_minmax, size_t n_floats, uint32_t dims[3],
+                         uint32_t *shift);
+
 /* Image-tile gather, root side: the frame from the gathered tiles.  `staging_dev` holds
  * tile slots of tile_w x tile_h RGBA float pixels (the peers' blocks as received, one after the
  * other); slot_of_tile_dev[t] is the slot of tile t (tiles numbered row-major over the frame).

@@ -246,6 +246,40 @@ def test_schedules_and_culling_do_not_change_pixels(vr, monkeypatch, env):
             np.testing.assert_array_equal(img, frames[("default", view, seed)], err_msg="%s %s" % (view, seed))
 
 
+@pytest.mark.parametrize("fmt,res", [(UCHAR, (96, 80, 72)), (USHORT, (70, 33, 50)), (FLOAT, (64, 64, 40))])
+def test_cell_grid_bounds(fmt, res, monkeypatch):
+    """The cell grid (min, max of the voxels a fetch in or next to a cell of 8^3 voxels can read): the
+    one-wave-per-cell kernel and the separable streaming build (x and y ranges per voxel slice from
+    whole micro-brick lines, then the z range) both give exactly the extrema of the voxels
+    [8c - 1, 8c + 9]^3 clipped to the volume."""
+    vol = common.noise_volume(res, fmt, seed=31, smooth=False)
+    got = {}
+    for name, env in (("wave", "1"), ("stream", None)):
+        if env:
+            monkeypatch.setenv("VRHIP_CELLS_PER_WAVE", env)
+        else:
+            monkeypatch.delenv("VRHIP_CELLS_PER_WAVE", raising=False)
+        r2 = VolumeRenderCL()
+        r2.initialize()
+        try:
+            r2.loadVolumeArrays([vol], fmt)
+            r2.setTransferFunction(common.tffs()["default"])
+            got[name], shift = r2.downloadCells()
+            assert shift == 3
+        finally:
+            r2.close()
+    cz, cy, cx = got["wave"].shape[:3]
+    want = np.empty_like(got["wave"])
+    v = vol.astype(np.float32)
+    for k in range(cz):
+        for j in range(cy):
+            for i in range(cx):
+                box = v[max(8 * k - 1, 0):8 * k + 10, max(8 * j - 1, 0):8 * j + 10, max(8 * i - 1, 0):8 * i + 10]
+                want[k, j, i] = (box.min(), box.max())
+    np.testing.assert_array_equal(got["wave"], want)
+    np.testing.assert_array_equal(got["stream"], want)
+
+
 def test_pathtrace_culling_is_exact(vr, monkeypatch):
     """The majorant grid only skips fetches that cannot change the walk: the image with and
     without it is identical, and it does skip a large share of the fetches."""

@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""tools/cells_time.py -- time the cell-grid build (per-wave kernel vs two-pass streaming build) at 2048^3."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa
+from volumerenderercl_amd import VolumeRenderCL, frontend
+for mode in ("stream", "wave"):
+    if mode == "wave":
+        os.environ["VRHIP_CELLS_PER_WAVE"] = "1"
+    else:
+        os.environ.pop("VRHIP_CELLS_PER_WAVE", None)
+    vr = VolumeRenderCL(); vr.initialize()
+    vr.synthVolume("shells", (2048, 2048, 2048), 0)
+    vr.setTransferFunction(frontend.tff_from_stops())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    vr.lib.vrhip_download_cells(vr.handle, None, 0, None, None)
+    torch.cuda.synchronize()
+    print(mode, "cell grid build incl. bounds + words: %.2f ms (host clock)" % ((time.perf_counter() - t0) * 1e3))
+    vr.close()

@@ -67,6 +67,118 @@ __global__ __launch_bounds__(kThreads) void vr_cell_minmax_kernel(VolView vv, Ce
     if (lane == 0) out[cell] = any_bad ? make_float2(1.f, 0.f) : make_float2(mn, mx);
 }
 
+// ---- the same (min, max) by separable streaming passes (cells of 8 or 16 voxels: volumes up to 4096^3)
+//
+// The extrema over the box [(c << s) - 1, ((c + 1) << s) + 1]^3 separate by axis.  Pass XY reads every
+// voxel as part of whole 64-byte micro-brick lines: a workgroup takes one row of cells (cy) in one
+// slice of micro-bricks (mz) and a thread a micro-brick column.  Over the rows y of the cell's halo'd
+// range it reduces, per z slice of the bricks, three x classes of its four voxel columns -- A: all
+// four, L: the first two (what the cell on the left takes from this brick), H: the last one (what the
+// cell on the right takes) -- into LDS; then a thread per cell combines H of the brick to its left, A
+// of its own bricks and L of the brick to its right: the extrema over the x and y ranges of the cell
+// for that voxel slice z.  Pass Z reduces the 2^s + 3 slices of each cell.  Exactly the kernel
+// above's values (NaN voxels give (-inf, +inf): never culled, never empty).
+template <typename VT> struct CellAcc {   // extrema of raw voxel values; integer voxels stay integers until the end
+    uint32_t mn = 0xffffffffu, mx = 0u;
+    VR_DEV void add(VT v) { mn = min(mn, (uint32_t)v); mx = max(mx, (uint32_t)v); }
+    VR_DEV float2 get() const { return mn > mx ? make_float2(__builtin_inff(), -__builtin_inff()) : make_float2((float)mn, (float)mx); }
+};
+template <> struct CellAcc<float> {
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    VR_DEV void add(float f)
+    {
+        if (!(f == f)) { mn = -__builtin_inff(); mx = __builtin_inff(); }
+        mn = f < mn ? f : mn;
+        mx = f > mx ? f : mx;
+    }
+    VR_DEV float2 get() const { return make_float2(mn, mx); }
+};
+struct CellMerge {
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    VR_DEV void merge(float2 q) { mn = q.x < mn ? q.x : mn; mx = q.y > mx ? q.y : mx; }
+};
+
+template <typename VT>
+__global__ __launch_bounds__(kThreads) void vr_cell_xy_kernel(VolView vv, CellView grid, float2 *xy /* [d][cy][cx] */)
+{
+    extern __shared__ float2 s_cls[];   // [nbx][4 z slices][3 classes]
+    const int cyi = blockIdx.x % grid.cy, mz = blockIdx.x / grid.cy;
+    const int s = grid.shift, E = 1 << s, bpc = E >> 2;
+    const VT *base = (const VT *)vv.data;
+    const int y_a = max((cyi << s) - 1, 0), y_b = min(((cyi + 1) << s) + 1, vv.h - 1);   // halo'd rows, clipped
+    constexpr int N16 = 64 * (int)sizeof(VT) / 16;
+    for (int mx = threadIdx.x; mx < (int)vv.nbx; mx += kThreads) {
+        CellAcc<VT> acc[4][3];
+        for (int my = y_a >> 2; my <= (y_b >> 2); ++my) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(base + (unsigned long long)mz * vv.zstride +
+                                                             (unsigned long long)my * vv.ystride +
+                                                             (unsigned long long)mx * 64ull);
+            uint4 q[N16];
+#pragma unroll
+            for (int i = 0; i < N16; ++i) q[i] = p[i];
+            VT v[64];
+            __builtin_memcpy(v, q, sizeof v);
+#pragma unroll
+            for (int dy = 0; dy < 4; ++dy) {
+                const int y = 4 * my + dy;
+                if (y < y_a || y > y_b) continue;   // (uniform over the workgroup)
+#pragma unroll
+                for (int dz = 0; dz < 4; ++dz) {
+                    const VT *r = v + dz * 16 + dy * 4;
+                    // columns beyond the volume's width hold padding: never part of a class
+                    const int xs = 4 * mx;
+                    if (xs + 3 < vv.w) {
+                        acc[dz][0].add(r[0]); acc[dz][0].add(r[1]); acc[dz][0].add(r[2]); acc[dz][0].add(r[3]);
+                        acc[dz][1].add(r[0]); acc[dz][1].add(r[1]);
+                        acc[dz][2].add(r[3]);
+                    } else {
+                        for (int dx = 0; dx < 4; ++dx)
+                            if (xs + dx < vv.w) {
+                                acc[dz][0].add(r[dx]);
+                                if (dx < 2) acc[dz][1].add(r[dx]);
+                                if (dx == 3) acc[dz][2].add(r[dx]);
+                            }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int dz = 0; dz < 4; ++dz)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s_cls[(mx * 4 + dz) * 3 + k] = acc[dz][k].get();
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < grid.cx * 4; i += kThreads) {
+        const int cxi = i >> 2, dz = i & 3;
+        const int z = 4 * mz + dz;
+        if (z >= vv.d) continue;
+        CellMerge a;
+        const int b0 = cxi * bpc;
+        if (b0 - 1 >= 0) a.merge(s_cls[((b0 - 1) * 4 + dz) * 3 + 2]);
+        for (int b = b0; b < b0 + bpc && b < (int)vv.nbx; ++b) a.merge(s_cls[(b * 4 + dz) * 3 + 0]);
+        if (b0 + bpc < (int)vv.nbx) a.merge(s_cls[((b0 + bpc) * 4 + dz) * 3 + 1]);
+        xy[((size_t)z * grid.cy + cyi) * grid.cx + cxi] = make_float2(a.mn, a.mx);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void vr_cell_z_kernel(CellView grid, int d, const float2 *xy, float2 *out)
+{
+    const size_t n_cells = (size_t)grid.cx * grid.cy * grid.cz;
+    const size_t c = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (c >= n_cells) return;
+    const size_t plane = (size_t)grid.cx * grid.cy;
+    const int czi = (int)(c / plane);
+    const size_t xyi = c % plane;
+    const int z_a = max((czi << grid.shift) - 1, 0), z_b = min(((czi + 1) << grid.shift) + 1, d - 1);
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    for (int z = z_a; z <= z_b; ++z) {
+        const float2 q = xy[(size_t)z * plane + xyi];
+        mn = q.x < mn ? q.x : mn;
+        mx = q.y > mx ? q.y : mx;
+    }
+    out[c] = make_float2(mn, mx);
+}
+
 // sparse table of the TF opacity for O(1) range maxima: T[j][i] = max(alpha[i .. i + 2^j - 1])
 __global__ __launch_bounds__(kThreads) void vr_cell_sparse_kernel(TfView tf, float *T)
 {
@@ -163,9 +275,39 @@ hipError_t vr_launch_cell_bmask(const VolView &vol, const CellView &grid, int bw
 }
 
 hipError_t vr_launch_cell_minmax(const VolView &vol, int format, const CellView &grid,
-                                 float2 *minmax, hipStream_t stream)
+                                 float2 *minmax, hipStream_t stream, float2 *records)
 {
     const size_t n_cells = (size_t)grid.cx * grid.cy * grid.cz;
+    if (records && grid.shift <= 4) {
+        // separable streaming build (records: d * cy * cx float2 of scratch)
+        const size_t lds = (size_t)vol.nbx * 4 * 3 * sizeof(float2);
+        dim3 g1((unsigned)(grid.cy * (int)vol.nbz)), block(kThreads);
+        int nb = 0;
+        hipError_t e;
+        switch (format) {
+        case VRHIP_UCHAR:
+            e = vr_prepare_kernel(vr_cell_xy_kernel<uint8_t>, kThreads, lds, &nb, "cell grid xy", 0);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(vr_cell_xy_kernel<uint8_t>, g1, block, lds, stream, vol, grid, records);
+            break;
+        case VRHIP_USHORT:
+            e = vr_prepare_kernel(vr_cell_xy_kernel<uint16_t>, kThreads, lds, &nb, "cell grid xy", 0);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(vr_cell_xy_kernel<uint16_t>, g1, block, lds, stream, vol, grid, records);
+            break;
+        case VRHIP_FLOAT:
+            e = vr_prepare_kernel(vr_cell_xy_kernel<float>, kThreads, lds, &nb, "cell grid xy", 0);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(vr_cell_xy_kernel<float>, g1, block, lds, stream, vol, grid, records);
+            break;
+        default: return hipErrorInvalidValue;
+        }
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(vr_cell_z_kernel, dim3((unsigned)((n_cells + kThreads - 1) / kThreads)), block, 0, stream,
+                           grid, vol.d, (const float2 *)records, minmax);
+        return hipGetLastError();
+    }
     const size_t per_block = kThreads / 64;
     dim3 g((unsigned)((n_cells + per_block - 1) / per_block)), block(kThreads);
     switch (format) {

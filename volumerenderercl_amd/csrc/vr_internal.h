@@ -219,8 +219,11 @@ hipError_t vr_launch_build_footprint(const VolView &vol, int format, hipStream_t
 hipError_t vr_launch_pathtrace(const RaycastLaunch &a, hipStream_t stream);
 // cell grid (vr_cells.hip): per-cell (min,max) of the raw voxel values incl. halo; then opacity
 // bound + empty bit from (min,max) and the transfer function.  sparse_scratch: 13 * 4096 floats.
+// records: d * cy * cx float2 of scratch for the separable streaming build (cells of <= 16 voxels,
+// micro-brick rows of <= 2048 bricks: the x classes of a row live in LDS), or nullptr: the
+// one-wave-per-cell kernel
 hipError_t vr_launch_cell_minmax(const VolView &vol, int format, const CellView &grid,
-                                 float2 *minmax, hipStream_t stream);
+                                 float2 *minmax, hipStream_t stream, float2 *records = nullptr);
 hipError_t vr_launch_cell_bounds(const float2 *minmax, const CellView &grid, float inv_max,
                                  const TfView &tf, float *sparse_scratch, float *bound,
                                  uint32_t *empty_bits, hipStream_t stream);

@@ -519,7 +519,21 @@ int ensure_cells(vrhip_renderer *r)
     if (!r->cell_sparse) VR_HIP(r, hipMalloc((void **)&r->cell_sparse, 13 * 4096 * sizeof(float)));
     if (!s.pt_minmax) VR_HIP(r, hipMalloc((void **)&s.pt_minmax, n_cells * sizeof(float2)));
     if (!s.pt_minmax_valid) {
-        VR_HIP(r, vr_launch_cell_minmax(make_vol_view(r, s.dev), r->format, g, s.pt_minmax, r->stream));
+        // scratch for the separable streaming build (one (min, max) per cell column and voxel slice),
+        // held only while it runs
+        float2 *records = nullptr;
+        const size_t n_rec = (size_t)g.cx * g.cy * r->res[2];
+        if (shift <= 4 && r->nb[0] <= 1600u && !getenv("VRHIP_CELLS_PER_WAVE") &&
+            hipMalloc((void **)&records, n_rec * sizeof(float2)) != hipSuccess) {
+            (void)hipGetLastError();
+            records = nullptr;
+        }
+        hipError_t e = vr_launch_cell_minmax(make_vol_view(r, s.dev), r->format, g, s.pt_minmax, r->stream, records);
+        if (records) {
+            if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
+            (void)hipFree(records);
+        }
+        VR_HIP(r, e);
         s.pt_minmax_valid = true;
     }
     VR_HIP(r, vr_launch_cell_bounds(s.pt_minmax, g, inv_max_of(r->format), make_tf_view(r),
@@ -939,6 +953,27 @@ int vrhip_set_stream(vrhip_renderer *r, void *hip_stream, int use_own)
     if (set_device(r)) return VRHIP_ERR_HIP;
     VR_HIP(r, hipStreamSynchronize(r->stream));
     r->stream = use_own ? r->own_stream : (hipStream_t)hip_stream;
+    return VRHIP_OK;
+}
+
+int vrhip_download_cells(vrhip_renderer *r, float *out_minmax, size_t n_floats, uint32_t dims[3],
+                         uint32_t *shift)
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    VR_REQUIRE(r, !r->vols.empty() && r->timestep < r->vols.size() && r->vols[r->timestep].dev,
+               VRHIP_ERR_NODATA, "No volume data is loaded.");
+    VR_REQUIRE(r, r->tff && r->tff_n, VRHIP_ERR_NODATA, "No transfer function set.");
+    if (set_device(r)) return VRHIP_ERR_HIP;
+    r->pt_dirty = true;
+    int rc = ensure_cells(r);
+    if (rc) return rc;
+    const size_t n_cells = (size_t)r->cells.cx * r->cells.cy * r->cells.cz;
+    if (dims) { dims[0] = (uint32_t)r->cells.cx; dims[1] = (uint32_t)r->cells.cy; dims[2] = (uint32_t)r->cells.cz; }
+    if (shift) *shift = (uint32_t)r->cells.shift;
+    if (!out_minmax) return VRHIP_OK;
+    VR_REQUIRE(r, n_floats == 2 * n_cells, VRHIP_ERR_INVALID, "vrhip_download_cells: size mismatch");
+    VR_HIP(r, hipStreamSynchronize(r->stream));
+    VR_HIP(r, hipMemcpy(out_minmax, r->vols[r->timestep].pt_minmax, n_cells * sizeof(float2), hipMemcpyDeviceToHost));
     return VRHIP_OK;
 }
 
