@@ -57,8 +57,9 @@ def parse():
     ap.add_argument("--workload", default="shells2048", choices=sorted(WORKLOADS))
     ap.add_argument("--viewport", type=int, default=1024)
     ap.add_argument("--tile", type=int, default=64, help="tile edge for the multi-GPU split")
-    ap.add_argument("--frames-per-gather", type=int, default=32,
-                    help="multi-GPU: independent frames per RCCL gather")
+    ap.add_argument("--frames-per-gather", type=int, default=64,
+                    help="multi-GPU: independent frames per RCCL gather (each renderer of a rank renders "
+                         "its half of them in one set of launches: <= 32 frames per set)")
     ap.add_argument("--frames-per-launch", type=int, default=8,
                     help="independent frames (own jitter seeds) rendered by one set of launches "
                          "(vrhip_render_batch); 1 = one frame per launch set")
@@ -397,8 +398,8 @@ def main():
         roofline = {
             "kernel": ("vr_pathtrace_kernel <%s>, one launch per sample-per-pixel pass" % fmt_name.lower())
                       if technique == 1 else
-                      "ray-cast pass <%s, ESS=%s> = vr_dda_prepass_kernel + vr_raycast_kernel + "
-                      "(counting sort) + vr_raycast_split_kernel, back-to-back launches per frame"
+                      "ray-cast pass <%s, ESS=%s> = vr_dda_prepass_kernel + vr_raycast_rays_kernel + "
+                      "(counting sort) + vr_raycast_split_kernel, back-to-back launches per set of frames"
                       % (fmt_name.lower(), ess),
             "bound": "hbm",
             "achieved": achieved,

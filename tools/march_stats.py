@@ -21,9 +21,11 @@ vr.setTransferFunction({"default": frontend.tff_from_stops, "haze": frontend.haz
 vr.setIllumination(illum)
 vr.updateView(frontend.view_matrix(frontend.quat_from_axis_angle((1, 1, 0), 30.0)))
 mt = frontend.Mt19937()
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 32)()
 f = vr.lib.vrhip_debug_march_stats
 f.argtypes = [C.c_void_p, C.c_int]
+if os.environ.get("VRHIP_ROUND_BUDGET_STATS"):
+    vr.setRoundBudget(int(os.environ["VRHIP_ROUND_BUDGET_STATS"]))
 for k in range(3):
     vr.setSeed(mt())
     vr.setIteration(0)
@@ -36,3 +38,10 @@ for n, x in zip(names, v):
     print("%-28s %12d" % (n, x))
 print("live lanes per round %.1f; DDA lanes per DDA exec %.1f; stepping lanes per exec %.1f; samples per B1 pass %.1f, per B2 pass %.1f" % (
     v[1] / max(v[0], 1), v[4] / max(v[3], 1), v[6] / max(v[5], 1), v[7] / max(v[8], 1), v[10] / max(v[11], 1)))
+
+if any(v[16:]):
+    names1 = ["rounds", "live lanes x rounds", "DDA step executions", "  lanes in them", "lookahead executions", "  lanes in them",
+              "evaluation batches", "  lanes in them", "refills", "valid samples evaluated"]
+    print("-- phase 1 on the ray list (vr_raycast_rays_kernel)")
+    for n, x in zip(names1, v[16:]):
+        print("%-28s %12d" % (n, x))

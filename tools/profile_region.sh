@@ -32,3 +32,7 @@ d=json.load(open('$OUT/bench.json'))
 thr = d['frames_in_flight']>1 or d['frames_per_launch']>1
 print(d['warmup'] + (d['frames_in_flight']*min(d['frames_per_launch'], d['steps']) if thr else 0) + d['steps'])")
 python3 "$ROOT/tools/pmc_issue.py" "$OUT" "$WL" "$FRAMES" "$OUT/issue.json"
+VB=$(python3 -c "
+import sys; sys.path.insert(0, '$ROOT'); import bench
+w = bench.WORKLOADS['$WL']; print(w[1] ** 3 * bench.FMT_BYTES[w[2]])")
+python3 "$ROOT/tools/pmc_traffic.py" "$OUT" "$WL" "$FRAMES" "$OUT/traffic.json" "$VB"

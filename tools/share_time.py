@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""tools/share_time.py [WORLD] [VIEWPORT] -- GPU time per frame of rank 0's tile share of a WORLD-rank split
+(no gather), for several (renderers in flight, frames per launch set): what image-tile strong scaling
+can reach before the collective.  One GPU."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from volumerenderercl_amd import VolumeRenderCL, frontend, tiles
+
+world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+V = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+dev = torch.device("cuda", 0)
+vr = VolumeRenderCL(); vr.initialize()
+vr.synthVolume("shells", (2048,) * 3, 0)
+vr.setTransferFunction(frontend.tff_from_stops())
+vr.updateView(frontend.view_matrix(frontend.quat_from_axis_angle((1, 1, 0), 30.0)))
+vr.setRoundBudget(48)
+mt = frontend.Mt19937()
+seeds = [mt() for _ in range(4096)]
+twins = [vr] + [vr.shareVolumes() for _ in range(3)]
+streams = [torch.cuda.Stream(dev) for _ in twins]
+for r, s in zip(twins, streams):
+    r.set_stream(s.cuda_stream)
+for w in sorted({1, world}):
+    split = tiles.TileSplit(V, V, 64, 64, w, 0)
+    ids = None if w == 1 else split.my_tiles
+    npix = V * V if w == 1 else len(ids) * 64 * 64
+    for fif, fpl in ((1, 1), (2, 8), (2, 16), (2, 32), (3, 16), (4, 8), (1, 32), (4, 16)):
+        outs = [torch.empty((fpl, npix, 4), dtype=torch.float32, device=dev) for _ in range(fif)]
+        def run(nsets):
+            k = 0
+            for i in range(nsets):
+                j = i % fif
+                sd = seeds[k:k + fpl]; k += fpl
+                if ids is None:
+                    twins[j].render_batch(V, V, sd, outs[j].data_ptr())
+                else:
+                    twins[j].render_batch(V, V, sd, outs[j].data_ptr(), 64, 64, ids, frame_stride=npix)
+        run(fif); torch.cuda.synchronize()
+        nsets = max(fif * 2, 256 // fpl)
+        t0 = time.perf_counter(); run(nsets); torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / (nsets * fpl)
+        print("world %d share (%d px)  %d renderer(s) x %2d frames/set: %.4f ms/frame" % (w, npix, fif, fpl, ms), flush=True)

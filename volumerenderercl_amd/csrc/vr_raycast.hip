@@ -39,6 +39,13 @@ namespace {
 
 constexpr int kSplit = 4;            // lanes per ray in phase 2 (x kBatch samples per lane)
 
+#ifdef VR_MARCH_STATS   // diagnostic build: what the waves of the marching kernels spend their rounds on
+__device__ unsigned long long g_march_stats[32];   // [0, 16) march kernel, [16, 32) phase 1 on the ray list
+#define VR_MS(i, v) ms_acc[i] += (unsigned long long)(v)
+#else
+#define VR_MS(i, v)
+#endif
+
 // Occupancy experiments: -DVR_WAVES_PER_EU=N asks the compiler to fit N waves per SIMD
 #ifdef VR_WAVES_PER_EU
 #define VR_OCC __attribute__((amdgpu_waves_per_eu(VR_WAVES_PER_EU, VR_WAVES_PER_EU)))
@@ -1009,8 +1016,12 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
     bool have = false, drained = false;
     uint32_t gx = 0, gy = 0, out_index = 0, my_rounds = 0, frame_idx = 0;
     bool guess_empty = true;
+    uint32_t cool = 0;   // evaluation batches before the ray guesses "empty" again (see the lookahead below)
     LeapCache lc;
     lc.key0 = lc.key1 = 0xffffffffu; lc.m0 = lc.m1 = 0ull; lc.du = lc.dv = lc.ds = lc.inv_step = 0.f;
+#ifdef VR_MARCH_STATS
+    unsigned long long ms_acc[16] = {0};
+#endif
     RayCtx c;
     RayDyn d;
     setup_ray<true>(0u, 0u, false, fr, cam, rp, rc, resf, voxLen, grid, c, d, rp.seed);   // S_DONE
@@ -1022,6 +1033,7 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
             const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle_m);
             const bool all_idle = idle_m == ~0ull;
             if ((!drained && n_idle >= kRefillLanes) || all_idle) {
+                VR_MS(8, 1);                                                   // refills
                 if (idle && have) {   // retire a finished ray (suspended ones have given up `have`)
                     write_pixel<false>(fr, rp, c, d, voxLen, gx, gy, (size_t)out_index);
                     have = false;
@@ -1050,6 +1062,7 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
                             fetch_skip_word(sb, grid, d);
                             my_rounds = 0;
                             guess_empty = true;
+                            cool = 0;
                             leap_reset(lc, c, vol.fw, vol.fh, vol.fd);
                         }
                     }
@@ -1061,9 +1074,13 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
             }
         }
         // ---- one round (the patch kernel's)
+        VR_MS(0, 1);                                                           // rounds
+        VR_MS(1, __builtin_popcountll(__ballot(d.state != S_DONE)));           // live lanes, summed over rounds
         for (int it = 0;; ++it) {
             if (!__ballot(d.state == S_BRICK)) break;
             if (it >= kMaxBrickSteps && __ballot(d.state == S_SAMPLE)) break;
+            VR_MS(2, 1);                                                       // DDA step executions
+            VR_MS(3, __builtin_popcountll(__ballot(d.state == S_BRICK)));      // lanes in them
             dda_step<0>(sb, grid, c, d, n0, n1);
         }
         if (!__ballot(d.state != S_DONE)) continue;
@@ -1107,12 +1124,22 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
             }
             more_empty = !ready;
         } else if (skip_empty && lookahead_pays(d.state == S_SAMPLE, guess_empty)) {
+            VR_MS(4, 1);                                                       // lookahead executions
+            VR_MS(5, __builtin_popcountll(__ballot(d.state == S_SAMPLE)));     // lanes in them
             if (d.state == S_SAMPLE) {
                 const uint32_t em = empty_mask<VT, 0, kLook1>(cells, vol, c, d.t);
                 more_empty = skip_empty_run(em, c, d, false, n0);
                 guess_empty = (em & 1u) != 0u;
+                // a transparent sample in a cell that is NOT empty (the rim of a structure) says little
+                // about the samples behind it: no new guess for the next `cool` batches.  How long: as
+                // many batches as the mask shows non-empty samples ahead
+                if (!(em & 1u)) cool = (uint32_t)(__builtin_ctz(em | 0x10000u) / kBatch);
                 after_segment<true>(c, d);
             }
+        }
+        if (__ballot(d.state == S_SAMPLE && !more_empty)) {
+            VR_MS(6, 1);                                                       // evaluation batches
+            VR_MS(7, __builtin_popcountll(__ballot(d.state == S_SAMPLE && !more_empty)));   // lanes in them
         }
         if (d.state == S_SAMPLE && !more_empty) {
             float tk[kBatch];
@@ -1125,15 +1152,27 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
                 vk[k] = vk[k - 1] && !(tk[k - 1] >= c.tfar) && (tk[k] < d.t_exit);  // :868, :790
             }
             float p0[kBatch], p1[kBatch], p2[kBatch], opk[kBatch];
+#ifdef VR_MARCH_STATS
+            for (int k = 0; k < kBatch; ++k) ms_acc[9] += vk[k] ? 1 : 0;      // valid samples evaluated (per lane: summed below)
+#endif
             eval_batch<VT, 0, false, FP>(vol, s_tff, tffn, s_stage, c, rp, rc, refInterval, tk, vk, p0, p1, p2,
                                          opk, litk);
 #pragma unroll
             for (int k = 0; k < kBatch; ++k)
                 if (vk[k] && d.state == S_SAMPLE) composite(c, d, p0[k], p1[k], p2[k], opk[k], tk[k]);
-            if (vk[kBatch - 1]) guess_empty = opk[kBatch - 1] == 0.f;
+            if (vk[kBatch - 1]) guess_empty = opk[kBatch - 1] == 0.f && cool == 0u;
+            if (cool) --cool;
             after_segment<true>(c, d);
         }
     }
+#ifdef VR_MARCH_STATS
+    if (lane == 0)
+        for (int i = 0; i < 9; ++i) atomicAdd(&g_march_stats[16 + i], ms_acc[i]);
+    {
+        unsigned long long w = wave_sum(ms_acc[9]);
+        if (lane == 0) atomicAdd(&g_march_stats[16 + 9], w);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------ decoupled march
@@ -1170,12 +1209,6 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
 #define VR_MARK(x) asm volatile("; VRMARK " x ::: "memory")
 #else
 #define VR_MARK(x)
-#endif
-#ifdef VR_MARCH_STATS   // diagnostic build: what the waves of the march kernel spend their rounds on
-__device__ unsigned long long g_march_stats[16];
-#define VR_MS(i, v) ms_acc[i] += (unsigned long long)(v)
-#else
-#define VR_MS(i, v)
 #endif
 #ifndef VR_MARCH_Q
 #define VR_MARCH_Q 4
@@ -1932,6 +1965,7 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
     bool have = false, drained = false;
     uint32_t gx = 0, gy = 0, out_index = 0, my_rounds = 0;
     bool guess_empty = true;   // identical in the four lanes of a ray, like all of its state
+    uint32_t cool = 0;         // evaluation batches before the ray guesses "empty" again
     RayCtx c;
     RayDyn d;
     setup_ray<ESS>(0u, 0u, false, fr, cam, rp, rc, resf, voxLen, grid, c, d, rp.seed);   // S_DONE
@@ -1986,6 +2020,7 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
                             if (ESS) fetch_skip_word(sb, grid, d);
                             my_rounds = 0;
                             guess_empty = true;
+                            cool = 0;
                             leap_reset(lc, c, vol.fw, vol.fh, vol.fd);
                         }
                     }
@@ -2053,6 +2088,11 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
                                             (uint32_t)quad_bcast<2>(em), (uint32_t)quad_bcast<3>(em)};
                     more_empty = skip_empty_run_wide(m4, c, d, count, c_taken);
                     guess_empty = (m4[0] & 1u) != 0u;
+                    // (see phase 1: no new guess while the mask shows samples in cells that are not empty)
+                    if (!(m4[0] & 1u)) {
+                        const uint32_t all = m4[0] | (m4[1] << kLook2) | (m4[2] << (2 * kLook2)) | (m4[3] << (3 * kLook2));
+                        cool = (uint32_t)((all ? __builtin_ctz(all) : 4 * kLook2) / (kSplit * kBatch));
+                    }
                     after_segment<ESS>(c, d);
                 }
             }
@@ -2113,7 +2153,8 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
                 {   // the ray's 16th sample of this round: lane 3 of the quad, slot kBatch - 1
                     const int f3v = quad_bcast<3>(fl[kBatch - 1]);
                     const float o3 = quad_bcast<3>(opk[kBatch - 1]);
-                    if (f3v & 1) guess_empty = o3 == 0.f;
+                    if (f3v & 1) guess_empty = o3 == 0.f && cool == 0u;
+                    if (cool) --cool;
                 }
                 after_segment<ESS>(c, d);
                 VR_STAMP(6);
@@ -2346,13 +2387,13 @@ hipError_t launch_typed(const RaycastLaunch &a, hipStream_t stream)
 
 #ifdef VR_MARCH_STATS
 // diagnostic builds only: read (and optionally clear) the march kernel's round statistics
-extern "C" int vrhip_debug_march_stats(unsigned long long out[16], int reset)
+extern "C" int vrhip_debug_march_stats(unsigned long long out[32], int reset)
 {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_march_stats), 16 * sizeof(unsigned long long)) != hipSuccess)
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_march_stats), 32 * sizeof(unsigned long long)) != hipSuccess)
         return -1;
     if (reset) {
-        unsigned long long z[16] = {0};
+        unsigned long long z[32] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_march_stats), z, sizeof z) != hipSuccess) return -1;
     }
     return 0;
