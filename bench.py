@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--frames-per-gather", type=int, default=64,
                     help="multi-GPU: independent frames per RCCL gather (each renderer of a rank renders "
                          "its half of them in one set of launches: <= 32 frames per set)")
-    ap.add_argument("--frames-per-launch", type=int, default=8,
+    ap.add_argument("--frames-per-launch", type=int, default=16,
                     help="independent frames (own jitter seeds) rendered by one set of launches "
                          "(vrhip_render_batch); 1 = one frame per launch set")
     ap.add_argument("--round-budget", type=int, default=48,
@@ -262,7 +262,12 @@ def main():
     # world > 1: one gather in flight -- the gather + assembly of a batch of frames overlap the
     # rendering of the next batch
     chunks = [list(range(c0, min(c0 + fpg, args.steps))) for c0 in range(0, args.steps, fpg)]
-    blocks = [list(range(c0, min(c0 + fpl, args.steps))) for c0 in range(0, args.steps, fpl)]
+    # the timed frames in launch sets of <= fpl frames, as many sets as a multiple of the renderers in
+    # flight and all of (nearly) the same size: no renderer is left with a short last set
+    n_sets = -(-args.steps // fpl)
+    n_sets = min(args.steps, -(-n_sets // fif) * fif)
+    bounds = [round(i * args.steps / n_sets) for i in range(n_sets + 1)]
+    blocks = [list(range(bounds[i], bounds[i + 1])) for i in range(n_sets) if bounds[i + 1] > bounds[i]]
     drv = driver_mt if (world > 1 and throughput) else driver
 
     def submit_chunk(chunk):
@@ -327,7 +332,7 @@ def main():
                 "profile_region": True, "workload": args.workload, "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
                 "avg_launch_ms": gpu_region_s / args.steps * 1e3,
-                "frames_in_flight": fif, "frames_per_launch": fpl,
+                "frames_in_flight": fif, "frames_per_launch": max(len(b_) for b_ in blocks) if throughput else 1,
                 "round_budget": args.round_budget if throughput else 10,
                 "launch_sets_in_region": len(blocks) if (world == 1 and throughput) else args.steps,
                 "note": "timed region only; work counters, roofline and cpu_baseline come from the full run"})
@@ -414,10 +419,10 @@ def main():
             "algorithmic_bytes_per_launch": int(alg_bytes),
             "avg_launch_ms": kernel_s * 1e3,
             "frames_in_flight": fif,
-            "frames_per_launch": fpl,
+            "frames_per_launch": max(len(b_) for b_ in blocks) if throughput else 1,
             "round_budget": args.round_budget if throughput else 10,
             "serial_launch_ms": serial_s * 1e3 if serial_s else None,
-            "launch_note": ("%d renderer(s) on as many streams over one shared volume, each rendering %d independent "
+            "launch_note": ("%d renderer(s) on as many streams over one shared volume, each rendering up to %d independent "
                             "frames (own jitter seeds) per set of launches (vrhip_render_batch): avg_launch_ms = "
                             "HIP-event time of the timed region / frames, phase-1 round budget %d (throughput "
                             "schedule); serial_launch_ms = the same frames one at a time with the single-frame "

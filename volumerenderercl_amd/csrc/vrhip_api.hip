@@ -118,9 +118,12 @@ struct vrhip_renderer {
     void *fp = nullptr;               // footprint volume of the current time step (VolView::fp)
     size_t fp_cap = 0;                // bytes allocated
     bool fp_valid = false;
+    uint32_t fp_timestep = 0;         // the time step `fp` was built for
     bool fp_active = false;           // this frame reads it
+    const void *fp_use = nullptr;     // what this frame reads: the renderer's own `fp` or its owner's
+    vrhip_renderer *vol_owner = nullptr;   // vrhip_share_volumes: whose voxels (and footprint volume) this renderer renders from
     bool use_fp = true;               // VRHIP_NO_FOOTPRINT=1 disables
-    size_t fp_max_bytes = (size_t)33 << 30;   // VRHIP_FOOTPRINT_MAX_GB
+    size_t fp_max_bytes = (size_t)96 << 30;   // VRHIP_FOOTPRINT_MAX_GB
     float4 *env = nullptr;            // environment map (float RGBA), or nullptr
     uint32_t env_w = 0, env_h = 0;
 
@@ -272,7 +275,7 @@ VolView make_render_view(const vrhip_renderer *r, const VolumeSlot &s)
     VolView v = make_vol_view(r, s.dev);
     for (int i = 0; i < 3; ++i) v.chan[i] = s.chan[i];
     v.channels = r->channels;
-    v.fp = (r->fp_valid && r->fp_active) ? r->fp : nullptr;
+    v.fp = r->fp_active ? r->fp_use : nullptr;
     return v;
 }
 
@@ -424,9 +427,13 @@ int ensure_hit_images(vrhip_renderer *r, uint32_t w, uint32_t h)
 }
 
 // Footprint volume of the current time step (VolView::fp, DESIGN.md "Footprint volume"): 8x the
-// volume's bytes, so that a trilinear fetch is one load.  Measured: -8 % frame time at 256^3,
-// -5 % at 1024^3 UCHAR, -3 % around 30 GB (1536^3 UCHAR, 1024^3 FLOAT), nothing at 2048^3 (69 GB),
-// hence the cap.  Built on first use, kept until the volume or the time step changes.
+// volume's bytes, so that a trilinear fetch is one load and none of the micro-brick address
+// arithmetic.  The march is bound by VALU issue, so the instructions saved are frame time: -12 % at
+// 2048^3 UCHAR in throughput mode (69 GB; 0.297 -> 0.261 ms), -4 % one frame at a time, -7 % on the
+// dense "haze" volume (round 2; round 1 had measured +-0 one frame at a time and capped it at 33 GB).
+// 288 GB of HBM are what this is for: the cap is 96 GB, one copy per GPU (renderers that share an
+// owner's voxels read the owner's).  Built on first use, kept until the volume or the time step
+// changes.
 int ensure_footprint(vrhip_renderer *r)
 {
     r->fp_active = false;
@@ -438,9 +445,22 @@ int ensure_footprint(vrhip_renderer *r)
     const size_t bytes = (size_t)v.fp_nbx * v.fp_nby * ((size_t)(r->res[2] + 4u) >> 2) * 64u * 8u *
                          fmt_bytes(r->format);
     if (bytes > r->fp_max_bytes) return VRHIP_OK;
-    if (!r->fp_valid) {
+    // a renderer that shares an owner's voxels reads the owner's footprint volume of the same time step
+    // (69 GB at 2048^3: one copy per GPU, not one per frame in flight); the owner builds it with its
+    // first frame, which in every driver here comes before the twins' frames
+    if (r->vol_owner) {
+        const vrhip_renderer *o = r->vol_owner;
+        if (o->fp && o->fp_valid && o->fp_timestep == r->timestep) {
+            r->fp_use = o->fp;
+            r->fp_active = true;
+        }
+        return VRHIP_OK;   // (no copy of its own: the plain layout until the owner has one)
+    }
+    if (!r->fp_valid || r->fp_timestep != r->timestep) {
+        // (renderers that share this one's volumes may be reading the old one on their own streams)
+        VR_HIP(r, hipDeviceSynchronize());
+        r->fp_valid = false;
         if (bytes > r->fp_cap) {
-            VR_HIP(r, hipStreamSynchronize(r->stream));
             if (r->fp) VR_HIP(r, hipFree(r->fp));
             r->fp = nullptr;
             r->fp_cap = 0;
@@ -454,8 +474,11 @@ int ensure_footprint(vrhip_renderer *r)
         VolView fv = v;
         fv.fp = r->fp;
         VR_HIP(r, vr_launch_build_footprint(fv, r->format, r->stream));
+        VR_HIP(r, hipStreamSynchronize(r->stream));   // sharers render on other streams
         r->fp_valid = true;
+        r->fp_timestep = r->timestep;
     }
+    r->fp_use = r->fp;
     r->fp_active = true;
     return VRHIP_OK;
 }
@@ -1126,6 +1149,7 @@ int vrhip_clear_volumes(vrhip_renderer *r)
     }
     r->vols.clear();
     r->fp_valid = false;
+    r->vol_owner = nullptr;
 
     r->bricks_valid = false;
     r->skip_dirty = true;
@@ -1180,7 +1204,8 @@ int vrhip_share_volumes(vrhip_renderer *r, vrhip_renderer *owner)
     }
     r->bricks_valid = owner->bricks_valid;
     r->timestep = owner->timestep < r->vols.size() ? owner->timestep : 0;
-    r->fp_valid = false;   // the footprint volume follows the renderer's own time step: not shared
+    r->fp_valid = false;   // (its own footprint volume is not used while it shares: ensure_footprint)
+    r->vol_owner = owner;
     r->skip_dirty = true;
     r->pt_dirty = true;
     return VRHIP_OK;
