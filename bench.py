@@ -449,6 +449,10 @@ def main():
                 "peak": peak_wi / 1e9,
                 "unit": "G wave-instructions/s",
                 "frac": ach_wi / peak_wi,
+                # what the chip sustains on independent v_fma_f32 chains with every CU busy
+                # (tools/micro_occ.hip, MI355X: 4.9e11/s at two waves per SIMD, 5.76e11 at eight)
+                "peak_measured": 576.0,
+                "frac_of_measured": ach_wi / 5.76e11,
                 "valu_wave_insts_per_frame": issue["valu_wave_insts_per_frame"],
                 "valu_lane_utilisation": issue.get("valu_lane_utilisation"),
                 "source": issue.get("source"),

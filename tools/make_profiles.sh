@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/profiles_$R
 mkdir -p "$OUT"
 cd "$ROOT"
 bash tools/profile_region.sh ${R}_tput shells2048 --warmup 0 --steps 64 > "$OUT/region_tput.log" 2>&1
-bash tools/profile_region.sh ${R}_single shells2048 --warmup 0 --steps 32 --frames-in-flight 1 --frames-per-launch 1 > "$OUT/region_single.log" 2>&1
+bash tools/profile_region.sh ${R}_single shells2048 --warmup 1 --steps 32 --frames-in-flight 1 --frames-per-launch 1 > "$OUT/region_single.log" 2>&1
 for t in tput single; do
   D=$ROOT/gpurun_out/region_${R}_$t
   cp "$D/stats.csv" "$OUT/shells2048_${t}_kernel_stats.csv"
