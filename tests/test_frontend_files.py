@@ -55,3 +55,29 @@ def test_tff_files_round_trip(tmp_path):
     (tmp_path / "empty.tff").write_text("# nothing\n1 2 3\n")
     with pytest.raises(ValueError):
         frontend.read_tff_stops(str(tmp_path / "empty.tff"))
+
+
+def test_view_matrix_against_an_independent_composition():
+    """updateViewMatrix (volumerenderwidget.cpp:1079-1098) composes QMatrix4x4 operations:
+    identity . rotate(q) . translate(t) . scale(t.z), each post-multiplying, and hands the matrix over
+    transposed (Qt stores column-major, the kernel reads rows).  Restated here with scipy's
+    quaternion-to-matrix conversion (Qt's scalar-first (w, x, y, z) -> scipy's (x, y, z, w)) and
+    explicit 4x4 products -- an implementation that shares no code with frontend.view_matrix."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(0)
+    cases = [((1.0, 0.0, 0.0, 0.0), (0.0, 0.0, 2.0)), (frontend.quat_from_axis_angle((1, 1, 0), 30.0), (0.0, 0.0, 2.0))]
+    for _ in range(20):
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        cases.append((tuple(q), tuple(rng.uniform(-1.5, 3.0, 3))))
+    for q, t in cases:
+        R = np.eye(4)
+        R[:3, :3] = Rotation.from_quat([q[1], q[2], q[3], q[0]]).as_matrix()
+        T = np.eye(4)
+        T[:3, 3] = t
+        S = np.diag([t[2], t[2], t[2], 1.0])
+        want = (R @ T @ S).astype(np.float32).reshape(-1)      # row-major = the transposed column-major data
+        got = np.array(frontend.view_matrix(q, t), dtype=np.float32)
+        np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-6)
+    # the default camera of SURVEY 8(d): rot = identity, translation (0, 0, 2)
+    assert frontend.view_matrix() == [2, 0, 0, 0, 0, 2, 0, 0, 0, 0, 2, 2, 0, 0, 0, 1]
