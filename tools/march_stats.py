@@ -45,3 +45,7 @@ if any(v[16:]):
     print("-- phase 1 on the ray list (vr_raycast_rays_kernel)")
     for n, x in zip(names1, v[16:]):
         print("%-28s %12d" % (n, x))
+
+if any(v[28:]):
+    print("-- pre-pass: patches that walk %d, DDA step executions %d (%.1f per patch), lanes in them %d (%.1f per execution), valid rays in those patches %d" % (
+        v[28], v[29], v[29] / max(v[28], 1), v[30], v[30] / max(v[29], 1), v[31]))

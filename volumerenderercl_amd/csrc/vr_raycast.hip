@@ -92,14 +92,16 @@ struct Grid {     // wave-uniform brick-grid constants
     uint32_t oob_word;
 };
 
-// volumeraycast.cl:605-760 for one pixel: ray, background, clip, step size, DDA set-up.
-template <bool ESS>
-VR_DEV void setup_ray(uint32_t gx, uint32_t gy, bool inside, const FrameView &fr,
-                      const vrhip_camera_params &cam, const vrhip_rendering_params &rp,
-                      const vrhip_raycast_params &rcp, f3 resf, f3 voxLen, const Grid &g, RayCtx &c,
-                      RayDyn &d, uint32_t seed)
+// volumeraycast.cl:605-683 for one pixel: ray, background, clip.  The first half of setup_ray: all the
+// pre-pass's patch culling needs (and all a ray that is never marched needs: write_pixel reads the
+// background and the clip result).  SHADE: the illumination invariants (:280-303).
+template <bool SHADE>
+VR_DEV void setup_ray_head(uint32_t gx, uint32_t gy, bool inside, const FrameView &fr,
+                           const vrhip_camera_params &cam, const vrhip_rendering_params &rp, RayCtx &c,
+                           RayDyn &d, uint32_t seed, float &rnd)
 {
     const Ray ray = make_ray(gx, gy, fr, cam, rp, seed);
+    rnd = ray.rnd;
     c.cam = ray.cam;
     c.dir = ray.dir;
     c.env0 = ray.env[0]; c.env1 = ray.env[1]; c.env2 = ray.env[2]; c.env3 = ray.env[3];
@@ -112,11 +114,16 @@ VR_DEV void setup_ray(uint32_t gx, uint32_t gy, bool inside, const FrameView &fr
     c.stepv0 = c.stepv1 = c.stepv2 = 0;
     c.exit0 = c.exit1 = c.exit2 = 0;
     c.dT0 = c.dT1 = c.dT2 = 0.f;
-    const f3 toLight = neg3(ray.dir);
-    c.lgt = normalize3(toLight);
-    f3 hv = add3(toLight, c.lgt);
-    c.hvalid = !(dot3(hv, hv) < 1.e-6f);
-    c.hv = normalize3(hv);
+    if (SHADE) {
+        const f3 toLight = neg3(ray.dir);
+        c.lgt = normalize3(toLight);
+        f3 hv = add3(toLight, c.lgt);
+        c.hvalid = !(dot3(hv, hv) < 1.e-6f);
+        c.hv = normalize3(hv);
+    } else {
+        c.lgt = c.hv = mk3(0.f, 0.f, 0.f);
+        c.hvalid = false;
+    }
 
     d.state = S_DONE;
     d.t = 0.f; d.t_exit = ray.tfar; d.alpha = 0.f;
@@ -129,22 +136,29 @@ VR_DEV void setup_ray(uint32_t gx, uint32_t gy, bool inside, const FrameView &fr
 #ifdef VR_RAYLEN
     d.nsmp = 0;
 #endif
+    if (c.valid) c.tnear = vmax(0.f, ray.tnear);   // :719 (the unclamped value is not needed again)
+}
+
+// volumeraycast.cl:709-760: step size, jitter offset, DDA set-up -- for rays that will be marched.
+template <bool ESS>
+VR_DEV void setup_ray_tail(const vrhip_raycast_params &rcp, f3 resf, f3 voxLen, const Grid &g, RayCtx &c,
+                           RayDyn &d, float rnd)
+{
     if (c.valid) {
         // volumeraycast.cl:709-733
         float stepSize = vmin(c.sampleDist,
                               c.sampleDist / (rcp.samplingRate *
-                                              len3(mul3(scale3(ray.dir, c.sampleDist), resf))));
+                                              len3(mul3(scale3(c.dir, c.sampleDist), resf))));
         c.nominal = ceilf(c.sampleDist / stepSize);
         c.stepSize = c.sampleDist / c.nominal;
-        c.tnear = vmax(0.f, ray.tnear);
         d.t = c.tnear;
-        c.offset = (len3(voxLen) * ray.rnd) * 2.0f;
+        c.offset = (len3(voxLen) * rnd) * 2.0f;
         d.state = ESS ? S_BRICK : S_SAMPLE;
         if (ESS) {   // 3-D DDA set-up (:737-760)
             const int bres[3] = {g.bw, g.bh, g.bd};
             const float bl[3] = {g.bl0, g.bl1, g.bl2};
-            const float dirv[3] = {ray.dir.x, ray.dir.y, ray.dir.z};
-            const float camv[3] = {ray.cam.x, ray.cam.y, ray.cam.z};
+            const float dirv[3] = {c.dir.x, c.dir.y, c.dir.z};
+            const float camv[3] = {c.cam.x, c.cam.y, c.cam.z};
             int stepv[3], cell[3], exitc[3];
             float tv[3], dT[3];
             for (int i = 0; i < 3; ++i) {
@@ -165,6 +179,18 @@ VR_DEV void setup_ray(uint32_t gx, uint32_t gy, bool inside, const FrameView &fr
             d.tv0 = tv[0]; d.tv1 = tv[1]; d.tv2 = tv[2];
         }
     }
+}
+
+// volumeraycast.cl:605-760 for one pixel: ray, background, clip, step size, DDA set-up.
+template <bool ESS>
+VR_DEV void setup_ray(uint32_t gx, uint32_t gy, bool inside, const FrameView &fr,
+                      const vrhip_camera_params &cam, const vrhip_rendering_params &rp,
+                      const vrhip_raycast_params &rcp, f3 resf, f3 voxLen, const Grid &g, RayCtx &c,
+                      RayDyn &d, uint32_t seed)
+{
+    float rnd;
+    setup_ray_head<true>(gx, gy, inside, fr, cam, rp, c, d, seed, rnd);
+    setup_ray_tail<ESS>(rcp, resf, voxLen, g, c, d, rnd);
 }
 
 // bitmap word of the cell the ray is in (out-of-range cells read the trailing word, which
@@ -859,7 +885,8 @@ VR_DEV float wave_max_f(float v)
 // same t on a reference ray r of the patch; 256 test points on r (four per lane) leave no point of r
 // farther than h / 2 from one of them.  The reference DDA of a ray only visits bricks that touch the
 // ray within one brick (its crossing times are accumulated sums, off by far less than a brick), so
-// all it can visit lies within floor((rho + h / 2) / brick) + 2 bricks of a test point's (clamped) brick.
+// all it can visit lies within floor((rho + h / 2) / brick) + 2 bricks of a test point's (clamped) brick
+// (+1 because the test points' bricks are found with a reciprocal, good to a brick).
 // If that is within the radius the bitmap was dilated by and every test point reads 0, every brick
 // any of the rays visits is skipped: the rays end as they started.  Out-of-range cells read the
 // (0, 0) decision, which must be "skip" for any of this to hold.
@@ -882,15 +909,19 @@ VR_DEV bool patch_is_clear(const SkipView &skip, const Grid &g, const RayCtx &c,
     const int bres[3] = {g.bw, g.bh, g.bd};
     // a point within `need` of a test point lies at most floor(need / brick) + 1 bricks from the test
     // point's brick; one more for bricks the DDA visits next to the ray
-    for (int i = 0; i < 3; ++i)
-        if (!(floorf(need / (2.f * bl[i])) + 2.f <= (float)skip.near_r)) return false;
+    float ibs[3];   // bricks per world unit
+    for (int i = 0; i < 3; ++i) {
+        ibs[i] = 0.5f / bl[i];
+        // (+3: one brick more than the derivation needs, for the reciprocal in the test points' bricks)
+        if (!(floorf(need / (2.f * bl[i])) + 3.f <= (float)skip.near_r)) return false;
+    }
     bool live = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float t = tn + ((float)(lane + 64u * (uint32_t)k) + 0.5f) * h;
         const float p[3] = {rc.x + t * rd.x, rc.y + t * rd.y, rc.z + t * rd.z};
-        int cell[3];
-        for (int i = 0; i < 3; ++i) cell[i] = iclamp((int)floorf((p[i] + 1.f) / (2.f * bl[i])), 0, bres[i] - 1);
+        int cell[3];   // (good to a brick: the radius test above has a brick to spare for it)
+        for (int i = 0; i < 3; ++i) cell[i] = iclamp((int)floorf((p[i] + 1.f) * ibs[i]), 0, bres[i] - 1);
         const uint32_t idx = ((uint32_t)cell[2] * (uint32_t)g.bh + (uint32_t)cell[1]) * (uint32_t)g.bw + (uint32_t)cell[0];
         live = live || ((skip.near_bits[idx >> 5] >> (idx & 31u)) & 1u);
     }
@@ -923,17 +954,35 @@ __global__ __launch_bounds__(kBlockDim) void vr_dda_prepass_kernel(
     const Grid grid = make_grid(bricks, rc, skip.n_words, true);
     RayCtx c;
     RayDyn d;
-    setup_ray<true>(gx, gy, inside, fr, cam, rp, rc, resf, voxLen, grid, c, d, seed);
+    float rnd;
+    setup_ray_head<false>(gx, gy, inside, fr, cam, rp, c, d, seed, rnd);   // (nothing is shaded here)
     const size_t out_index = (size_t)wt.out_base + (size_t)ly * fr.out_stride + lx;
     if (rp.imgEss && image_ess_patch(fr, rp, c, wt, lane, inside, gx, gy, out_index)) return;
     if (skip.near_bits && patch_is_clear(skip, grid, c, lane)) {
         // no ray of this patch can meet a brick that is not skipped: what the walk would leave
+        // (step size and DDA set-up are not needed for that)
         if (inside) write_pixel<true>(fr, rp, c, d, voxLen, gx, gy, out_index);
         return;
     }
+    setup_ray_tail<true>(rc, resf, voxLen, grid, c, d, rnd);
     fetch_skip_word(skip.bits, grid, d);
     unsigned long long n0 = 0, n1 = 0;
+#ifdef VR_MARCH_STATS
+    unsigned long long w_steps = 0, l_steps = 0;
+    while (__ballot(d.state == S_BRICK)) {
+        w_steps++;
+        l_steps += __builtin_popcountll(__ballot(d.state == S_BRICK));
+        dda_step<0>(skip.bits, grid, c, d, n0, n1);
+    }
+    if (lane == 0) {
+        atomicAdd(&g_march_stats[28], 1ull);                                     // patches that walk
+        atomicAdd(&g_march_stats[29], w_steps);                                  // DDA step executions
+        atomicAdd(&g_march_stats[30], l_steps);                                  // lanes in them
+        atomicAdd(&g_march_stats[31], (unsigned long long)__builtin_popcountll(__ballot(c.valid)));   // valid rays
+    }
+#else
     while (__ballot(d.state == S_BRICK)) dda_step<0>(skip.bits, grid, c, d, n0, n1);
+#endif
     const bool live = d.state == S_SAMPLE;
     const unsigned long long m = __ballot(live);
     if (inside && !live) {
