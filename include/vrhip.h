@@ -214,6 +214,10 @@ int vrhip_set_image_ess(vrhip_renderer *r, uint32_t width, uint32_t height, cons
  * current time step if need be.  out == NULL: dims / shift only.  For tests. */
 int vrhip_download_cells(vrhip_renderer *r, float *out_minmax, size_t n_floats, uint32_t dims[3],
                          uint32_t *shift);
+/* The same for the finer grid the ray caster's empty bits live on (cells of 4 voxels up to 2048^3;
+ * the grid above where the two coincide). */
+int vrhip_download_empty_cells(vrhip_renderer *r, float *out_minmax, size_t n_floats, uint32_t dims[3],
+                               uint32_t *shift);
 
 /* Image-tile gather, root side: the frame from the gathered tiles.  `staging_dev` holds
  * tile slots of tile_w x tile_h RGBA float pixels (the peers' blocks as received, one after the

@@ -248,10 +248,11 @@ def test_schedules_and_culling_do_not_change_pixels(vr, monkeypatch, env):
 
 @pytest.mark.parametrize("fmt,res", [(UCHAR, (96, 80, 72)), (USHORT, (70, 33, 50)), (FLOAT, (64, 64, 40))])
 def test_cell_grid_bounds(fmt, res, monkeypatch):
-    """The cell grid (min, max of the voxels a fetch in or next to a cell of 8^3 voxels can read): the
-    one-wave-per-cell kernel and the separable streaming build (x and y ranges per voxel slice from
-    whole micro-brick lines, then the z range) both give exactly the extrema of the voxels
-    [8c - 1, 8c + 9]^3 clipped to the volume."""
+    """The cell grids (min, max of the voxels a fetch in or next to a cell of E^3 voxels can read; E = 8
+    for the opacity bounds, 4 for the ray caster's empty bits): the one-wave-per-cell kernel and the
+    separable streaming build (x and y ranges per voxel slice from whole micro-brick lines, then the z
+    range; the coarse grid reduced from the fine one) all give exactly the extrema of the voxels
+    [E c - 1, E c + E + 1]^3 clipped to the volume."""
     vol = common.noise_volume(res, fmt, seed=31, smooth=False)
     got = {}
     for name, env in (("wave", "1"), ("stream", None)):
@@ -264,20 +265,25 @@ def test_cell_grid_bounds(fmt, res, monkeypatch):
         try:
             r2.loadVolumeArrays([vol], fmt)
             r2.setTransferFunction(common.tffs()["default"])
-            got[name], shift = r2.downloadCells()
+            got[name, 8], shift = r2.downloadCells()
             assert shift == 3
+            got[name, 4], shift = r2.downloadCells(fine=True)
+            assert shift == 2
         finally:
             r2.close()
-    cz, cy, cx = got["wave"].shape[:3]
-    want = np.empty_like(got["wave"])
     v = vol.astype(np.float32)
-    for k in range(cz):
-        for j in range(cy):
-            for i in range(cx):
-                box = v[max(8 * k - 1, 0):8 * k + 10, max(8 * j - 1, 0):8 * j + 10, max(8 * i - 1, 0):8 * i + 10]
-                want[k, j, i] = (box.min(), box.max())
-    np.testing.assert_array_equal(got["wave"], want)
-    np.testing.assert_array_equal(got["stream"], want)
+    for E in (8, 4):
+        cz, cy, cx = got["wave", E].shape[:3]
+        assert (cz, cy, cx) == tuple(-(-n // E) for n in v.shape)
+        want = np.empty_like(got["wave", E])
+        for k in range(cz):
+            for j in range(cy):
+                for i in range(cx):
+                    box = v[max(E * k - 1, 0):E * k + E + 2, max(E * j - 1, 0):E * j + E + 2,
+                            max(E * i - 1, 0):E * i + E + 2]
+                    want[k, j, i] = (box.min(), box.max())
+        np.testing.assert_array_equal(got["wave", E], want)
+        np.testing.assert_array_equal(got["stream", E], want)
 
 
 def test_pathtrace_culling_is_exact(vr, monkeypatch):

@@ -233,6 +233,27 @@ __global__ __launch_bounds__(kThreads) void vr_cell_bounds_kernel(const float2 *
     }
 }
 
+// Coarse (min, max) from the fine grid's: a coarse cell's halo'd extent [E c - 1, E (c + 1) + 1] per
+// axis is the union of the extents [e f - 1, e (f + 1) + 1] of the fine cells f inside it.
+__global__ __launch_bounds__(kThreads) void vr_cell_reduce_kernel(const float2 *fine, CellView g, float2 *out)
+{
+    const size_t n = (size_t)g.cx * g.cy * g.cz;
+    const size_t c = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (c >= n) return;
+    const int cxi = (int)(c % (size_t)g.cx), cyi = (int)((c / (size_t)g.cx) % (size_t)g.cy);
+    const int czi = (int)(c / ((size_t)g.cx * g.cy));
+    const int ds = g.shift - g.eshift, m = 1 << ds;
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    for (int k = czi << ds; k < min((czi << ds) + m, g.ecz); ++k)
+        for (int j = cyi << ds; j < min((cyi << ds) + m, g.ecy); ++j)
+            for (int i = cxi << ds; i < min((cxi << ds) + m, g.ecx); ++i) {
+                const float2 q = fine[((size_t)k * g.ecy + j) * g.ecx + i];
+                mn = q.x < mn ? q.x : mn;
+                mx = q.y > mx ? q.y : mx;
+            }
+    out[c] = make_float2(mn, mx);
+}
+
 // CellView::bmask: one thread per ESS brick.  Sub-blocks that lie outside the volume are never
 // looked up (sample coordinates are clamped into the volume) and read 0.
 __global__ __launch_bounds__(kThreads) void vr_cell_bmask_kernel(VolView vv, CellView g, int bw, int bh,
@@ -252,10 +273,10 @@ __global__ __launch_bounds__(kThreads) void vr_cell_bmask_kernel(VolView vv, Cel
                 const int x1 = min(x0 + (1 << sx), vv.w) - 1, y1 = min(y0 + (1 << sy), vv.h) - 1;
                 const int z1 = min(z0 + (1 << sz), vv.d) - 1;
                 bool all = true;
-                for (int cz = z0 >> g.shift; cz <= (z1 >> g.shift); ++cz)
-                    for (int cy = y0 >> g.shift; cy <= (y1 >> g.shift); ++cy)
-                        for (int cx = x0 >> g.shift; cx <= (x1 >> g.shift); ++cx) {
-                            const uint32_t idx = ((uint32_t)cz * (uint32_t)g.cy + (uint32_t)cy) * (uint32_t)g.cx + (uint32_t)cx;
+                for (int cz = z0 >> g.eshift; cz <= (z1 >> g.eshift); ++cz)
+                    for (int cy = y0 >> g.eshift; cy <= (y1 >> g.eshift); ++cy)
+                        for (int cx = x0 >> g.eshift; cx <= (x1 >> g.eshift); ++cx) {
+                            const uint32_t idx = ((uint32_t)cz * (uint32_t)g.ecy + (uint32_t)cy) * (uint32_t)g.ecx + (uint32_t)cx;
                             all = all && ((g.empty[idx >> 5] >> (idx & 31u)) & 1u);
                         }
                 if (all) word |= 1ull << (i + 4 * j + 16 * k);
@@ -264,6 +285,14 @@ __global__ __launch_bounds__(kThreads) void vr_cell_bmask_kernel(VolView vv, Cel
 }
 
 } // namespace
+
+hipError_t vr_launch_cell_reduce(const float2 *fine, const CellView &grid, float2 *coarse, hipStream_t stream)
+{
+    const size_t n = (size_t)grid.cx * grid.cy * grid.cz;
+    hipLaunchKernelGGL(vr_cell_reduce_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                       stream, fine, grid, coarse);
+    return hipGetLastError();
+}
 
 hipError_t vr_launch_cell_bmask(const VolView &vol, const CellView &grid, int bw, int bh, int bd,
                                 unsigned long long *bmask, hipStream_t stream)

@@ -173,11 +173,18 @@ constexpr uint32_t kControlWords = 4 + 2 * kSortBins;   // queue head, cont coun
 //    exactly nothing (volumeraycast.cl:864-879 with alpha == 0), so runs of them are stepped over
 //    with the reference's own t sequence and without touching the volume.
 // Neither changes any pixel: both only skip work whose result is known.
+// The two live on grids of their own: the bounds on cells of 2^shift voxels (8 up to 2048^3: the path
+// tracer's table stays cache-sized), the empty bits on cells of 2^eshift voxels (4 up to 2048^3:
+// fewer fetches at the rims of a structure that can only return opacity 0).  A coarse cell's extent
+// is the union of the extents of the fine cells inside it, so the coarse (min, max) are reduced
+// from the fine ones where both exist.
 struct CellView {
     const float *bound;     // cx * cy * cz floats, x fastest; nullptr = feature off
-    const uint32_t *empty;  // 1 bit per cell, same order; nullptr = feature off
+    const uint32_t *empty;  // 1 bit per cell of the ecx * ecy * ecz grid, x fastest; nullptr = feature off
     int cx, cy, cz;
     int shift;
+    int ecx, ecy, ecz;
+    int eshift;
     // The empty bits once more, per ESS brick (the march kernel keeps the words of the bricks a ray
     // is in in registers): brick (bx, by, bz) of the bw x bh x bd brick grid, x fastest, is cut into
     // 4 x 4 x 4 sub-blocks of (edge / 4) voxels; bit i + 4 j + 16 k of its word is set when every
@@ -227,6 +234,8 @@ hipError_t vr_launch_cell_minmax(const VolView &vol, int format, const CellView 
 hipError_t vr_launch_cell_bounds(const float2 *minmax, const CellView &grid, float inv_max,
                                  const TfView &tf, float *sparse_scratch, float *bound,
                                  uint32_t *empty_bits, hipStream_t stream);
+// (min, max) of the coarse grid `grid` (cx.., shift) from those of the fine one (ecx.., eshift < shift)
+hipError_t vr_launch_cell_reduce(const float2 *fine, const CellView &grid, float2 *coarse, hipStream_t stream);
 // CellView::bmask from CellView::empty for the bw x bh x bd brick grid (grid.bex.. set)
 hipError_t vr_launch_cell_bmask(const VolView &vol, const CellView &grid, int bw, int bh, int bd,
                                 unsigned long long *bmask, hipStream_t stream);

@@ -45,6 +45,11 @@ __device__ unsigned long long g_march_stats[32];   // [0, 16) march kernel, [16,
 #else
 #define VR_MS(i, v)
 #endif
+#ifdef VR_ISA_MARKS   // diagnostic: comments in the -S output that delimit the stages (tools/isa_marks.py)
+#define VR_MARK(x) asm volatile("; VRMARK " x ::: "memory")
+#else
+#define VR_MARK(x)
+#endif
 
 // Occupancy experiments: -DVR_WAVES_PER_EU=N asks the compiler to fit N waves per SIMD
 #ifdef VR_WAVES_PER_EU
@@ -277,6 +282,7 @@ VR_DEV void eval_batch(const V &vol, const float4 *s_tff, int tffn, float *s_sta
                        float (&p1)[kBatch], float (&p2)[kBatch], float (&op)[kBatch],
                        bool (&shaded)[kBatch])
 {
+    VR_MARK("E_pos");
     f3 pk[kBatch];
     float dens[kBatch];
 #pragma unroll
@@ -285,6 +291,7 @@ VR_DEV void eval_batch(const V &vol, const float4 *s_tff, int tffn, float *s_sta
         pk[k] = mk3(pos.x * 0.5f + 0.5f, pos.y * 0.5f + 0.5f, pos.z * 0.5f + 0.5f);
         dens[k] = 0.f;
     }
+    VR_MARK("E_fetch");
     if (XS && rp.illumType == 4) {
         // handled below
     } else if (rp.useLinear) {
@@ -302,6 +309,7 @@ VR_DEV void eval_batch(const V &vol, const float4 *s_tff, int tffn, float *s_sta
         for (int k = 0; k < kBatch; ++k)
             dens[k] = (INSTR != 2 || vk[k]) ? vol.gradient_len(pk[k].x, pk[k].y, pk[k].z) : 0.f;
     }
+    VR_MARK("E_tf");
     float4 tfc[kBatch];
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) tfc[k] = tff_linear(s_tff, tffn, dens[k]);
@@ -324,6 +332,7 @@ VR_DEV void eval_batch(const V &vol, const float4 *s_tff, int tffn, float *s_sta
         }
     }
 
+    VR_MARK("E_slots");
     // ---- which samples need the expensive part, and their slots
     const bool shade_mode = XS ? (rp.illumType != 0 && rp.illumType != 4) : rp.illumType == 1;   // :809
     const bool want_grad = shade_mode || (rcp.contours && !rp.illumType);
@@ -350,6 +359,7 @@ VR_DEV void eval_batch(const V &vol, const float4 *s_tff, int tffn, float *s_sta
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) { ndl[k] = 0.f; spc[k] = 0.f; cnt[k] = 0.f; op[k] = 0.f; }
 
+    VR_MARK("E_stage");
     if (n_slots) {   // wave-uniform
 #pragma unroll
         for (int k = 0; k < kBatch; ++k) {
@@ -367,6 +377,7 @@ VR_DEV void eval_batch(const V &vol, const float4 *s_tff, int tffn, float *s_sta
         const uint32_t n_act = (uint32_t)__builtin_popcountll(act);
         const uint32_t arank = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32),
                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+    VR_MARK("E_dense");
         for (uint32_t base = 0; base < n_slots; base += n_act) {
             const uint32_t sidx = base + arank;
             const bool mine = sidx < n_slots;
@@ -412,6 +423,7 @@ VR_DEV void eval_batch(const V &vol, const float4 *s_tff, int tffn, float *s_sta
                 q[0] = o_ndl; q[1] = o_sp; q[2] = o_cnt; q[3] = o_op;
             }
         }
+    VR_MARK("E_readback");
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -423,6 +435,7 @@ VR_DEV void eval_batch(const V &vol, const float4 *s_tff, int tffn, float *s_sta
         }
     }
 
+    VR_MARK("E_combine");
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
         if (lit[k] && shade_mode && !(XS && rp.illumType == 5)) {
@@ -475,10 +488,10 @@ VR_DEV uint32_t empty_mask(const CellView &cv, const V &vol, const RayCtx &c, fl
 #pragma unroll
     for (int k = 0; k < kLook; ++k) {
         const float fk = (float)k;
-        const int x = iclamp((int)floorf(__builtin_fmaf(fk, du, u0)), 0, vol.w1) >> cv.shift;
-        const int y = iclamp((int)floorf(__builtin_fmaf(fk, dv, v0)), 0, vol.h1) >> cv.shift;
-        const int z = iclamp((int)floorf(__builtin_fmaf(fk, ds, s0)), 0, vol.d1) >> cv.shift;
-        const uint32_t idx = ((uint32_t)z * (uint32_t)cv.cy + (uint32_t)y) * (uint32_t)cv.cx + (uint32_t)x;
+        const int x = iclamp((int)floorf(__builtin_fmaf(fk, du, u0)), 0, vol.w1) >> cv.eshift;
+        const int y = iclamp((int)floorf(__builtin_fmaf(fk, dv, v0)), 0, vol.h1) >> cv.eshift;
+        const int z = iclamp((int)floorf(__builtin_fmaf(fk, ds, s0)), 0, vol.d1) >> cv.eshift;
+        const uint32_t idx = ((uint32_t)z * (uint32_t)cv.ecy + (uint32_t)y) * (uint32_t)cv.ecx + (uint32_t)x;
         w[k] = cv.empty[idx >> 5];
         sh[k] = idx & 31u;
     }
@@ -1056,7 +1069,11 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
     const uint32_t *sb = SKIP_LDS ? s_skip : skip.bits;
     const bool skip_empty = cells.empty != nullptr && rp.useLinear != 0;
     // (opt-in, VRHIP_MARCH_MICRO = leap steps per round: measured no faster than the lookahead below)
+#ifdef VR_NO_LEAP_STEPPING
+    const bool use_mask = false;
+#else
     const bool use_mask = skip_empty && cells.bmask != nullptr && fr.march_micro != 0;
+#endif
     const uint32_t leap_iters = fr.march_micro;
     const uint32_t budget = fr.round_budget ? fr.round_budget : 0xffffffffu;
     const uint32_t kRefillLanes = (fr.refill_min ? fr.refill_min : 16u) * 4u;   // idle lanes before a refill
@@ -1076,6 +1093,7 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
     setup_ray<true>(0u, 0u, false, fr, cam, rp, rc, resf, voxLen, grid, c, d, rp.seed);   // S_DONE
 
     for (;;) {
+        VR_MARK("R_top");
         {
             const bool idle = d.state == S_DONE;
             const unsigned long long idle_m = __ballot(idle);
@@ -1122,6 +1140,7 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
                 }
             }
         }
+        VR_MARK("R_dda");
         // ---- one round (the patch kernel's)
         VR_MS(0, 1);                                                           // rounds
         VR_MS(1, __builtin_popcountll(__ballot(d.state != S_DONE)));           // live lanes, summed over rounds
@@ -1133,6 +1152,7 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
             dda_step<0>(sb, grid, c, d, n0, n1);
         }
         if (!__ballot(d.state != S_DONE)) continue;
+        VR_MARK("R_susp");
         // a ray that has used its rounds goes to the continuation buffer (phase 2)
         {
             const bool susp = d.state != S_DONE && my_rounds >= budget;
@@ -1159,6 +1179,7 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
                 if (!__ballot(d.state != S_DONE)) continue;
             }
         }
+        VR_MARK("R_look");
         if (__ballot(d.state == S_SAMPLE)) my_rounds += d.state == S_SAMPLE ? 1u : 0u;
         bool more_empty = false;
         if (use_mask) {
@@ -1186,6 +1207,7 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
                 after_segment<true>(c, d);
             }
         }
+        VR_MARK("R_batch");
         if (__ballot(d.state == S_SAMPLE && !more_empty)) {
             VR_MS(6, 1);                                                       // evaluation batches
             VR_MS(7, __builtin_popcountll(__ballot(d.state == S_SAMPLE && !more_empty)));   // lanes in them
@@ -1206,6 +1228,7 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
 #endif
             eval_batch<VT, 0, false, FP>(vol, s_tff, tffn, s_stage, c, rp, rc, refInterval, tk, vk, p0, p1, p2,
                                          opk, litk);
+        VR_MARK("R_comp");
 #pragma unroll
             for (int k = 0; k < kBatch; ++k)
                 if (vk[k] && d.state == S_SAMPLE) composite(c, d, p0[k], p1[k], p2[k], opk[k], tk[k]);
@@ -1254,11 +1277,6 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
 // Rays come from the pre-pass's list with the DDA state reached there; a lane takes the next ray
 // when 4 * refill_min lanes of its wave are idle.  Exit condition reached by every wave: the list
 // head only grows and every ray ends.
-#ifdef VR_ISA_MARKS   // diagnostic: comments in the -S output that delimit the stages (tools/isa_marks.py)
-#define VR_MARK(x) asm volatile("; VRMARK " x ::: "memory")
-#else
-#define VR_MARK(x)
-#endif
 #ifndef VR_MARCH_Q
 #define VR_MARCH_Q 4
 #endif
@@ -1996,7 +2014,11 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
     const bool skip_empty = INSTR != 2 && cells.empty != nullptr && rp.useLinear != 0 &&
                             !(XS && rp.illumType == 4);
     // (opt-in, VRHIP_MARCH_MICRO = leap steps per round: measured no faster than the lookahead below)
+#ifdef VR_NO_LEAP_STEPPING
+    const bool use_mask = false;
+#else
     const bool use_mask = skip_empty && cells.bmask != nullptr && fr.march_micro != 0;
+#endif
     const uint32_t leap_iters = fr.march_micro;
     LeapCache lc;
     lc.key0 = lc.key1 = 0xffffffffu; lc.m0 = lc.m1 = 0ull; lc.du = lc.dv = lc.ds = lc.inv_step = 0.f;

@@ -22,6 +22,8 @@ struct VolumeSlot {
     bool bricks_built = false;   // `bricks` holds the (min,max) of the voxels now in `dev`
     float2 *pt_minmax = nullptr;   // path tracer: per-cell (min,max) incl. halo, built on demand
     bool pt_minmax_valid = false;
+    float2 *fine_minmax = nullptr; // ray caster: the same on the finer grid of the empty bits
+    bool fine_minmax_valid = false;
     bool borrowed = false;    // dev / chan / bricks belong to another renderer (vrhip_share_volumes)
 };
 
@@ -68,13 +70,14 @@ struct vrhip_renderer {
 
     // cell grid of the current timestep + TF (CellView, vr_internal.h): opacity bound for the
     // path tracer, empty bits for the ray caster
-    CellView cells = {nullptr, nullptr, 0, 0, 0, 3, nullptr, 0, 0, 0};
+    CellView cells = {nullptr, nullptr, 0, 0, 0, 3, 0, 0, 0, 3, nullptr, 0, 0, 0};
     unsigned long long *cell_bmask = nullptr;   // CellView::bmask (per ESS brick)
     size_t bmask_cap = 0;
     float *cell_bound = nullptr;
     uint32_t *cell_empty = nullptr;
     float *cell_sparse = nullptr;  // 13 x 4096 floats of scratch for the TF range-max table
-    size_t cell_cap = 0;
+    size_t cell_cap = 0, empty_cap = 0;
+    bool cells_have_bound = false, cells_have_empty = false;   // r->cells' tables match volume, time step and TF
     bool pt_dirty = true;          // cells out of date (volume, timestep or TF changed)
     bool pt_cull = true;           // VRHIP_PT_NO_CULL=1 disables the path tracer's culling
     bool skip_empty = true;        // VRHIP_NO_EMPTY_SKIP=1 disables the ray caster's empty runs
@@ -299,15 +302,31 @@ TfView make_tf_view(const vrhip_renderer *r)
     return t;
 }
 
-// Does the ray caster step over empty cells (CellView::empty)?  The cells are 8 voxels wide; where the
-// ESS bricks are not much larger the brick skipping has done the work already and the lookahead only
-// costs: measured on MI355X +6 % frame time at 1024^3 (bricks of 16) and 256^3 (bricks of 4), -25 % at
-// 2048^3 (bricks of 32).  Without ESS bricks the cells are all there is.
+// log2 of the cell edges of the two cell grids (CellView): opacity bounds on at most 256 cells per axis,
+// empty bits on at most 512 (edges 8 and 4 up to 2048^3)
+void cell_shifts(const vrhip_renderer *r, int *shift, int *eshift)
+{
+    const uint32_t mres = std::max(r->res[0], std::max(r->res[1], r->res[2]));
+    int sh = 3, es = 2;
+    while (((mres + (1u << sh) - 1) >> sh) > 256u) ++sh;
+    if (const char *e = getenv("VRHIP_CELL_SHIFT")) es = std::max(2, std::min(5, atoi(e)));   // A/B: 3 = one grid
+    while (((mres + (1u << es) - 1) >> es) > 512u) ++es;
+    *shift = sh;
+    *eshift = std::min(es, sh);
+}
+
+// Does the ray caster step over empty cells (CellView::empty)?  Where the ESS bricks are not much
+// larger than the cells the brick skipping has done the work already and the lookahead only costs.
+// Measured on MI355X with cells of 4 voxels: -13 % frame time at 1024^3 (bricks of 16), -30 % at 2048^3
+// (bricks of 32), +3 % at 256^3 (bricks of 4); with cells of 8 (round 1): +6 % at 1024^3 and 256^3,
+// -25 % at 2048^3.  So: bricks of at least four cells.  Without ESS bricks the cells are all there is.
 bool ray_skip_empty(const vrhip_renderer *r)
 {
     if (!r->skip_empty || r->channels > 1) return false;
     if (r->skip_empty_force || !r->use_ess || !r->bricks_valid) return true;
-    return std::max(r->brick_edge[0], std::max(r->brick_edge[1], r->brick_edge[2])) >= 32u;
+    int shift, eshift;
+    cell_shifts(r, &shift, &eshift);
+    return std::max(r->brick_edge[0], std::max(r->brick_edge[1], r->brick_edge[2])) >= (4u << eshift);
 }
 
 int set_device(const vrhip_renderer *r)
@@ -350,6 +369,7 @@ int prepare_slot(vrhip_renderer *r, const uint32_t res[3], int format, uint32_t 
     r->pt_dirty = true;
     r->fp_valid = false;
     s.pt_minmax_valid = false;
+    s.fine_minmax_valid = false;
     *slot = &s;
     return VRHIP_OK;
 }
@@ -513,85 +533,133 @@ int ensure_skipmap(vrhip_renderer *r)
     return VRHIP_OK;
 }
 
-// (Re)build the cell grid when the volume, the timestep or the TF changed.  Cells of 2^shift
-// voxels per axis, at most 256 per axis (shift 3 up to 2048^3: 2 MiB of empty bits).
-int ensure_cells(vrhip_renderer *r)
+// The (min, max) of one cell grid of the current time step (geometry: g.cx.., g.shift), built with the
+// separable streaming kernels where they apply.
+static int build_cell_minmax(vrhip_renderer *r, VolumeSlot &s, const CellView &g, float2 *out)
 {
-    if (!r->pt_dirty && r->cell_bound) return VRHIP_OK;
+    // scratch for the separable build (one (min, max) per cell column and voxel slice), held only
+    // while it runs
+    float2 *records = nullptr;
+    const size_t n_rec = (size_t)g.cx * g.cy * r->res[2];
+    if (g.shift <= 4 && r->nb[0] <= 1600u && !getenv("VRHIP_CELLS_PER_WAVE") &&
+        hipMalloc((void **)&records, n_rec * sizeof(float2)) != hipSuccess) {
+        (void)hipGetLastError();
+        records = nullptr;
+    }
+    hipError_t e = vr_launch_cell_minmax(make_vol_view(r, s.dev), r->format, g, out, r->stream, records);
+    if (records) {
+        if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
+        (void)hipFree(records);
+    }
+    VR_HIP(r, e);
+    return VRHIP_OK;
+}
+
+// (Re)build what the coming frame needs of the cell grids when the volume, the timestep or the TF
+// changed: the opacity bounds (path tracer; cells of 2^shift voxels, at most 256 per axis: shift 3
+// up to 2048^3) and / or the empty bits (ray caster; cells of 2^eshift voxels, at most 512 per axis:
+// shift 2 up to 2048^3, 16 MiB of bits).
+int ensure_cells(vrhip_renderer *r, bool need_bound, bool need_empty)
+{
+    if (r->pt_dirty) {
+        r->cells_have_bound = r->cells_have_empty = false;
+        r->pt_dirty = false;
+    }
+    if ((!need_bound || r->cells_have_bound) && (!need_empty || r->cells_have_empty)) return VRHIP_OK;
     VolumeSlot &s = r->vols[r->timestep];
-    uint32_t mres = std::max(r->res[0], std::max(r->res[1], r->res[2]));
-    int shift = 3;
-    while (((mres + (1u << shift) - 1) >> shift) > 256u) ++shift;
-    CellView g;
+    int shift, eshift;
+    cell_shifts(r, &shift, &eshift);
+    CellView g = r->cells;
     g.shift = shift;
     g.cx = (int)((r->res[0] + (1u << shift) - 1) >> shift);
     g.cy = (int)((r->res[1] + (1u << shift) - 1) >> shift);
     g.cz = (int)((r->res[2] + (1u << shift) - 1) >> shift);
-    const size_t n_cells = (size_t)g.cx * g.cy * g.cz;
-    if (n_cells > r->cell_cap) {
-        VR_HIP(r, hipStreamSynchronize(r->stream));
-        if (r->cell_bound) VR_HIP(r, hipFree(r->cell_bound));
-        if (r->cell_empty) VR_HIP(r, hipFree(r->cell_empty));
-        r->cell_bound = nullptr;
-        r->cell_empty = nullptr;
-        r->cell_cap = 0;
-        VR_HIP(r, hipMalloc((void **)&r->cell_bound, n_cells * sizeof(float)));
-        VR_HIP(r, hipMalloc((void **)&r->cell_empty, ((n_cells + 31) / 32) * sizeof(uint32_t)));
-        r->cell_cap = n_cells;
-    }
+    g.eshift = eshift;
+    g.ecx = (int)((r->res[0] + (1u << eshift) - 1) >> eshift);
+    g.ecy = (int)((r->res[1] + (1u << eshift) - 1) >> eshift);
+    g.ecz = (int)((r->res[2] + (1u << eshift) - 1) >> eshift);
+    const size_t n_cells = (size_t)g.cx * g.cy * g.cz, n_fine = (size_t)g.ecx * g.ecy * g.ecz;
+    CellView fine = g;   // the fine grid's geometry for the kernels that take one grid
+    fine.shift = eshift; fine.cx = g.ecx; fine.cy = g.ecy; fine.cz = g.ecz;
     if (!r->cell_sparse) VR_HIP(r, hipMalloc((void **)&r->cell_sparse, 13 * 4096 * sizeof(float)));
-    if (!s.pt_minmax) VR_HIP(r, hipMalloc((void **)&s.pt_minmax, n_cells * sizeof(float2)));
-    if (!s.pt_minmax_valid) {
-        // scratch for the separable streaming build (one (min, max) per cell column and voxel slice),
-        // held only while it runs
-        float2 *records = nullptr;
-        const size_t n_rec = (size_t)g.cx * g.cy * r->res[2];
-        if (shift <= 4 && r->nb[0] <= 1600u && !getenv("VRHIP_CELLS_PER_WAVE") &&
-            hipMalloc((void **)&records, n_rec * sizeof(float2)) != hipSuccess) {
-            (void)hipGetLastError();
-            records = nullptr;
+
+    // ---- (min, max) per cell: a property of the voxels, kept per time step
+    const bool one_grid = eshift == shift;
+    if (need_empty && !one_grid && !s.fine_minmax_valid) {
+        if (!s.fine_minmax) VR_HIP(r, hipMalloc((void **)&s.fine_minmax, n_fine * sizeof(float2)));
+        int rc = build_cell_minmax(r, s, fine, s.fine_minmax);
+        if (rc) return rc;
+        s.fine_minmax_valid = true;
+    }
+    if ((need_bound || one_grid) && !s.pt_minmax_valid) {
+        if (!s.pt_minmax) VR_HIP(r, hipMalloc((void **)&s.pt_minmax, n_cells * sizeof(float2)));
+        if (s.fine_minmax_valid) {
+            VR_HIP(r, vr_launch_cell_reduce(s.fine_minmax, g, s.pt_minmax, r->stream));
+        } else {
+            int rc = build_cell_minmax(r, s, g, s.pt_minmax);
+            if (rc) return rc;
         }
-        hipError_t e = vr_launch_cell_minmax(make_vol_view(r, s.dev), r->format, g, s.pt_minmax, r->stream, records);
-        if (records) {
-            if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
-            (void)hipFree(records);
-        }
-        VR_HIP(r, e);
         s.pt_minmax_valid = true;
     }
-    VR_HIP(r, vr_launch_cell_bounds(s.pt_minmax, g, inv_max_of(r->format), make_tf_view(r),
-                                    r->cell_sparse, r->cell_bound, r->cell_empty, r->stream));
-    g.bound = r->cell_bound;
-    g.empty = r->cell_empty;
-    // the empty bits per ESS brick, for the march kernel (ESS bricks of >= 4 voxels per axis)
-    g.bmask = nullptr;
-    g.bex = g.bey = g.bez = 0;
-    if (r->bricks_valid) {
-        int lg[3];
-        bool ok = true;
-        for (int i = 0; i < 3; ++i) {
-            lg[i] = 0;
-            while ((1u << lg[i]) < r->brick_edge[i]) ++lg[i];
-            ok = ok && lg[i] >= 2 && r->brick_tex[i] <= 256u;
+
+    // ---- with the transfer function: bounds, empty bits
+    if (need_bound && !r->cells_have_bound) {
+        if (n_cells > r->cell_cap) {
+            VR_HIP(r, hipStreamSynchronize(r->stream));
+            if (r->cell_bound) VR_HIP(r, hipFree(r->cell_bound));
+            r->cell_bound = nullptr;
+            r->cell_cap = 0;
+            VR_HIP(r, hipMalloc((void **)&r->cell_bound, n_cells * sizeof(float)));
+            r->cell_cap = n_cells;
         }
-        if (ok) {
-            const size_t nb = (size_t)r->brick_tex[0] * r->brick_tex[1] * r->brick_tex[2];
-            if (nb > r->bmask_cap) {
-                VR_HIP(r, hipStreamSynchronize(r->stream));
-                if (r->cell_bmask) VR_HIP(r, hipFree(r->cell_bmask));
-                r->cell_bmask = nullptr;
-                r->bmask_cap = 0;
-                VR_HIP(r, hipMalloc((void **)&r->cell_bmask, nb * sizeof(unsigned long long)));
-                r->bmask_cap = nb;
+        VR_HIP(r, vr_launch_cell_bounds(s.pt_minmax, g, inv_max_of(r->format), make_tf_view(r),
+                                        r->cell_sparse, r->cell_bound, nullptr, r->stream));
+        r->cells_have_bound = true;
+    }
+    g.bound = r->cells_have_bound ? r->cell_bound : nullptr;
+    if (need_empty && !r->cells_have_empty) {
+        if (n_fine > r->empty_cap) {
+            VR_HIP(r, hipStreamSynchronize(r->stream));
+            if (r->cell_empty) VR_HIP(r, hipFree(r->cell_empty));
+            r->cell_empty = nullptr;
+            r->empty_cap = 0;
+            VR_HIP(r, hipMalloc((void **)&r->cell_empty, ((n_fine + 63) / 64) * 2 * sizeof(uint32_t)));
+            r->empty_cap = n_fine;
+        }
+        VR_HIP(r, vr_launch_cell_bounds(one_grid ? s.pt_minmax : s.fine_minmax, fine, inv_max_of(r->format),
+                                        make_tf_view(r), r->cell_sparse, nullptr, r->cell_empty, r->stream));
+        r->cells_have_empty = true;
+        g.empty = r->cell_empty;
+        // the empty bits per ESS brick, for the march kernel (ESS bricks of >= 4 voxels per axis)
+        g.bmask = nullptr;
+        g.bex = g.bey = g.bez = 0;
+        if (r->bricks_valid) {
+            int lg[3];
+            bool ok = true;
+            for (int i = 0; i < 3; ++i) {
+                lg[i] = 0;
+                while ((1u << lg[i]) < r->brick_edge[i]) ++lg[i];
+                ok = ok && lg[i] >= 2 && r->brick_tex[i] <= 256u;
             }
-            g.bex = lg[0]; g.bey = lg[1]; g.bez = lg[2];
-            VR_HIP(r, vr_launch_cell_bmask(make_vol_view(r, s.dev), g, (int)r->brick_tex[0], (int)r->brick_tex[1],
-                                           (int)r->brick_tex[2], r->cell_bmask, r->stream));
-            g.bmask = r->cell_bmask;
+            if (ok) {
+                const size_t nb = (size_t)r->brick_tex[0] * r->brick_tex[1] * r->brick_tex[2];
+                if (nb > r->bmask_cap) {
+                    VR_HIP(r, hipStreamSynchronize(r->stream));
+                    if (r->cell_bmask) VR_HIP(r, hipFree(r->cell_bmask));
+                    r->cell_bmask = nullptr;
+                    r->bmask_cap = 0;
+                    VR_HIP(r, hipMalloc((void **)&r->cell_bmask, nb * sizeof(unsigned long long)));
+                    r->bmask_cap = nb;
+                }
+                g.bex = lg[0]; g.bey = lg[1]; g.bez = lg[2];
+                VR_HIP(r, vr_launch_cell_bmask(make_vol_view(r, s.dev), g, (int)r->brick_tex[0], (int)r->brick_tex[1],
+                                               (int)r->brick_tex[2], r->cell_bmask, r->stream));
+                g.bmask = r->cell_bmask;
+            }
         }
     }
+    if (!r->cells_have_empty) { g.empty = nullptr; g.bmask = nullptr; }
     r->cells = g;
-    r->pt_dirty = false;
     return VRHIP_OK;
 }
 
@@ -790,7 +858,7 @@ int prepare_render(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t 
         if (rc) return rc;
     }
     if (r->render.technique == 1 ? r->pt_cull : ray_skip_empty(r)) {
-        rc = ensure_cells(r);
+        rc = ensure_cells(r, r->render.technique == 1, r->render.technique != 1);
         if (rc) return rc;
     }
     return ensure_queue(r, width, height, tile_w, tile_h, tile_ids, n_tiles, n_frames, frame_stride);
@@ -979,8 +1047,8 @@ int vrhip_set_stream(vrhip_renderer *r, void *hip_stream, int use_own)
     return VRHIP_OK;
 }
 
-int vrhip_download_cells(vrhip_renderer *r, float *out_minmax, size_t n_floats, uint32_t dims[3],
-                         uint32_t *shift)
+static int download_cells_impl(vrhip_renderer *r, bool fine, float *out_minmax, size_t n_floats, uint32_t dims[3],
+                               uint32_t *shift)
 {
     if (!r) return VRHIP_ERR_INVALID;
     VR_REQUIRE(r, !r->vols.empty() && r->timestep < r->vols.size() && r->vols[r->timestep].dev,
@@ -988,16 +1056,33 @@ int vrhip_download_cells(vrhip_renderer *r, float *out_minmax, size_t n_floats, 
     VR_REQUIRE(r, r->tff && r->tff_n, VRHIP_ERR_NODATA, "No transfer function set.");
     if (set_device(r)) return VRHIP_ERR_HIP;
     r->pt_dirty = true;
-    int rc = ensure_cells(r);
+    int rc = ensure_cells(r, true, true);
     if (rc) return rc;
-    const size_t n_cells = (size_t)r->cells.cx * r->cells.cy * r->cells.cz;
-    if (dims) { dims[0] = (uint32_t)r->cells.cx; dims[1] = (uint32_t)r->cells.cy; dims[2] = (uint32_t)r->cells.cz; }
-    if (shift) *shift = (uint32_t)r->cells.shift;
+    const CellView &g = r->cells;
+    const bool second = fine && g.eshift != g.shift;
+    const int cx = second ? g.ecx : g.cx, cy = second ? g.ecy : g.cy, cz = second ? g.ecz : g.cz;
+    const size_t n_cells = (size_t)cx * cy * cz;
+    if (dims) { dims[0] = (uint32_t)cx; dims[1] = (uint32_t)cy; dims[2] = (uint32_t)cz; }
+    if (shift) *shift = (uint32_t)(second ? g.eshift : g.shift);
     if (!out_minmax) return VRHIP_OK;
     VR_REQUIRE(r, n_floats == 2 * n_cells, VRHIP_ERR_INVALID, "vrhip_download_cells: size mismatch");
     VR_HIP(r, hipStreamSynchronize(r->stream));
-    VR_HIP(r, hipMemcpy(out_minmax, r->vols[r->timestep].pt_minmax, n_cells * sizeof(float2), hipMemcpyDeviceToHost));
+    const VolumeSlot &s = r->vols[r->timestep];
+    VR_HIP(r, hipMemcpy(out_minmax, second ? s.fine_minmax : s.pt_minmax, n_cells * sizeof(float2),
+                        hipMemcpyDeviceToHost));
     return VRHIP_OK;
+}
+
+int vrhip_download_cells(vrhip_renderer *r, float *out_minmax, size_t n_floats, uint32_t dims[3],
+                         uint32_t *shift)
+{
+    return download_cells_impl(r, false, out_minmax, n_floats, dims, shift);
+}
+
+int vrhip_download_empty_cells(vrhip_renderer *r, float *out_minmax, size_t n_floats, uint32_t dims[3],
+                               uint32_t *shift)
+{
+    return download_cells_impl(r, true, out_minmax, n_floats, dims, shift);
 }
 
 int vrhip_assemble_frame(vrhip_renderer *r, const float *staging_dev, const uint32_t *slot_of_tile_dev,
@@ -1146,6 +1231,7 @@ int vrhip_clear_volumes(vrhip_renderer *r)
             if (s.bricks) (void)hipFree(s.bricks);
         }
         if (s.pt_minmax) (void)hipFree(s.pt_minmax);
+        if (s.fine_minmax) (void)hipFree(s.fine_minmax);
     }
     r->vols.clear();
     r->fp_valid = false;

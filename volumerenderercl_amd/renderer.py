@@ -459,13 +459,14 @@ class VolumeRenderCL:
                                                     out.nbytes))
         return out
 
-    def downloadCells(self):
-        """(min, max) of every cell of the cell grid (vrhip_download_cells): ndarray [cz, cy, cx, 2], shift."""
+    def downloadCells(self, fine=False):
+        """(min, max) of every cell of the cell grid (vrhip_download_cells; fine: the grid of the ray
+        caster's empty bits, vrhip_download_empty_cells): ndarray [cz, cy, cx, 2], shift."""
+        fn = self._lib.vrhip_download_empty_cells if fine else self._lib.vrhip_download_cells
         dims, shift = (C.c_uint32 * 3)(), C.c_uint32()
-        self._check(self._lib.vrhip_download_cells(self._h, None, 0, dims, C.byref(shift)))
+        self._check(fn(self._h, None, 0, dims, C.byref(shift)))
         out = np.empty((dims[2], dims[1], dims[0], 2), dtype=np.float32)
-        self._check(self._lib.vrhip_download_cells(self._h, out.ctypes.data_as(C.c_void_p), out.size, dims,
-                                                   C.byref(shift)))
+        self._check(fn(self._h, out.ctypes.data_as(C.c_void_p), out.size, dims, C.byref(shift)))
         return out, int(shift.value)
 
     def lastBricksSeconds(self):
