@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""tools/cells_time.py -- time the cell-grid build (per-wave kernel vs two-pass streaming build) at 2048^3."""
+"""tools/cells_time.py -- time the build of both cell grids (cells of 4 and of 8 voxels, bounds, empty bits, per-brick
+words) at 2048^3: separable streaming build vs the one-wave-per-cell kernel."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -15,7 +16,8 @@ for mode in ("stream", "wave"):
     vr.setTransferFunction(frontend.tff_from_stops())
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    vr.lib.vrhip_download_cells(vr.handle, None, 0, None, None)
+    rc = vr.lib.vrhip_download_cells(vr.handle, None, 0, None, None)
+    assert rc == 0, vr.lib.vrhip_last_error(vr.handle)
     torch.cuda.synchronize()
     print(mode, "cell grid build incl. bounds + words: %.2f ms (host clock)" % ((time.perf_counter() - t0) * 1e3))
     vr.close()

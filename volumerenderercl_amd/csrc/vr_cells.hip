@@ -2,6 +2,7 @@
 // renderer (CellView, vr_internal.h): the path tracer's opacity bound and the ray caster's
 // empty-cell bitmap.  Nothing here has a counterpart in the reference; both devices leave every
 // pixel unchanged (tests: test_pathtrace_culling_is_exact, test_empty_skipping_is_exact).
+#include <algorithm>
 #include "vr_device_math.h"
 #include "vr_internal.h"
 
@@ -16,11 +17,11 @@ constexpr int kSparseLevels = 13;   // 2^12 = 4096 >= max transfer function entr
 // NaN voxels (FLOAT volumes) mark the cell min > max: never culled, never empty.
 template <typename VT>
 __global__ __launch_bounds__(kThreads) void vr_cell_minmax_kernel(VolView vv, CellView grid,
-                                                                  float2 *out)
+                                                                  float2 *out, size_t cell0)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const size_t n_cells = (size_t)grid.cx * grid.cy * grid.cz;
-    const size_t cell = (size_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    const size_t cell = cell0 + (size_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
     if (cell >= n_cells) return;
     const int cxi = (int)(cell % (size_t)grid.cx);
     const int cyi = (int)((cell / (size_t)grid.cx) % (size_t)grid.cy);
@@ -78,10 +79,18 @@ __global__ __launch_bounds__(kThreads) void vr_cell_minmax_kernel(VolView vv, Ce
 // of its own bricks and L of the brick to its right: the extrema over the x and y ranges of the cell
 // for that voxel slice z.  Pass Z reduces the 2^s + 3 slices of each cell.  Exactly the kernel
 // above's values (NaN voxels give (-inf, +inf): never culled, never empty).
+// (a record of the passes: extrema in the voxel type, mn > mx = nothing yet; FLOAT volumes flag NaN as (-inf, +inf))
+template <typename VT> struct CellRec { VT mn, mx; };
 template <typename VT> struct CellAcc {   // extrema of raw voxel values; integer voxels stay integers until the end
     uint32_t mn = 0xffffffffu, mx = 0u;
     VR_DEV void add(VT v) { mn = min(mn, (uint32_t)v); mx = max(mx, (uint32_t)v); }
-    VR_DEV float2 get() const { return mn > mx ? make_float2(__builtin_inff(), -__builtin_inff()) : make_float2((float)mn, (float)mx); }
+    VR_DEV CellRec<VT> rec() const
+    {
+        CellRec<VT> q;
+        q.mn = mn > mx ? (VT)~(VT)0 : (VT)mn;
+        q.mx = mn > mx ? (VT)0 : (VT)mx;
+        return q;
+    }
 };
 template <> struct CellAcc<float> {
     float mn = __builtin_inff(), mx = -__builtin_inff();
@@ -91,92 +100,204 @@ template <> struct CellAcc<float> {
         mn = f < mn ? f : mn;
         mx = f > mx ? f : mx;
     }
-    VR_DEV float2 get() const { return make_float2(mn, mx); }
+    VR_DEV CellRec<float> rec() const { return CellRec<float>{mn, mx}; }
 };
-struct CellMerge {
+template <typename VT> struct CellMerge {
+    CellRec<VT> a;
+    bool any = false;
+    VR_DEV void merge(CellRec<VT> q)
+    {
+        if (q.mn > q.mx) return;              // nothing in q
+        if (!any) { a = q; any = true; return; }
+        a.mn = q.mn < a.mn ? q.mn : a.mn;
+        a.mx = q.mx > a.mx ? q.mx : a.mx;
+    }
+    VR_DEV CellRec<VT> rec() const
+    {
+        if (any) return a;
+        CellRec<VT> e;
+        e.mn = (VT)1; e.mx = (VT)0;
+        return e;
+    }
+};
+template <> struct CellMerge<float> {   // (-inf, +inf) of a NaN survives min / max; (+inf, -inf) is neutral
     float mn = __builtin_inff(), mx = -__builtin_inff();
-    VR_DEV void merge(float2 q) { mn = q.x < mn ? q.x : mn; mx = q.y > mx ? q.y : mx; }
+    VR_DEV void merge(CellRec<float> q) { mn = q.mn < mn ? q.mn : mn; mx = q.mx > mx ? q.mx : mx; }
+    VR_DEV CellRec<float> rec() const { return CellRec<float>{mn, mx}; }
 };
 
-template <typename VT>
-__global__ __launch_bounds__(kThreads) void vr_cell_xy_kernel(VolView vv, CellView grid, float2 *xy /* [d][cy][cx] */)
+// Per-column extrema of some voxel rows of one z slice of a micro-brick (4 columns x 4 rows, the
+// 16 * sizeof(VT) bytes a lane loads).  The columns stay apart until the end, where the x classes are
+// formed from the columns that lie inside the volume (padding columns never enter a class).
+template <typename VT> struct CellCols {
+    CellAcc<VT> c[4];
+    VR_DEV void add_row(const VT *r) { c[0].add(r[0]); c[1].add(r[1]); c[2].add(r[2]); c[3].add(r[3]); }
+    VR_DEV void merge(const CellCols &o)
+    {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            c[i].mn = o.c[i].mn < c[i].mn ? o.c[i].mn : c[i].mn;
+            c[i].mx = o.c[i].mx > c[i].mx ? o.c[i].mx : c[i].mx;
+        }
+    }
+    // x class k (A: all columns, L: 0 and 1, H: 3) over the first `ncols` columns
+    VR_DEV CellRec<VT> rec(int k, int ncols) const
+    {
+        CellAcc<VT> a;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool in = i < ncols && (k == 0 || (k == 1 && i < 2) || (k == 2 && i == 3));
+            if (in) { a.mn = c[i].mn < a.mn ? c[i].mn : a.mn; a.mx = c[i].mx > a.mx ? c[i].mx : a.mx; }
+        }
+        return a.rec();
+    }
+};
+// UCHAR: the columns as 16-bit lanes of two registers (columns 0|2 and 1|3), packed min / max
+template <> struct CellCols<uint8_t> {
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    us2 mnA = us2{0x00ff, 0x00ff}, mnB = us2{0x00ff, 0x00ff}, mxA = us2{0, 0}, mxB = us2{0, 0};
+    static VR_DEV us2 lanes(uint32_t x) { us2 r; __builtin_memcpy(&r, &x, 4); return r; }
+    VR_DEV void add_row(const uint8_t *r)
+    {
+        uint32_t wd;
+        __builtin_memcpy(&wd, r, 4);
+        const us2 e = lanes(wd & 0x00ff00ffu), o = lanes((wd >> 8) & 0x00ff00ffu);
+        mnA = __builtin_elementwise_min(mnA, e); mxA = __builtin_elementwise_max(mxA, e);
+        mnB = __builtin_elementwise_min(mnB, o); mxB = __builtin_elementwise_max(mxB, o);
+    }
+    VR_DEV void merge(const CellCols &o)
+    {
+        mnA = __builtin_elementwise_min(mnA, o.mnA); mxA = __builtin_elementwise_max(mxA, o.mxA);
+        mnB = __builtin_elementwise_min(mnB, o.mnB); mxB = __builtin_elementwise_max(mxB, o.mxB);
+    }
+    VR_DEV CellRec<uint8_t> rec(int k, int ncols) const
+    {
+        const unsigned short mn[4] = {mnA.x, mnB.x, mnA.y, mnB.y}, mx[4] = {mxA.x, mxB.x, mxA.y, mxB.y};
+        unsigned short lo = 0x00ff, hi = 0;   // nothing: (255, 0)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool in = i < ncols && (k == 0 || (k == 1 && i < 2) || (k == 2 && i == 3));
+            if (in) { lo = min(lo, mn[i]); hi = max(hi, mx[i]); }
+        }
+        CellRec<uint8_t> q;
+        q.mn = (uint8_t)lo; q.mx = (uint8_t)hi;
+        return q;
+    }
+};
+
+// R rows of cells of 2^S voxels per workgroup: the R * E + 3 voxel rows they cover between them are read
+// once (R * E / 4 + 2 micro-brick rows).  A lane takes one z slice of a micro-brick column -- 16 *
+// sizeof(VT) contiguous bytes per micro-brick, a wave's loads cover whole lines -- and reduces each
+// slice to three y classes of its four voxel rows, like the x classes: A all four, L rows 0 and 1 (what
+// the row of cells below takes from this micro-brick row), H row 3 (what the one above takes).  Which
+// class of which micro-brick row goes to which row of cells is known at compile time; only rows beyond
+// the volume's height (padding of the last micro-brick row) are tested for.
+template <typename VT, int R, int S>
+__global__ __launch_bounds__(kThreads) void vr_cell_xy_kernel(VolView vv, CellView grid, CellRec<VT> *xy /* [d][cy][cx] */)
 {
-    extern __shared__ float2 s_cls[];   // [nbx][4 z slices][3 classes]
-    const int cyi = blockIdx.x % grid.cy, mz = blockIdx.x / grid.cy;
-    const int s = grid.shift, E = 1 << s, bpc = E >> 2;
+    extern __shared__ unsigned char s_raw[];
+    CellRec<VT> *s_cls = reinterpret_cast<CellRec<VT> *>(s_raw);   // [R][nbx][4 z slices][3 classes]
+    constexpr int BPC = (1 << S) / 4;        // micro-brick rows per row of cells
+    constexpr int NMY = R * BPC + 2;         // micro-brick rows a workgroup reads
+    constexpr int N16 = (int)sizeof(VT);     // 16-byte loads per slice
+    constexpr int kPre = sizeof(VT) == 1 ? 6 : sizeof(VT) == 2 ? 4 : 2;   // slices in flight per lane
+    const int nrb = (grid.cy + R - 1) / R;
+    const int cy0 = ((int)blockIdx.x % nrb) * R, mz = (int)blockIdx.x / nrb;
+    const int nrows = min(R, grid.cy - cy0);
     const VT *base = (const VT *)vv.data;
-    const int y_a = max((cyi << s) - 1, 0), y_b = min(((cyi + 1) << s) + 1, vv.h - 1);   // halo'd rows, clipped
-    constexpr int N16 = 64 * (int)sizeof(VT) / 16;
-    for (int mx = threadIdx.x; mx < (int)vv.nbx; mx += kThreads) {
-        CellAcc<VT> acc[4][3];
-        for (int my = y_a >> 2; my <= (y_b >> 2); ++my) {
-            const uint4 *p = reinterpret_cast<const uint4 *>(base + (unsigned long long)mz * vv.zstride +
-                                                             (unsigned long long)my * vv.ystride +
-                                                             (unsigned long long)mx * 64ull);
-            uint4 q[N16];
+    const int my_first = cy0 * BPC - 1, my_last = (vv.h - 1) >> 2;
+    for (int t = threadIdx.x; t < (int)vv.nbx * 4; t += kThreads) {
+        const int mx = t >> 2, dz = t & 3;
+        CellCols<VT> acc[R];
+        const VT *col = base + (unsigned long long)mz * vv.zstride + (unsigned long long)mx * 64ull +
+                        (unsigned long long)dz * 16ull;
 #pragma unroll
-            for (int i = 0; i < N16; ++i) q[i] = p[i];
-            VT v[64];
-            __builtin_memcpy(v, q, sizeof v);
+        for (int j0 = 0; j0 < NMY; j0 += kPre) {
+            uint4 q[kPre][N16];
 #pragma unroll
-            for (int dy = 0; dy < 4; ++dy) {
-                const int y = 4 * my + dy;
-                if (y < y_a || y > y_b) continue;   // (uniform over the workgroup)
+            for (int jj = 0; jj < kPre; ++jj) {
+                if (j0 + jj >= NMY) continue;
+                const int my = min(max(my_first + j0 + jj, 0), my_last);   // (rows outside are loaded and not used)
+                const uint4 *p = reinterpret_cast<const uint4 *>(col + (unsigned long long)my * vv.ystride);
 #pragma unroll
-                for (int dz = 0; dz < 4; ++dz) {
-                    const VT *r = v + dz * 16 + dy * 4;
-                    // columns beyond the volume's width hold padding: never part of a class
-                    const int xs = 4 * mx;
-                    if (xs + 3 < vv.w) {
-                        acc[dz][0].add(r[0]); acc[dz][0].add(r[1]); acc[dz][0].add(r[2]); acc[dz][0].add(r[3]);
-                        acc[dz][1].add(r[0]); acc[dz][1].add(r[1]);
-                        acc[dz][2].add(r[3]);
-                    } else {
-                        for (int dx = 0; dx < 4; ++dx)
-                            if (xs + dx < vv.w) {
-                                acc[dz][0].add(r[dx]);
-                                if (dx < 2) acc[dz][1].add(r[dx]);
-                                if (dx == 3) acc[dz][2].add(r[dx]);
-                            }
-                    }
+                for (int i = 0; i < N16; ++i) q[jj][i] = p[i];
+            }
+#pragma unroll
+            for (int jj = 0; jj < kPre; ++jj) {
+                constexpr int dummy = 0; (void)dummy;
+                const int j = j0 + jj;
+                if (j >= NMY) continue;
+                const int my = my_first + j;
+                if (my < 0 || my > my_last) continue;   // (uniform over the workgroup)
+                VT v[16];
+                __builtin_memcpy(v, q[jj], sizeof v);
+                const int nvalid = min(4, vv.h - 4 * my);   // rows of this micro-brick row inside the volume
+                CellCols<VT> A, L, H;
+                L.add_row(v);
+                if (nvalid > 1) L.add_row(v + 4);
+                A = L;
+                if (nvalid > 2) A.add_row(v + 8);
+                if (nvalid > 3) { H.add_row(v + 12); A.merge(H); }
+#pragma unroll
+                for (int rl = 0; rl < R; ++rl) {
+                    const int jr = 1 + rl * BPC;   // first micro-brick row of this row of cells
+                    if (j == jr - 1) acc[rl].merge(H);
+                    if (j >= jr && j < jr + BPC) acc[rl].merge(A);
+                    if (j == jr + BPC) acc[rl].merge(L);
                 }
             }
         }
+        const int ncols = min(4, vv.w - 4 * mx);
 #pragma unroll
-        for (int dz = 0; dz < 4; ++dz)
+        for (int rl = 0; rl < R; ++rl)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) s_cls[(mx * 4 + dz) * 3 + k] = acc[dz][k].get();
+            for (int k = 0; k < 3; ++k) s_cls[((rl * (int)vv.nbx + mx) * 4 + dz) * 3 + k] = acc[rl].rec(k, ncols);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < grid.cx * 4; i += kThreads) {
-        const int cxi = i >> 2, dz = i & 3;
+    for (int i = threadIdx.x; i < nrows * grid.cx * 4; i += kThreads) {
+        const int rl = i / (grid.cx * 4), j = i - rl * grid.cx * 4;
+        const int dz = j / grid.cx, cxi = j - dz * grid.cx;   // (neighbouring threads write neighbouring records)
         const int z = 4 * mz + dz;
         if (z >= vv.d) continue;
-        CellMerge a;
-        const int b0 = cxi * bpc;
-        if (b0 - 1 >= 0) a.merge(s_cls[((b0 - 1) * 4 + dz) * 3 + 2]);
-        for (int b = b0; b < b0 + bpc && b < (int)vv.nbx; ++b) a.merge(s_cls[(b * 4 + dz) * 3 + 0]);
-        if (b0 + bpc < (int)vv.nbx) a.merge(s_cls[((b0 + bpc) * 4 + dz) * 3 + 1]);
-        xy[((size_t)z * grid.cy + cyi) * grid.cx + cxi] = make_float2(a.mn, a.mx);
+        const CellRec<VT> *cls = s_cls + (size_t)rl * vv.nbx * 12;
+        CellMerge<VT> a;
+        const int b0 = cxi * BPC;
+        if (b0 - 1 >= 0) a.merge(cls[((b0 - 1) * 4 + dz) * 3 + 2]);
+        for (int b = b0; b < b0 + BPC && b < (int)vv.nbx; ++b) a.merge(cls[(b * 4 + dz) * 3 + 0]);
+        if (b0 + BPC < (int)vv.nbx) a.merge(cls[((b0 + BPC) * 4 + dz) * 3 + 1]);
+        xy[((size_t)z * grid.cy + (cy0 + rl)) * grid.cx + cxi] = a.rec();
     }
 }
 
-__global__ __launch_bounds__(kThreads) void vr_cell_z_kernel(CellView grid, int d, const float2 *xy, float2 *out)
+// (a thread takes kZCells cells next to each other in x: the records of integer volumes are 2 or 4 bytes)
+constexpr int kZCells = 4;
+template <typename VT>
+__global__ __launch_bounds__(kThreads) void vr_cell_z_kernel(CellView grid, int d, const CellRec<VT> *xy, float2 *out)
 {
-    const size_t n_cells = (size_t)grid.cx * grid.cy * grid.cz;
-    const size_t c = (size_t)blockIdx.x * kThreads + threadIdx.x;
-    if (c >= n_cells) return;
+    const int gx = (grid.cx + kZCells - 1) / kZCells;
+    const size_t n_groups = (size_t)gx * grid.cy * grid.cz;
+    const size_t gi = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (gi >= n_groups) return;
+    const int cx0 = (int)(gi % (size_t)gx) * kZCells;
+    const int cyi = (int)((gi / (size_t)gx) % (size_t)grid.cy), czi = (int)(gi / ((size_t)gx * grid.cy));
     const size_t plane = (size_t)grid.cx * grid.cy;
-    const int czi = (int)(c / plane);
-    const size_t xyi = c % plane;
+    const size_t row = (size_t)cyi * grid.cx + cx0;
     const int z_a = max((czi << grid.shift) - 1, 0), z_b = min(((czi + 1) << grid.shift) + 1, d - 1);
-    float mn = __builtin_inff(), mx = -__builtin_inff();
+    const int n = min(kZCells, grid.cx - cx0);
+    CellMerge<VT> a[kZCells];
     for (int z = z_a; z <= z_b; ++z) {
-        const float2 q = xy[(size_t)z * plane + xyi];
-        mn = q.x < mn ? q.x : mn;
-        mx = q.y > mx ? q.y : mx;
+        const CellRec<VT> *p = xy + (size_t)z * plane + row;
+#pragma unroll
+        for (int i = 0; i < kZCells; ++i)
+            if (i < n) a[i].merge(p[i]);
     }
-    out[c] = make_float2(mn, mx);
+#pragma unroll
+    for (int i = 0; i < kZCells; ++i) {
+        if (i >= n) continue;
+        const CellRec<VT> q = a[i].rec();
+        out[(size_t)czi * plane + row + i] =
+            q.mn > q.mx ? make_float2(__builtin_inff(), -__builtin_inff()) : make_float2((float)q.mn, (float)q.mx);
+    }
 }
 
 // sparse table of the TF opacity for O(1) range maxima: T[j][i] = max(alpha[i .. i + 2^j - 1])
@@ -303,55 +424,84 @@ hipError_t vr_launch_cell_bmask(const VolView &vol, const CellView &grid, int bw
     return hipGetLastError();
 }
 
+namespace {
+template <typename VT, int R, int S>
+hipError_t launch_xy_rs(const VolView &vol, const CellView &grid, hipStream_t stream, CellRec<VT> *rec)
+{
+    const size_t lds = (size_t)R * vol.nbx * 4 * 3 * sizeof(CellRec<VT>);
+    int nb = 0;
+    hipError_t e = vr_prepare_kernel(vr_cell_xy_kernel<VT, R, S>, kThreads, lds, &nb, "cell grid xy", 0);
+    if (e != hipSuccess) return e;
+    const int nrb = (grid.cy + R - 1) / R;
+    hipLaunchKernelGGL((vr_cell_xy_kernel<VT, R, S>), dim3((unsigned)(nrb * (int)vol.nbz)), dim3(kThreads), lds, stream,
+                       vol, grid, rec);
+    return hipGetLastError();
+}
+template <typename VT, int R>
+hipError_t launch_xy(const VolView &vol, const CellView &grid, hipStream_t stream, CellRec<VT> *rec)
+{
+    switch (grid.shift) {
+    case 2: return launch_xy_rs<VT, R, 2>(vol, grid, stream, rec);
+    case 3: return launch_xy_rs<VT, R, 3>(vol, grid, stream, rec);
+    case 4: return launch_xy_rs<VT, (R > 2 ? 2 : R), 4>(vol, grid, stream, rec);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template <typename VT>
+hipError_t launch_separable(const VolView &vol, const CellView &grid, float2 *minmax, hipStream_t stream, void *records)
+{
+    CellRec<VT> *rec = static_cast<CellRec<VT> *>(records);
+    // rows of cells per workgroup: as many (<= 4) as keep the class table within 64 KiB of LDS
+    const size_t per_row = (size_t)vol.nbx * 4 * 3 * sizeof(CellRec<VT>);
+    hipError_t e;
+    if (4 * per_row <= 65536) e = launch_xy<VT, 4>(vol, grid, stream, rec);
+    else if (2 * per_row <= 65536) e = launch_xy<VT, 2>(vol, grid, stream, rec);
+    else e = launch_xy<VT, 1>(vol, grid, stream, rec);
+    if (e != hipSuccess) return e;
+    const size_t n_groups = (size_t)((grid.cx + kZCells - 1) / kZCells) * grid.cy * grid.cz;
+    hipLaunchKernelGGL(vr_cell_z_kernel<VT>, dim3((unsigned)((n_groups + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                       stream, grid, vol.d, (const CellRec<VT> *)rec, minmax);
+    return hipGetLastError();
+}
+} // namespace
+
 hipError_t vr_launch_cell_minmax(const VolView &vol, int format, const CellView &grid,
-                                 float2 *minmax, hipStream_t stream, float2 *records)
+                                 float2 *minmax, hipStream_t stream, void *records)
 {
     const size_t n_cells = (size_t)grid.cx * grid.cy * grid.cz;
     if (records && grid.shift <= 4) {
-        // separable streaming build (records: d * cy * cx float2 of scratch)
-        const size_t lds = (size_t)vol.nbx * 4 * 3 * sizeof(float2);
-        dim3 g1((unsigned)(grid.cy * (int)vol.nbz)), block(kThreads);
-        int nb = 0;
-        hipError_t e;
+        // separable streaming build (records: d * cy * cx CellRec of scratch, vr_cell_record_bytes)
+        hipError_t e = hipErrorInvalidValue;
+        switch (format) {
+        case VRHIP_UCHAR: e = launch_separable<uint8_t>(vol, grid, minmax, stream, records); break;
+        case VRHIP_USHORT: e = launch_separable<uint16_t>(vol, grid, minmax, stream, records); break;
+        case VRHIP_FLOAT: e = launch_separable<float>(vol, grid, minmax, stream, records); break;
+        default: break;
+        }
+        return e;
+    }
+    // one wave per cell, in launches of at most 2^24 cells (a launch of more than 2^32 threads does not run)
+    const size_t per_block = kThreads / 64, chunk = (size_t)1 << 24;
+    for (size_t c0 = 0; c0 < n_cells; c0 += chunk) {
+        const size_t n = std::min(chunk, n_cells - c0);
+        dim3 g((unsigned)((n + per_block - 1) / per_block)), block(kThreads);
         switch (format) {
         case VRHIP_UCHAR:
-            e = vr_prepare_kernel(vr_cell_xy_kernel<uint8_t>, kThreads, lds, &nb, "cell grid xy", 0);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(vr_cell_xy_kernel<uint8_t>, g1, block, lds, stream, vol, grid, records);
+            hipLaunchKernelGGL(vr_cell_minmax_kernel<uint8_t>, g, block, 0, stream, vol, grid, minmax, c0);
             break;
         case VRHIP_USHORT:
-            e = vr_prepare_kernel(vr_cell_xy_kernel<uint16_t>, kThreads, lds, &nb, "cell grid xy", 0);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(vr_cell_xy_kernel<uint16_t>, g1, block, lds, stream, vol, grid, records);
+            hipLaunchKernelGGL(vr_cell_minmax_kernel<uint16_t>, g, block, 0, stream, vol, grid, minmax, c0);
             break;
         case VRHIP_FLOAT:
-            e = vr_prepare_kernel(vr_cell_xy_kernel<float>, kThreads, lds, &nb, "cell grid xy", 0);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(vr_cell_xy_kernel<float>, g1, block, lds, stream, vol, grid, records);
+            hipLaunchKernelGGL(vr_cell_minmax_kernel<float>, g, block, 0, stream, vol, grid, minmax, c0);
             break;
         default: return hipErrorInvalidValue;
         }
-        e = hipGetLastError();
+        hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(vr_cell_z_kernel, dim3((unsigned)((n_cells + kThreads - 1) / kThreads)), block, 0, stream,
-                           grid, vol.d, (const float2 *)records, minmax);
-        return hipGetLastError();
     }
-    const size_t per_block = kThreads / 64;
-    dim3 g((unsigned)((n_cells + per_block - 1) / per_block)), block(kThreads);
-    switch (format) {
-    case VRHIP_UCHAR:
-        hipLaunchKernelGGL(vr_cell_minmax_kernel<uint8_t>, g, block, 0, stream, vol, grid, minmax);
-        break;
-    case VRHIP_USHORT:
-        hipLaunchKernelGGL(vr_cell_minmax_kernel<uint16_t>, g, block, 0, stream, vol, grid, minmax);
-        break;
-    case VRHIP_FLOAT:
-        hipLaunchKernelGGL(vr_cell_minmax_kernel<float>, g, block, 0, stream, vol, grid, minmax);
-        break;
-    default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
+    return hipSuccess;
 }
 
 hipError_t vr_launch_cell_bounds(const float2 *minmax, const CellView &grid, float inv_max,

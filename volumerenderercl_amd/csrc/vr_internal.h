@@ -229,8 +229,11 @@ hipError_t vr_launch_pathtrace(const RaycastLaunch &a, hipStream_t stream);
 // records: d * cy * cx float2 of scratch for the separable streaming build (cells of <= 16 voxels,
 // micro-brick rows of <= 2048 bricks: the x classes of a row live in LDS), or nullptr: the
 // one-wave-per-cell kernel
+// records: scratch of vr_cell_record_bytes(format) * grid.cx * grid.cy * vol.d bytes for the separable
+// streaming build (nullptr, or cells of more than 16 voxels: the one-wave-per-cell kernel)
+inline size_t vr_cell_record_bytes(int format) { return format == VRHIP_UCHAR ? 2 : format == VRHIP_USHORT ? 4 : 8; }
 hipError_t vr_launch_cell_minmax(const VolView &vol, int format, const CellView &grid,
-                                 float2 *minmax, hipStream_t stream, float2 *records = nullptr);
+                                 float2 *minmax, hipStream_t stream, void *records = nullptr);
 hipError_t vr_launch_cell_bounds(const float2 *minmax, const CellView &grid, float inv_max,
                                  const TfView &tf, float *sparse_scratch, float *bound,
                                  uint32_t *empty_bits, hipStream_t stream);

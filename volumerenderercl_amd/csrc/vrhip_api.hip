@@ -539,10 +539,10 @@ static int build_cell_minmax(vrhip_renderer *r, VolumeSlot &s, const CellView &g
 {
     // scratch for the separable build (one (min, max) per cell column and voxel slice), held only
     // while it runs
-    float2 *records = nullptr;
+    void *records = nullptr;
     const size_t n_rec = (size_t)g.cx * g.cy * r->res[2];
     if (g.shift <= 4 && r->nb[0] <= 1600u && !getenv("VRHIP_CELLS_PER_WAVE") &&
-        hipMalloc((void **)&records, n_rec * sizeof(float2)) != hipSuccess) {
+        hipMalloc(&records, n_rec * vr_cell_record_bytes(r->format)) != hipSuccess) {
         (void)hipGetLastError();
         records = nullptr;
     }
