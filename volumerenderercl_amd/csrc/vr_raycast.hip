@@ -471,27 +471,35 @@ constexpr int kLook1 = VR_LOOK1, kLook2 = VR_LOOK2;
 
 // Bit k set: sample k of the run t0, t0 + stepSize, ... lies in an EMPTY cell (CellView): its
 // fetch can only map to opacity 0, so compositing it changes nothing (:864-879 with alpha == 0).
-// The cell is found from a linearised texel position (u0 + k * du): the cell extents carry a
-// one-texel halo for exactly this purpose, so the lookahead costs a few instructions per sample
-// and no voxel access.
+// The cell comes from a linearised voxel position u' = p * res (+ k * du'), in cells: the fetch's
+// low-corner texel is x0 = floor(u' - 0.5), so x' = floor(u') is x0 or x0 + 1 -- also with the
+// linearisation's error, which is far below half a texel -- and the voxels x0, x0 + 1 the fetch reads
+// lie in [x' - 1, x' + 1], inside the extent [E c - 1, E c + E + 1] the cell of x' answers for (the
+// halo is there for exactly this).  Three instructions per axis and sample, no voxel access.
+// Positions outside the volume (speculative samples past the ray's end, whose bits nobody reads)
+// clamp to a cell inside.
 template <typename VT, int INSTR, int kLook, typename V>
 VR_DEV uint32_t empty_mask(const CellView &cv, const V &vol, const RayCtx &c, float t0)
 {
     const f3 p0 = add3(c.cam, scale3(c.dir, t0 - c.offset));
-    const float u0 = (p0.x * 0.5f + 0.5f) * vol.fw - 0.5f;
-    const float v0 = (p0.y * 0.5f + 0.5f) * vol.fh - 0.5f;
-    const float s0 = (p0.z * 0.5f + 0.5f) * vol.fd - 0.5f;
-    const float du = (c.dir.x * c.stepSize) * (0.5f * vol.fw);
-    const float dv = (c.dir.y * c.stepSize) * (0.5f * vol.fh);
-    const float ds = (c.dir.z * c.stepSize) * (0.5f * vol.fd);
+    const float inv_e = __uint_as_float((uint32_t)(127 - cv.eshift) << 23);   // 2^-eshift
+    const float su = vol.fw * inv_e, sv = vol.fh * inv_e, ss = vol.fd * inv_e;
+    const float u0 = (p0.x * 0.5f + 0.5f) * su;
+    const float v0 = (p0.y * 0.5f + 0.5f) * sv;
+    const float s0 = (p0.z * 0.5f + 0.5f) * ss;
+    const float du = (c.dir.x * c.stepSize) * (0.5f * su);
+    const float dv = (c.dir.y * c.stepSize) * (0.5f * sv);
+    const float ds = (c.dir.z * c.stepSize) * (0.5f * ss);
+    const uint32_t mx = (uint32_t)cv.ecx - 1u, my = (uint32_t)cv.ecy - 1u, mz = (uint32_t)cv.ecz - 1u;
     uint32_t w[kLook], sh[kLook];
 #pragma unroll
     for (int k = 0; k < kLook; ++k) {
         const float fk = (float)k;
-        const int x = iclamp((int)floorf(__builtin_fmaf(fk, du, u0)), 0, vol.w1) >> cv.eshift;
-        const int y = iclamp((int)floorf(__builtin_fmaf(fk, dv, v0)), 0, vol.h1) >> cv.eshift;
-        const int z = iclamp((int)floorf(__builtin_fmaf(fk, ds, s0)), 0, vol.d1) >> cv.eshift;
-        const uint32_t idx = ((uint32_t)z * (uint32_t)cv.ecy + (uint32_t)y) * (uint32_t)cv.ecx + (uint32_t)x;
+        // (int) truncates: (-1, 0) -> 0; anything below wraps to a large unsigned and clamps like the far side
+        const uint32_t x = min((uint32_t)(int)__builtin_fmaf(fk, du, u0), mx);
+        const uint32_t y = min((uint32_t)(int)__builtin_fmaf(fk, dv, v0), my);
+        const uint32_t z = min((uint32_t)(int)__builtin_fmaf(fk, ds, s0), mz);
+        const uint32_t idx = (z * (uint32_t)cv.ecy + y) * (uint32_t)cv.ecx + x;
         w[k] = cv.empty[idx >> 5];
         sh[k] = idx & 31u;
     }
