@@ -460,7 +460,10 @@ VR_DEV void eval_batch(const V &vol, const float4 *s_tff, int tffn, float *s_sta
 }
 
 #ifndef VR_LOOK1
-#define VR_LOOK1 16
+#define VR_LOOK1 24
+#endif
+#ifndef VR_LOOK_NUM
+#define VR_LOOK_NUM 2   // the lookahead runs when at least 1 / VR_LOOK_NUM of the sampling lanes expect an empty sample
 #endif
 #ifndef VR_LOOK2
 #define VR_LOOK2 8
@@ -567,7 +570,7 @@ VR_DEV bool lookahead_pays(bool sampling, bool guess_empty)
 {
     const int n_s = __builtin_popcountll(__ballot(sampling));
     const int n_g = __builtin_popcountll(__ballot(sampling && guess_empty));
-    return n_g > 0 && 2 * n_g >= n_s;
+    return n_g > 0 && VR_LOOK_NUM * n_g >= n_s;
 }
 
 // ---- stepping over empty space in O(1) per run (CellView::bmask + vr_leap)
