@@ -23,12 +23,17 @@ mkdir -p "$ROOT/profiles/$R"
 cp "$OUT/pmc_issue_tput.json" "$ROOT/profiles/$R/pmc_issue.json"
 cp "$OUT/pmc_traffic_tput.json" "$ROOT/profiles/$R/pmc_traffic.json"
 timeout -k 10 400 python3 bench.py --out-json "$OUT/bench_shells2048.json" > /dev/null 2> "$OUT/bench_shells2048.err"; echo "shells2048 rc=$?"
+timeout -k 10 400 python3 bench.py --steps 20 --warmup 5 --out-json "$OUT/bench_shells2048_driver_args.json" > /dev/null 2> "$OUT/bench_shells2048_driver_args.err"; echo "shells2048 (driver arguments) rc=$?"
 timeout -k 10 300 python3 bench.py --workload sphere256_plain --viewport 512 --out-json "$OUT/bench_sphere256_plain_512.json" > /dev/null 2> "$OUT/bench_sphere256_plain.err"; echo "config1 rc=$?"
 timeout -k 10 300 python3 bench.py --workload sphere256 --out-json "$OUT/bench_sphere256.json" > /dev/null 2> "$OUT/bench_sphere256.err"; echo "config2 rc=$?"
 timeout -k 10 400 python3 bench.py --workload shells1024u16 --out-json "$OUT/bench_shells1024u16.json" > /dev/null 2> "$OUT/bench_shells1024u16.err"; echo "config3 rc=$?"
 timeout -k 10 400 python3 bench.py --workload pt1024f --steps 64 --out-json "$OUT/bench_pt1024f_64spp.json" > /dev/null 2> "$OUT/bench_pt1024f.err"; echo "config5 rc=$?"
 timeout -k 10 400 python3 bench.py --workload haze2048 --out-json "$OUT/bench_haze2048.json" > /dev/null 2> "$OUT/bench_haze2048.err"; echo "haze2048 rc=$?"
 timeout -k 10 400 python3 bench.py --workload shells2048 --viewport 2048 --steps 32 --out-json "$OUT/bench_shells2048_vp2048_1gpu.json" > /dev/null 2> "$OUT/bench_vp2048.err"; echo "config4@1gpu rc=$?"
+# the build of the two cell grids at 2048^3 (cells of 4 and of 8 voxels)
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/cells_trace" -o c -- python3 "$ROOT/tools/cells_time.py" > "$OUT/cells_time.log" 2>&1 )
+find "$OUT/cells_trace" -name "*kernel_stats.csv" -exec cp {} "$OUT/cells_2048_kernel_stats.csv" \;
+rm -rf "$OUT/cells_trace"
 python3 - <<PY
 import json, glob, os
 for f in sorted(glob.glob("$OUT/bench_*.json")):

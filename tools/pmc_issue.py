@@ -45,10 +45,11 @@ def main():
     for k, d in sorted(acc.items()):
         per = {c: v / frames for c, v in sorted(d.items())}
         der = {}
-        if per.get("SQ_INSTS_VALU") and per.get("SQ_THREAD_CYCLES_VALU"):
-            # THREAD_CYCLES_VALU: active lanes summed over VALU issue cycles (4 cycles per
-            # instruction and 16 lanes per cycle on the counter's model) -> lanes per instruction
-            der["active_lanes_per_valu_inst"] = per["SQ_THREAD_CYCLES_VALU"] / per["SQ_INSTS_VALU"] / 4.0
+        if per.get("SQ_ACTIVE_INST_VALU") and per.get("SQ_THREAD_CYCLES_VALU"):
+            # active lanes per VALU instruction: thread-cycles over the cycles a VALU instruction was
+            # issuing (the ratio rocprof-compute reports as "VALU active threads"; both counters run in
+            # the same unit, and SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU is 1.00-1.02 on these kernels)
+            der["active_lanes_per_valu_inst"] = min(64.0, per["SQ_THREAD_CYCLES_VALU"] / per["SQ_ACTIVE_INST_VALU"])
         if per.get("SQ_ACTIVE_INST_VALU") and per.get("SQ_WAVE_CYCLES"):
             der["valu_issuing_share_of_wave_cycles"] = per["SQ_ACTIVE_INST_VALU"] / per["SQ_WAVE_CYCLES"]
         if per.get("SQ_WAIT_ANY") and per.get("SQ_WAVE_CYCLES"):
@@ -62,7 +63,7 @@ def main():
     res["per_frame_total"] = dict(sorted(tot.items()))
     res["valu_wave_insts_per_frame"] = tot.get("SQ_INSTS_VALU", 0.0)
     if tot.get("SQ_THREAD_CYCLES_VALU") and tot.get("SQ_INSTS_VALU"):
-        res["valu_lane_utilisation"] = tot["SQ_THREAD_CYCLES_VALU"] / tot["SQ_INSTS_VALU"] / 4.0 / 64.0
+        res["valu_lane_utilisation"] = min(1.0, tot["SQ_THREAD_CYCLES_VALU"] / max(tot["SQ_ACTIVE_INST_VALU"], 1.0) / 64.0)
     allj = {}
     if os.path.exists(out_path):
         allj = json.load(open(out_path))
