@@ -200,12 +200,13 @@ def test_empty_skipping_is_exact(vr, monkeypatch):
 
 @pytest.mark.parametrize("env", [{"VRHIP_CULL_RADIUS": "0"}, {"VRHIP_CULL_RADIUS": "12"},
                                  {"VRHIP_MARCH": "1"}, {"VRHIP_MARCH": "1", "VRHIP_MARCH_MICRO": "1"},
-                                 {"VRHIP_MARCH_MICRO": "3"}, {"VRHIP_EMPTY_SKIP": "1", "VRHIP_MARCH_MICRO": "6"},
+                                 {"VRHIP_EMPTY_SKIP": "1"}, {"VRHIP_EMPTY_SKIP": "1", "VRHIP_CELL_SHIFT": "3"},
                                  {"VRHIP_LDS_STAGE": "1"}, {"VRHIP_LDS_STAGE": "2"}])
 def test_schedules_and_culling_do_not_change_pixels(vr, monkeypatch, env):
     """Scheduling devices of round 2 -- patch culling in the DDA pre-pass (off / wide radius), the
     decoupled march kernel (vr_march_kernel: per-brick empty words, exact leaps of the t chain with
-    vr_leap, dense evaluation queues), leap stepping inside the two-phase kernels, the LDS brick
+    vr_leap, dense evaluation queues), empty-run skipping forced on where the heuristic leaves it off
+    (empty bits on cells of 4 voxels, and of 8: one grid for bounds and bits), the LDS brick
     staging experiment (vr_raycast_staged_kernel, with and without the staged boxes) -- on a 256^3 field
     with large empty regions, bricks of 4 voxels, three views, two seeds: bit-identical to the
     default schedule's frames and equal to the oracle's."""

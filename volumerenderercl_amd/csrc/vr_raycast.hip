@@ -1080,10 +1080,10 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
     const uint32_t *sb = SKIP_LDS ? s_skip : skip.bits;
     const bool skip_empty = cells.empty != nullptr && rp.useLinear != 0;
     // (opt-in, VRHIP_MARCH_MICRO = leap steps per round: measured no faster than the lookahead below)
-#ifdef VR_NO_LEAP_STEPPING
-    const bool use_mask = false;
-#else
+#ifdef VR_LEAP_STEPPING   // diagnostic build; VRHIP_MARCH_MICRO = leap steps per round
     const bool use_mask = skip_empty && cells.bmask != nullptr && fr.march_micro != 0;
+#else   // (kept out of the default build: its registers cost the two-phase kernels 2.5 % of the frame)
+    const bool use_mask = false;
 #endif
     const uint32_t leap_iters = fr.march_micro;
     const uint32_t budget = fr.round_budget ? fr.round_budget : 0xffffffffu;
@@ -2025,10 +2025,10 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
     const bool skip_empty = INSTR != 2 && cells.empty != nullptr && rp.useLinear != 0 &&
                             !(XS && rp.illumType == 4);
     // (opt-in, VRHIP_MARCH_MICRO = leap steps per round: measured no faster than the lookahead below)
-#ifdef VR_NO_LEAP_STEPPING
-    const bool use_mask = false;
-#else
+#ifdef VR_LEAP_STEPPING   // diagnostic build; VRHIP_MARCH_MICRO = leap steps per round
     const bool use_mask = skip_empty && cells.bmask != nullptr && fr.march_micro != 0;
+#else   // (kept out of the default build: its registers cost the two-phase kernels 2.5 % of the frame)
+    const bool use_mask = false;
 #endif
     const uint32_t leap_iters = fr.march_micro;
     LeapCache lc;

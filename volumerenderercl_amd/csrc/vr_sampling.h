@@ -11,7 +11,10 @@
 
 namespace {
 
-constexpr int kBlockDim = 256;       // 4 waves
+#ifndef VR_BLOCK_DIM
+#define VR_BLOCK_DIM 256
+#endif
+constexpr int kBlockDim = VR_BLOCK_DIM;   // 4 waves
 #ifndef VR_MAXBRICK
 #define VR_MAXBRICK 4
 #endif
