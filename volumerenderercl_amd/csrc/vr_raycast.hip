@@ -294,7 +294,7 @@ VR_DEV void eval_batch(const V &vol, const float4 *s_tff, int tffn, float *s_sta
     VR_MARK("E_fetch");
     if (XS && rp.illumType == 4) {
         // handled below
-    } else if (rp.useLinear) {
+    } else if (!XS || rp.useLinear) {   // (nearest filtering, contours and the depth cue: XS variants, see launch_typed)
 #pragma unroll
         for (int k = 0; k < kBatch; ++k)
             if (INSTR != 2 || vk[k]) dens[k] = vol.linear(pk[k].x, pk[k].y, pk[k].z);
@@ -335,7 +335,7 @@ VR_DEV void eval_batch(const V &vol, const float4 *s_tff, int tffn, float *s_sta
     VR_MARK("E_slots");
     // ---- which samples need the expensive part, and their slots
     const bool shade_mode = XS ? (rp.illumType != 0 && rp.illumType != 4) : rp.illumType == 1;   // :809
-    const bool want_grad = shade_mode || (rcp.contours && !rp.illumType);
+    const bool want_grad = shade_mode || (XS && rcp.contours && !rp.illumType);
     const uint32_t lane = threadIdx.x & 63u;
     bool lit[kBatch], need[kBatch];
     uint32_t slot[kBatch];
@@ -344,7 +344,7 @@ VR_DEV void eval_batch(const V &vol, const float4 *s_tff, int tffn, float *s_sta
     for (int k = 0; k < kBatch; ++k) {
         lit[k] = vk[k] && tfc[k].w > 0.1f && !(XS && rp.illumType == 4) && !multi;   // :809/:832, before the depth cue
         shaded[k] = lit[k] && shade_mode;
-        if (rcp.aerial) {                                     // :858-862
+        if (XS && rcp.aerial) {                               // :858-862
             float depthCue = 1.f - (tk[k] - c.tnear) / c.sampleDist;
             tfc[k].w *= depthCue;
         }
@@ -393,7 +393,7 @@ VR_DEV void eval_batch(const V &vol, const float4 *s_tff, int tffn, float *s_sta
                               __shfl(c.hv.z, owner, 64));
             const int hvalid = __shfl(c.hvalid ? 1 : 0, owner, 64);
             f3 dirv = mk3(0.f, 0.f, 0.f);
-            if (rcp.contours)
+            if (XS && rcp.contours)
                 dirv = mk3(__shfl(c.dir.x, owner, 64), __shfl(c.dir.y, owner, 64),
                            __shfl(c.dir.z, owner, 64));
             float o_ndl = 0.f, o_sp = 0.f, o_cnt = 0.f, o_op = 0.f;
@@ -447,7 +447,7 @@ VR_DEV void eval_batch(const V &vol, const float4 *s_tff, int tffn, float *s_sta
             const float f = ndl[k] > 0.95f ? 1.0f : ndl[k] > 0.5f ? 0.6f : ndl[k] > 0.25f ? 0.4f : 0.2f;
             if (!(ndl[k] > 0.95f)) { tfc[k].x *= f; tfc[k].y *= f; tfc[k].z *= f; }
         }
-        if (lit[k] && rcp.contours) {
+        if (XS && lit[k] && rcp.contours) {
             tfc[k].x *= cnt[k]; tfc[k].y *= cnt[k]; tfc[k].z *= cnt[k];
         }
         tfc[k].x = c.env0 - tfc[k].x;
@@ -2437,10 +2437,11 @@ template <typename VT>
 hipError_t launch_typed(const RaycastLaunch &a, hipStream_t stream)
 {
     const bool lds = a.skip.in_lds != 0;
-    // the rarely used shading modes 2-5 live in kernel variants of their own (XS), so that their
-    // code and registers do not tax the default ones
+    // the rarely used shading modes 2-5, contours, the depth cue and nearest filtering live in kernel
+    // variants of their own (XS), so that their code and registers do not tax the default ones
     const bool xs = a.render.illumType >= 2 || a.raycast.useAO != 0 || a.render.showEss != 0 ||
-                    a.render.imgEss != 0 || a.vol.channels > 1;
+                    a.render.imgEss != 0 || a.vol.channels > 1 || a.raycast.contours != 0 ||
+                    a.raycast.aerial != 0 || a.render.useLinear == 0;
     if (a.frame.lds_stage && !xs && a.instr == 0 && a.use_ess && sizeof(VT) == 1 && !a.raycast.contours &&
         !a.raycast.aerial && a.frame.n_wave_tiles)
         return launch_staged(a, stream);
