@@ -583,24 +583,38 @@ int ensure_cells(vrhip_renderer *r, bool need_bound, bool need_empty)
     fine.shift = eshift; fine.cx = g.ecx; fine.cy = g.ecy; fine.cz = g.ecz;
     if (!r->cell_sparse) VR_HIP(r, hipMalloc((void **)&r->cell_sparse, 13 * 4096 * sizeof(float)));
 
-    // ---- (min, max) per cell: a property of the voxels, kept per time step
+    // ---- (min, max) per cell: a property of the voxels, kept per time step.  A renderer that shares
+    // another one's voxels (vrhip_share_volumes) reads the owner's tables where the owner has built them.
     const bool one_grid = eshift == shift;
-    if (need_empty && !one_grid && !s.fine_minmax_valid) {
+    const float2 *fine_mm = nullptr, *coarse_mm = nullptr;
+    if (r->vol_owner && r->timestep < r->vol_owner->vols.size()) {
+        const VolumeSlot &os = r->vol_owner->vols[r->timestep];
+        if (os.dev == s.dev) {
+            bool use = false;
+            if (os.fine_minmax_valid && !s.fine_minmax_valid) { fine_mm = os.fine_minmax; use = true; }
+            if (os.pt_minmax_valid && !s.pt_minmax_valid) { coarse_mm = os.pt_minmax; use = true; }
+            // (what the owner's stream has written must be complete before this renderer's stream reads it)
+            if (use && r->vol_owner->stream != r->stream) VR_HIP(r, hipStreamSynchronize(r->vol_owner->stream));
+        }
+    }
+    if (need_empty && !one_grid && !s.fine_minmax_valid && !fine_mm) {
         if (!s.fine_minmax) VR_HIP(r, hipMalloc((void **)&s.fine_minmax, n_fine * sizeof(float2)));
         int rc = build_cell_minmax(r, s, fine, s.fine_minmax);
         if (rc) return rc;
         s.fine_minmax_valid = true;
     }
-    if ((need_bound || one_grid) && !s.pt_minmax_valid) {
+    if (s.fine_minmax_valid) fine_mm = s.fine_minmax;
+    if ((need_bound || one_grid) && !s.pt_minmax_valid && !coarse_mm) {
         if (!s.pt_minmax) VR_HIP(r, hipMalloc((void **)&s.pt_minmax, n_cells * sizeof(float2)));
-        if (s.fine_minmax_valid) {
-            VR_HIP(r, vr_launch_cell_reduce(s.fine_minmax, g, s.pt_minmax, r->stream));
+        if (fine_mm && !one_grid) {
+            VR_HIP(r, vr_launch_cell_reduce(fine_mm, g, s.pt_minmax, r->stream));
         } else {
             int rc = build_cell_minmax(r, s, g, s.pt_minmax);
             if (rc) return rc;
         }
         s.pt_minmax_valid = true;
     }
+    if (s.pt_minmax_valid) coarse_mm = s.pt_minmax;
 
     // ---- with the transfer function: bounds, empty bits
     if (need_bound && !r->cells_have_bound) {
@@ -612,7 +626,7 @@ int ensure_cells(vrhip_renderer *r, bool need_bound, bool need_empty)
             VR_HIP(r, hipMalloc((void **)&r->cell_bound, n_cells * sizeof(float)));
             r->cell_cap = n_cells;
         }
-        VR_HIP(r, vr_launch_cell_bounds(s.pt_minmax, g, inv_max_of(r->format), make_tf_view(r),
+        VR_HIP(r, vr_launch_cell_bounds(coarse_mm, g, inv_max_of(r->format), make_tf_view(r),
                                         r->cell_sparse, r->cell_bound, nullptr, r->stream));
         r->cells_have_bound = true;
     }
@@ -626,7 +640,7 @@ int ensure_cells(vrhip_renderer *r, bool need_bound, bool need_empty)
             VR_HIP(r, hipMalloc((void **)&r->cell_empty, ((n_fine + 63) / 64) * 2 * sizeof(uint32_t)));
             r->empty_cap = n_fine;
         }
-        VR_HIP(r, vr_launch_cell_bounds(one_grid ? s.pt_minmax : s.fine_minmax, fine, inv_max_of(r->format),
+        VR_HIP(r, vr_launch_cell_bounds(one_grid ? coarse_mm : fine_mm, fine, inv_max_of(r->format),
                                         make_tf_view(r), r->cell_sparse, nullptr, r->cell_empty, r->stream));
         r->cells_have_empty = true;
         g.empty = r->cell_empty;
@@ -1068,8 +1082,13 @@ static int download_cells_impl(vrhip_renderer *r, bool fine, float *out_minmax, 
     VR_REQUIRE(r, n_floats == 2 * n_cells, VRHIP_ERR_INVALID, "vrhip_download_cells: size mismatch");
     VR_HIP(r, hipStreamSynchronize(r->stream));
     const VolumeSlot &s = r->vols[r->timestep];
-    VR_HIP(r, hipMemcpy(out_minmax, second ? s.fine_minmax : s.pt_minmax, n_cells * sizeof(float2),
-                        hipMemcpyDeviceToHost));
+    const float2 *src = second ? (s.fine_minmax_valid ? s.fine_minmax : nullptr) : (s.pt_minmax_valid ? s.pt_minmax : nullptr);
+    if (!src && r->vol_owner && r->timestep < r->vol_owner->vols.size()) {   // tables read from the volumes' owner
+        const VolumeSlot &os = r->vol_owner->vols[r->timestep];
+        src = second ? (os.fine_minmax_valid ? os.fine_minmax : nullptr) : (os.pt_minmax_valid ? os.pt_minmax : nullptr);
+    }
+    VR_REQUIRE(r, src, VRHIP_ERR_NODATA, "vrhip_download_cells: no cell grid");
+    VR_HIP(r, hipMemcpy(out_minmax, src, n_cells * sizeof(float2), hipMemcpyDeviceToHost));
     return VRHIP_OK;
 }
 
