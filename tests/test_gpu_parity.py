@@ -266,12 +266,23 @@ def test_cell_grid_bounds(fmt, res, monkeypatch):
         try:
             r2.loadVolumeArrays([vol], fmt)
             r2.setTransferFunction(common.tffs()["default"])
-            got[name, 8], shift = r2.downloadCells()
+            got[name, 8], shift = r2.downloadCells()           # built directly (no fine grid yet)
             assert shift == 3
             got[name, 4], shift = r2.downloadCells(fine=True)
             assert shift == 2
         finally:
             r2.close()
+        r3 = VolumeRenderCL()
+        r3.initialize()
+        try:
+            r3.loadVolumeArrays([vol], fmt)
+            r3.setTransferFunction(common.tffs()["default"])
+            fine3, _ = r3.downloadCells(fine=True)
+            coarse3, _ = r3.downloadCells()                    # reduced from the fine grid
+            np.testing.assert_array_equal(fine3, got[name, 4])
+            np.testing.assert_array_equal(coarse3, got[name, 8])
+        finally:
+            r3.close()
     v = vol.astype(np.float32)
     for E in (8, 4):
         cz, cy, cx = got["wave", E].shape[:3]

@@ -1070,7 +1070,9 @@ static int download_cells_impl(vrhip_renderer *r, bool fine, float *out_minmax, 
     VR_REQUIRE(r, r->tff && r->tff_n, VRHIP_ERR_NODATA, "No transfer function set.");
     if (set_device(r)) return VRHIP_ERR_HIP;
     r->pt_dirty = true;
-    int rc = ensure_cells(r, true, true);
+    // (only the grid asked for: the coarse one is then built directly unless the fine one exists already,
+    // in which case it is reduced from it -- the tests take both routes)
+    int rc = ensure_cells(r, !fine, fine);
     if (rc) return rc;
     const CellView &g = r->cells;
     const bool second = fine && g.eshift != g.shift;
