@@ -1187,6 +1187,44 @@ def test_headline_size_volume_matches_oracle():
         r.close()
 
 
+def test_config3_size_volume_matches_oracle():
+    """BASELINE config 3's size: 1024^3 USHORT "shells" -- ESS bricks of 16 voxels, the smallest for which
+    the ray caster steps over empty cells by default (four cells of 4 voxels per brick edge), 128-byte
+    micro-bricks, a 17 GB footprint volume.  Field generated in HBM, downloaded; two seeds of a small
+    frame through the instrumented and the production kernels against the oracle: image, work counters,
+    ESS bricks."""
+    N = 1024
+    tff = common.tffs()["default"]
+    W, H = 128, 96
+    r = VolumeRenderCL()
+    r.initialize()
+    try:
+        r.synthVolume("shells", (N, N, N), USHORT)
+        vol = r.downloadVolume(0)
+        assert vol.shape == (N, N, N) and vol.dtype == np.uint16
+        r.setTransferFunction(tff)
+        ref_bricks = vro.generate_bricks(vol, USHORT)
+        assert ref_bricks.shape == (64, 64, 64, 2)
+        np.testing.assert_array_equal(r.downloadBricks(0), ref_bricks)
+        r.updateView(common.views()["rot30"])
+        for seed in (SEED, 581869302):
+            r.setSeed(seed)
+            r.setIteration(0)
+            cam, rp, rc, pt = common.to_oracle_params(*r.params())
+            rp.seed, rp.iteration = seed, 0
+            ref, rstats, _ = vro.render_tile(vol, USHORT, tff, cam, rp, rc, pt, W=W, H=H, bricks=ref_bricks)
+            assert rstats["bricks_skipped"] > 0 and rstats["samples_shaded"] > 0
+            for stats in (True, False):
+                r.setStatsEnabled(stats)
+                r.setIteration(0)
+                got = r.runRaycastNoGL(W, H)
+                assert np.abs(got.astype(np.float64) - ref).max() <= TOL, "seed=%d stats=%s" % (seed, stats)
+                if stats:
+                    assert r.getStats() == rstats
+    finally:
+        r.close()
+
+
 def test_shared_volume_twin_renders_the_same_frames(vr):
     """vrhip_share_volumes / VolumeRenderCL.shareVolumes: a second renderer on its own stream
     renders from the first one's voxels and bricks; frames of both equal the oracle's, also when
