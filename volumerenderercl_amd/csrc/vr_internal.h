@@ -112,6 +112,9 @@ struct ContRec {
 struct FrameView {
     uint32_t W, H;         // frame size in pixels
     uint32_t gsx, gsy;     // padded launch size the reference derives the camera from
+    // what make_ray derives from it for every pixel alike (:614-627), computed once on the host with
+    // the same IEEE operations: min(gsy / gsx, gsx / gsy), 2 / gsx, 2 / gsy
+    float ray_aspect, ray_psx, ray_psy;
     const WaveTile *queue; // n_wave_tiles entries, processed in order (centre first)
     uint32_t n_wave_tiles;
     uint32_t out_stride;   // pixels per row of `out`

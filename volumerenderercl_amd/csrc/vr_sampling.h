@@ -483,16 +483,14 @@ VR_DEV Ray make_ray(uint32_t gx, uint32_t gy, const FrameView &fr, const vrhip_c
     const f3 ms = mk3(rp.modelScale[0], rp.modelScale[1], rp.modelScale[2]);
     r.rnd = (float)parallel_rng3(gx, gy, seed) / 4294967296.0f;
 
-    float gsx = (float)fr.gsx, gsy = (float)fr.gsy;
-    float aspect = gsy / gsx;
-    aspect = vmin(aspect, gsx / gsy);
+    const float aspect = fr.ray_aspect;   // min(gsy / gsx, gsx / gsy), from the host (FrameView)
     int maxImg = (int)(fr.gsx > fr.gsy ? fr.gsx : fr.gsy);
     float icx = ((float)(int)gx / (float)maxImg) * 2.f;
     float icy = ((float)(int)gy / (float)maxImg) * 2.f;
     if (fr.gsx > fr.gsy) { icx -= 1.0f; icy -= aspect; }
     else { icx -= aspect; icy -= 1.0f; }
     icy *= -1.f;
-    float psx = 2.f / gsx, psy = 2.f / gsy;
+    const float psx = fr.ray_psx, psy = fr.ray_psy;   // 2 / gsx, 2 / gsy
     float rnd2 = (float)parallel_rng3(gy, gx, 2u * seed) / 4294967296.0f;
     icx += rnd2 * psx;
     icy += (-r.rnd) * psy;

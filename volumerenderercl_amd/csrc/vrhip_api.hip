@@ -779,6 +779,15 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
     // when the size is already a multiple of 8; the camera is derived from it.
     a->frame.gsx = width + (8u - width % 8u);
     a->frame.gsy = height + (8u - height % 8u);
+    {
+        const float gsx = (float)a->frame.gsx, gsy = (float)a->frame.gsy;
+        float aspect = gsy / gsx;
+        const float other = gsx / gsy;
+        aspect = other < aspect ? other : aspect;   // vmin(aspect, other), vr_device_math.h
+        a->frame.ray_aspect = aspect;
+        a->frame.ray_psx = 2.f / gsx;
+        a->frame.ray_psy = 2.f / gsy;
+    }
     a->frame.queue = r->queue_dev;
     a->frame.n_wave_tiles = r->queue_n;
     a->frame.out_stride = out_stride;
