@@ -68,18 +68,14 @@ __global__ __launch_bounds__(kThreads) void vr_cell_minmax_kernel(VolView vv, Ce
     if (lane == 0) out[cell] = any_bad ? make_float2(1.f, 0.f) : make_float2(mn, mx);
 }
 
-// ---- the same (min, max) by separable streaming passes (cells of 8 or 16 voxels: volumes up to 4096^3)
+// ---- the same (min, max) by separable streaming passes (cells of 4, 8 or 16 voxels)
 //
-// The extrema over the box [(c << s) - 1, ((c + 1) << s) + 1]^3 separate by axis.  Pass XY reads every
-// voxel as part of whole 64-byte micro-brick lines: a workgroup takes one row of cells (cy) in one
-// slice of micro-bricks (mz) and a thread a micro-brick column.  Over the rows y of the cell's halo'd
-// range it reduces, per z slice of the bricks, three x classes of its four voxel columns -- A: all
-// four, L: the first two (what the cell on the left takes from this brick), H: the last one (what the
-// cell on the right takes) -- into LDS; then a thread per cell combines H of the brick to its left, A
-// of its own bricks and L of the brick to its right: the extrema over the x and y ranges of the cell
-// for that voxel slice z.  Pass Z reduces the 2^s + 3 slices of each cell.  Exactly the kernel
+// The extrema over the box [(c << s) - 1, ((c + 1) << s) + 1]^3 separate by axis.  Pass XY
+// (vr_cell_xy_kernel, below) reads every voxel as part of whole micro-brick lines and leaves, per
+// voxel slice z and cell column (cx, cy), the extrema over the cell's x and y ranges: a record in the
+// voxel type.  Pass Z (vr_cell_z_kernel) reduces the 2^s + 3 slices of each cell.  Exactly the kernel
 // above's values (NaN voxels give (-inf, +inf): never culled, never empty).
-// (a record of the passes: extrema in the voxel type, mn > mx = nothing yet; FLOAT volumes flag NaN as (-inf, +inf))
+// A record of the passes: extrema in the voxel type, mn > mx = nothing yet; FLOAT volumes flag NaN as (-inf, +inf).
 template <typename VT> struct CellRec { VT mn, mx; };
 template <typename VT> struct CellAcc {   // extrema of raw voxel values; integer voxels stay integers until the end
     uint32_t mn = 0xffffffffu, mx = 0u;
