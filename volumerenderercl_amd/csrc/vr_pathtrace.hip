@@ -183,7 +183,7 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
         const bool walking = state >= P_PRIMARY && state <= P_SHADOW;
         if (__ballot(walking)) {
             float tk[B], dens[B], al[B];
-            f3 pk[B], sk[B];
+            f3 pk[B];
             bool ink[B], need[B];
             float tc = px.t;
 #pragma unroll
@@ -192,34 +192,44 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
                 tk[k] = tc;
                 pk[k] = add3(px.org, scale3(px.wdir, tc));
                 ink[k] = in_volume(pk[k]);
-                sk[k] = mk3(pk[k].x * 0.5f + 0.5f, pk[k].y * 0.5f + 0.5f, pk[k].z * 0.5f + 0.5f);
                 need[k] = walking && ink[k];
             }
             // majorant cull: no value a fetch in this cell can return maps to an opacity that
             // reaches the walk's threshold -> the step is a rejection whatever the voxels hold
             if (cull) {
-                // cell of step k from the walk's texel-space line u(t) = a + b * t (one fma per
-                // axis; exact to far better than the texel of halo the cells carry)
-                const float hx = 0.5f * vol.fw, hy = 0.5f * vol.fh, hz = 0.5f * vol.fd;
-                const float ax = __builtin_fmaf(px.org.x, hx, hx - 0.5f), bx = px.wdir.x * hx;
-                const float ay = __builtin_fmaf(px.org.y, hy, hy - 0.5f), by = px.wdir.y * hy;
-                const float az = __builtin_fmaf(px.org.z, hz, hz - 0.5f), bz = px.wdir.z * hz;
+                // cell of step k from the walk's voxel-space line u'(t) = a + b * t, in cells (one fma,
+                // one conversion and one clamp per axis).  u' = p * res: the fetch's low-corner texel is
+                // x0 = floor(u' - 0.5), so x' = floor(u') is x0 or x0 + 1 (the line's rounding is far
+                // below half a texel), and the voxels x0, x0 + 1 lie in [x' - 1, x' + 1] -- inside the
+                // extent [E c - 1, E c + E + 1] the cell of x' answers for.  Steps outside the volume
+                // (never fetched: `ink`) clamp to a cell inside.
+                const float inv_e = __uint_as_float((uint32_t)(127 - grid.shift) << 23);   // 2^-shift
+                const float hx = 0.5f * vol.fw * inv_e, hy = 0.5f * vol.fh * inv_e, hz = 0.5f * vol.fd * inv_e;
+                const float ax = __builtin_fmaf(px.org.x, hx, hx), bx = px.wdir.x * hx;
+                const float ay = __builtin_fmaf(px.org.y, hy, hy), by = px.wdir.y * hy;
+                const float az = __builtin_fmaf(px.org.z, hz, hz), bz = px.wdir.z * hz;
+                const uint32_t mx = (uint32_t)grid.cx - 1u, my = (uint32_t)grid.cy - 1u, mz = (uint32_t)grid.cz - 1u;
                 float bnd[B];
 #pragma unroll
-                for (int k = 0; k < B; ++k)
-                    bnd[k] = grid.bound[vol.cell_index_texel(__builtin_fmaf(bx, tk[k], ax),
-                                                             __builtin_fmaf(by, tk[k], ay),
-                                                             __builtin_fmaf(bz, tk[k], az), grid)];
+                for (int k = 0; k < B; ++k) {
+                    // (int) truncates: (-1, 0) -> 0; anything below wraps to a large unsigned and clamps
+                    const uint32_t x = min((uint32_t)(int)__builtin_fmaf(bx, tk[k], ax), mx);
+                    const uint32_t y = min((uint32_t)(int)__builtin_fmaf(by, tk[k], ay), my);
+                    const uint32_t z = min((uint32_t)(int)__builtin_fmaf(bz, tk[k], az), mz);
+                    bnd[k] = grid.bound[(z * (uint32_t)grid.cy + y) * (uint32_t)grid.cx + x];
+                }
 #pragma unroll
                 for (int k = 0; k < B; ++k) need[k] = need[k] && !(bnd[k] < px.thr);
             }
 #pragma unroll
             for (int k = 0; k < B; ++k) {
                 dens[k] = 0.f;
-                if (need[k] || (INSTR != 2 && !cull)) dens[k] = vol.linear(sk[k].x, sk[k].y, sk[k].z);
+                if (need[k] || (INSTR != 2 && !cull))
+                    dens[k] = vol.linear(pk[k].x * 0.5f + 0.5f, pk[k].y * 0.5f + 0.5f, pk[k].z * 0.5f + 0.5f);
             }
+            // (the opacity only matters where the step was fetched: :432 below tests `need` first)
 #pragma unroll
-            for (int k = 0; k < B; ++k) al[k] = tff_linear_alpha(s_tff, tffn, dens[k]);
+            for (int k = 0; k < B; ++k) al[k] = (need[k] || !cull) ? tff_linear_alpha(s_tff, tffn, dens[k]) : 0.f;
             // the walk's exit conditions, in step order
             bool run = walking;
 #pragma unroll
