@@ -897,10 +897,24 @@ VR_DEV void flush_counters(DevStats *stats, uint32_t lane, const unsigned long l
 
 // ------------------------------------------------------------------ patch culling
 
+// maximum over the 64 lanes (all of them active), in every lane: six DPP steps -- row_shr 1, 2, 4, 8 leave
+// each row's maximum in its lane 15, row_bcast15 / row_bcast31 carry it on to lane 63 -- and a readlane
+template <int CTRL, int ROW_MASK>
+VR_DEV float dpp_max_step(float v)
+{
+    // lanes without a source (and rows outside ROW_MASK) keep their own value: `old` = v
+    const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+    return vmax(v, o);
+}
 VR_DEV float wave_max_f(float v)
 {
-    for (int off = 32; off > 0; off >>= 1) v = vmax(v, __shfl_xor(v, off, 64));
-    return v;
+    v = dpp_max_step<0x111, 0xf>(v);   // row_shr:1
+    v = dpp_max_step<0x112, 0xf>(v);   // row_shr:2
+    v = dpp_max_step<0x114, 0xf>(v);   // row_shr:4
+    v = dpp_max_step<0x118, 0xf>(v);   // row_shr:8
+    v = dpp_max_step<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v = dpp_max_step<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // True when NO ray of the wave's 8x8 patch can visit a brick that is not skipped (SkipView::near_bits).
