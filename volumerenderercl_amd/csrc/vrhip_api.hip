@@ -652,10 +652,12 @@ int ensure_cells(vrhip_renderer *r, bool need_bound, bool need_empty)
                                         make_tf_view(r), r->cell_sparse, nullptr, r->cell_empty, r->stream));
         r->cells_have_empty = true;
         g.empty = r->cell_empty;
-        // the empty bits per ESS brick, for the march kernel (ESS bricks of >= 4 voxels per axis)
+        // the empty bits per ESS brick, for the march kernel (ESS bricks of >= 4 voxels per axis); only
+        // the opt-in kernels read them (VRHIP_MARCH, leap stepping), so the default path does not pay the
+        // 0.2 ms per transfer-function change
         g.bmask = nullptr;
         g.bex = g.bey = g.bez = 0;
-        if (r->bricks_valid) {
+        if (r->bricks_valid && (r->march || r->march_micro)) {
             int lg[3];
             bool ok = true;
             for (int i = 0; i < 3; ++i) {
