@@ -140,11 +140,16 @@ int vrhip_set_round_budget(vrhip_renderer *r, uint32_t rounds);
 /* Frames in flight: renderer `r` (same device) renders from `owner`'s voxels and ESS bricks
  * instead of holding copies -- everything else (transfer function, parameters, frame and scratch
  * buffers, footprint volume, stream) is its own, so two renderers on two streams can
- * have one frame each in flight over one 8 GiB volume.  The owner must keep its volumes (no upload,
- * clear or destroy) while they are shared; `r` gives them back with vrhip_clear_volumes or by
- * uploading its own.  vrhip_build_bricks on `r` keeps the shared bricks, and on the owner it
- * never moves them: a brick grid is allocated once per time step and rebuilt only after that
- * step's voxels were uploaded again, so transfer-function edits on either renderer are safe. */
+ * have one frame each in flight over one 8 GiB volume.  The owner keeps a list of its sharers:
+ * when it clears its volumes, is destroyed, or uploads a volume of another size or a new time step,
+ * the sharers are detached first (they wait for their streams, drop the borrowed volumes and answer
+ * "No volume data is loaded." until they share again); an upload into an existing time step of the
+ * same size overwrites the shared voxels in place after the sharers' streams have drained, and the
+ * sharers rebuild what they had derived from them (the owner calls vrhip_build_bricks first).  `r`
+ * gives the volumes back with vrhip_clear_volumes or by uploading its own.  vrhip_build_bricks on `r`
+ * takes the owner's bricks, and on the owner it never moves them: a brick grid is allocated once per
+ * time step and rebuilt only after that step's voxels were uploaded again, so transfer-function edits
+ * on either renderer are safe. */
 int vrhip_share_volumes(vrhip_renderer *r, vrhip_renderer *owner);
 int vrhip_clear_volumes(vrhip_renderer *r);
 /* setTimestep (volumerendercl.cpp:1167-1174) */

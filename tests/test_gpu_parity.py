@@ -3,6 +3,8 @@ seeded inputs.  Bar: <= 1e-4 per channel (north_star); the kernels execute the o
 fp32 operation sequences, so the observed difference is expected to be exactly 0 and the
 integer work counters must match bit for bit.
 """
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -1605,3 +1607,111 @@ def test_batch_with_the_maximum_number_of_frames(vr):
         assert np.array_equal(got[f], vr.runRaycastNoGL(W, H)), "frame %d" % f
     with pytest.raises(ValueError):
         vr.render_batch(W, H, seeds + [1], out.data_ptr())
+
+
+def test_anisotropic_grid_samples_before_the_entry_face(monkeypatch):
+    """real samples near tnear lie up to 2 |voxLen| BEFORE the entry face (t - offset,
+    volumeraycast.cl:733 / :791) and are fetched clamp-to-edge.  On a 256 x 256 x 32 grid that is up
+    to ~8 texels in x: two cells of four voxels below 0.  The empty-cell lookahead has to clamp such a
+    position to the NEAR border cell (data touching the x = 0 face), not to the far one (empty here)."""
+    X, Y, Z = 256, 256, 32
+    zz, yy, xx = np.meshgrid(np.linspace(-1, 1, Z), np.linspace(-1, 1, Y), np.linspace(-1, 1, X), indexing="ij")
+    f = 0.55 + 0.4 * np.cos(9 * xx) * np.cos(7 * yy + 1) * np.cos(5 * zz + 2)
+    f[:, :, X // 2:] = 0.0                       # the far half (and its border cells) is exactly empty
+    vol = np.round(np.clip(f, 0, 1) * 255).astype(np.uint8)
+    assert vol[:, :, 0].min() > 0                # data on the x = 0 face
+    tff = common.tffs()["default"]
+    # camera on the -x side: the rays enter through the x = 0 face
+    view = frontend.view_matrix(frontend.quat_from_axis_angle((0, 1, 0), -88.0), (0.0, 0.0, 2.0))
+    W, H = 160, 120
+    monkeypatch.setenv("VRHIP_EMPTY_SKIP", "1")
+    r2 = VolumeRenderCL()
+    r2.initialize()
+    try:
+        for ess in (True, False):
+            for seed in (SEED, 581869302):
+                _setup(r2, vol, UCHAR, tff, view, ess=ess, seed=seed)
+                _compare(r2, vol, UCHAR, tff, W, H, ess=ess)
+    finally:
+        r2.close()
+
+
+def test_same_signature_kernels_get_their_own_launch_cache_entries():
+    """vr_prepare_kernel caches blocks/CU (and raises the dynamic-LDS limit) per kernel
+    ADDRESS; instantiations that share a function-pointer type (phase 1 / phase 2, INSTR / FP / XS
+    variants) must not share an entry.  VRHIP_DEBUG prints one line per new entry."""
+    import os
+    import re
+    import subprocess
+    import sys
+    code = r"""
+import numpy as np
+from tests import common
+from volumerenderercl_amd import UCHAR, VolumeRenderCL
+vr = VolumeRenderCL(); vr.initialize()
+vol = common.noise_volume((48, 48, 48), UCHAR, seed=3, smooth=False)
+vr.loadVolumeArrays([vol], UCHAR)
+big = np.repeat(common.tffs()["default"].reshape(-1, 4), 4, axis=0).reshape(-1)   # 4096 entries: 64 KiB of LDS
+for tff in (common.tffs()["default"], big):
+    vr.setTransferFunction(tff)
+    vr.updateView(common.views()["rot30"])
+    for stats in (False, True):
+        for contours in (False, True):
+            vr.setStatsEnabled(stats); vr.setContours(contours); vr.setSeed(7); vr.setIteration(0)
+            vr.runRaycastNoGL(64, 64)
+vr.close()
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, VRHIP_DEBUG="1"),
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    entries = re.findall(r"\[vrhip\] (.+?) @(0x[0-9a-f]+): device (\d+), lds=(\d+) B", p.stderr)
+    assert entries, p.stderr[-2000:]
+    keys = [(a, d, l) for _, a, d, l in entries]
+    assert len(keys) == len(set(keys))           # one line per (kernel, device, LDS size)
+    by_sig = {}
+    for what, addr, dev, lds in entries:
+        by_sig.setdefault((what, dev, lds), set()).add(addr)
+    # phase 1 and phase 2 (and the instrumented / XS instantiations) are different kernels behind
+    # one description and LDS size: every one of them has to show up
+    assert max(len(v) for v in by_sig.values()) >= 2, entries
+    assert len({a for _, a, _, _ in entries}) >= 4, entries
+
+
+def test_owner_going_away_detaches_its_sharers(vr):
+    """a sharing renderer dereferenced its owner on every frame.  Destroying / clearing /
+    re-sizing the owner now detaches the sharers first: they answer "No volume data is loaded." instead
+    of reading freed host and device memory; an in-place upload of the same size reaches them."""
+    vol = common.noise_volume((40, 36, 32), UCHAR, seed=31, smooth=False)
+    tff = common.tffs()["default"]
+    W, H = 64, 48
+    owner = VolumeRenderCL()
+    owner.initialize()
+    _setup(owner, vol, UCHAR, tff, common.views()["rot30"])
+    twin = owner.shareVolumes()
+    try:
+        twin.setSeed(SEED)
+        twin.setIteration(0)
+        a = twin.runRaycastNoGL(W, H)
+        twin.setIteration(0)
+        ref, _, _ = common.oracle_frame(twin, vol, UCHAR, tff, W, H)
+        np.testing.assert_array_equal(a, ref)
+        # in-place upload of other voxels of the same size: the twin renders the new ones
+        vol2 = common.noise_volume((40, 36, 32), UCHAR, seed=32, smooth=True)
+        owner._check(owner._lib.vrhip_upload_volume(owner._h, vol2.ctypes.data, (ctypes.c_uint32 * 3)(40, 36, 32),
+                                                    UCHAR, 0))
+        owner.setTransferFunction(tff)           # rebuilds the owner's bricks
+        twin.setTransferFunction(tff)            # the twin takes them and rebuilds what it derived
+        twin.setSeed(SEED)
+        twin.setIteration(0)
+        b = twin.runRaycastNoGL(W, H)
+        twin.setIteration(0)
+        ref2, _, _ = common.oracle_frame(twin, vol2, UCHAR, tff, W, H)
+        np.testing.assert_array_equal(b, ref2)
+        assert np.abs(ref2 - ref).max() > 0.01
+        owner.close()                            # the twin is detached, not dangling
+        with pytest.raises(RuntimeError, match="No volume data"):
+            twin.runRaycastNoGL(W, H)
+    finally:
+        twin.close()
+        owner.close()

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <tuple>
 #include <utility>
 
 #include "../../include/vrhip.h"
@@ -271,19 +272,20 @@ hipError_t vr_launch_retile(const VolView &vol, int format, const void *dense, i
 
 // Blocks per CU of `kernel` (block_dim threads, `lds` bytes of dynamic LDS), after raising the
 // kernel's dynamic LDS limit where needed.  Both are per device (hipFuncSetAttribute acts on the
-// current device's copy of the function), so the answers are cached per (device, LDS size) of
-// each kernel instantiation, under a lock: renderers on several devices or host threads share
-// this code.
+// current device's copy of the function), so the answers are cached per (kernel address, device,
+// LDS size), under a lock: renderers on several devices or host threads share this code.  The
+// kernel's address is part of the key because the function-local statics exist once per pointer
+// TYPE K, and many instantiations (ESS / INSTR / XS / FP variants) share one signature.
 template <typename K>
 hipError_t vr_prepare_kernel(K kernel, int block_dim, size_t lds, int *nb_out, const char *what, int num_cus)
 {
     static std::mutex mu;
-    static std::map<std::pair<int, size_t>, int> cache;
+    static std::map<std::tuple<const void *, int, size_t>, int> cache;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     std::lock_guard<std::mutex> lock(mu);
-    const auto key = std::make_pair(dev, lds);
+    const auto key = std::make_tuple((const void *)kernel, dev, lds);
     const auto it = cache.find(key);
     if (it != cache.end()) { *nb_out = it->second; return hipSuccess; }
     if (lds > 48 * 1024) {
@@ -298,7 +300,8 @@ hipError_t vr_prepare_kernel(K kernel, int block_dim, size_t lds, int *nb_out, c
         if (v > 0) nb = v;
     }
     if (getenv("VRHIP_DEBUG"))
-        fprintf(stderr, "[vrhip] %s: device %d, lds=%zu B, blocks/CU=%d, CUs=%d\n", what, dev, lds, nb, num_cus);
+        fprintf(stderr, "[vrhip] %s @%p: device %d, lds=%zu B, blocks/CU=%d, CUs=%d\n", what, (const void *)kernel, dev,
+                lds, nb, num_cus);
     cache[key] = nb;
     *nb_out = nb;
     return hipSuccess;

@@ -208,14 +208,13 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
                 const float ax = __builtin_fmaf(px.org.x, hx, hx), bx = px.wdir.x * hx;
                 const float ay = __builtin_fmaf(px.org.y, hy, hy), by = px.wdir.y * hy;
                 const float az = __builtin_fmaf(px.org.z, hz, hz), bz = px.wdir.z * hz;
-                const uint32_t mx = (uint32_t)grid.cx - 1u, my = (uint32_t)grid.cy - 1u, mz = (uint32_t)grid.cz - 1u;
+                const int mx = grid.cx - 1, my = grid.cy - 1, mz = grid.cz - 1;
                 float bnd[B];
 #pragma unroll
                 for (int k = 0; k < B; ++k) {
-                    // (int) truncates: (-1, 0) -> 0; anything below wraps to a large unsigned and clamps
-                    const uint32_t x = min((uint32_t)(int)__builtin_fmaf(bx, tk[k], ax), mx);
-                    const uint32_t y = min((uint32_t)(int)__builtin_fmaf(by, tk[k], ay), my);
-                    const uint32_t z = min((uint32_t)(int)__builtin_fmaf(bz, tk[k], az), mz);
+                    const uint32_t x = (uint32_t)iclamp((int)__builtin_fmaf(bx, tk[k], ax), 0, mx);
+                    const uint32_t y = (uint32_t)iclamp((int)__builtin_fmaf(by, tk[k], ay), 0, my);
+                    const uint32_t z = (uint32_t)iclamp((int)__builtin_fmaf(bz, tk[k], az), 0, mz);
                     bnd[k] = grid.bound[(z * (uint32_t)grid.cy + y) * (uint32_t)grid.cx + x];
                 }
 #pragma unroll

@@ -479,8 +479,8 @@ constexpr int kLook1 = VR_LOOK1, kLook2 = VR_LOOK2;
 // linearisation's error, which is far below half a texel -- and the voxels x0, x0 + 1 the fetch reads
 // lie in [x' - 1, x' + 1], inside the extent [E c - 1, E c + E + 1] the cell of x' answers for (the
 // halo is there for exactly this).  Three instructions per axis and sample, no voxel access.
-// Positions outside the volume (speculative samples past the ray's end, whose bits nobody reads)
-// clamp to a cell inside.
+// Positions outside the volume (samples before the entry face, speculative samples past the ray's
+// end) clamp to the nearest border cell, like the fetch's clamp-to-edge addressing.
 template <typename VT, int INSTR, int kLook, typename V>
 VR_DEV uint32_t empty_mask(const CellView &cv, const V &vol, const RayCtx &c, float t0)
 {
@@ -493,15 +493,18 @@ VR_DEV uint32_t empty_mask(const CellView &cv, const V &vol, const RayCtx &c, fl
     const float du = (c.dir.x * c.stepSize) * (0.5f * su);
     const float dv = (c.dir.y * c.stepSize) * (0.5f * sv);
     const float ds = (c.dir.z * c.stepSize) * (0.5f * ss);
-    const uint32_t mx = (uint32_t)cv.ecx - 1u, my = (uint32_t)cv.ecy - 1u, mz = (uint32_t)cv.ecz - 1u;
+    const int mx = cv.ecx - 1, my = cv.ecy - 1, mz = cv.ecz - 1;
     uint32_t w[kLook], sh[kLook];
 #pragma unroll
     for (int k = 0; k < kLook; ++k) {
         const float fk = (float)k;
-        // (int) truncates: (-1, 0) -> 0; anything below wraps to a large unsigned and clamps like the far side
-        const uint32_t x = min((uint32_t)(int)__builtin_fmaf(fk, du, u0), mx);
-        const uint32_t y = min((uint32_t)(int)__builtin_fmaf(fk, dv, v0), my);
-        const uint32_t z = min((uint32_t)(int)__builtin_fmaf(fk, ds, s0), mz);
+        // Signed clamp (one v_med3_i32): real samples near tnear lie up to 2 |voxLen| BEFORE the entry
+        // face (t - offset, :733 / :791) and are fetched clamp-to-edge, i.e. they read column 0 -- on an
+        // anisotropic grid that is several cells below 0, and an unsigned clamp would send them to the
+        // far border's cell.
+        const uint32_t x = (uint32_t)iclamp((int)__builtin_fmaf(fk, du, u0), 0, mx);
+        const uint32_t y = (uint32_t)iclamp((int)__builtin_fmaf(fk, dv, v0), 0, my);
+        const uint32_t z = (uint32_t)iclamp((int)__builtin_fmaf(fk, ds, s0), 0, mz);
         const uint32_t idx = (z * (uint32_t)cv.ecy + y) * (uint32_t)cv.ecx + x;
         w[k] = cv.empty[idx >> 5];
         sh[k] = idx & 31u;

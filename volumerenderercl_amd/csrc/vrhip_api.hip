@@ -126,6 +126,8 @@ struct vrhip_renderer {
     bool fp_active = false;           // this frame reads it
     const void *fp_use = nullptr;     // what this frame reads: the renderer's own `fp` or its owner's
     vrhip_renderer *vol_owner = nullptr;   // vrhip_share_volumes: whose voxels (and footprint volume) this renderer renders from
+    std::vector<vrhip_renderer *> sharers; // the renderers that render from THIS one's voxels (their vol_owner is this)
+    size_t fp_failed_bytes = 0;       // a footprint allocation of this size failed: not retried until the volume or the cap changes
     bool use_fp = true;               // VRHIP_NO_FOOTPRINT=1 disables
     size_t fp_max_bytes = (size_t)96 << 30;   // VRHIP_FOOTPRINT_MAX_GB
     float4 *env = nullptr;            // environment map (float RGBA), or nullptr
@@ -336,6 +338,17 @@ int set_device(const vrhip_renderer *r)
     return VRHIP_OK;
 }
 
+// Sharers of `owner` lose their (borrowed) volumes: nothing of theirs points into the owner any more.
+void detach_sharers(vrhip_renderer *owner)
+{
+    std::vector<vrhip_renderer *> list;
+    list.swap(owner->sharers);
+    for (vrhip_renderer *sh : list) {
+        sh->vol_owner = nullptr;           // (so that clearing does not look for itself in `owner->sharers`)
+        (void)vrhip_clear_volumes(sh);     // waits for the sharer's stream; borrowed slots are not freed
+    }
+}
+
 // (re)allocate a slot for `timestep`, checking that res/format agree with other timesteps
 int prepare_slot(vrhip_renderer *r, const uint32_t res[3], int format, uint32_t timestep,
                  VolumeSlot **slot, int channels = 1)
@@ -359,6 +372,24 @@ int prepare_slot(vrhip_renderer *r, const uint32_t res[3], int format, uint32_t 
         r->channels = channels;
         set_layout(r);
     }
+    // Renderers that share these voxels hold copies of the slots' device pointers.  A slot that is
+    // overwritten in place keeps its pointers: the sharers finish what they have in flight and drop
+    // everything they derived from the old voxels.  A new time step would outgrow their slot lists, so
+    // they are detached (they report "No volume data is loaded." until they share again).
+    if (!r->sharers.empty()) {
+        if (r->vols.size() <= timestep || !r->vols[timestep].dev) detach_sharers(r);
+        for (vrhip_renderer *sh : r->sharers) {
+            VR_HIP(r, hipStreamSynchronize(sh->stream));
+            sh->skip_dirty = true;
+            sh->pt_dirty = true;
+            sh->cells_have_bound = sh->cells_have_empty = false;
+            sh->bricks_valid = false;
+            if (timestep < sh->vols.size()) {
+                sh->vols[timestep].pt_minmax_valid = false;
+                sh->vols[timestep].fine_minmax_valid = false;
+            }
+        }
+    }
     if (r->vols.size() <= timestep) r->vols.resize(timestep + 1);
     VolumeSlot &s = r->vols[timestep];
     if (!s.dev) VR_HIP(r, hipMalloc(&s.dev, volume_alloc_bytes(r)));
@@ -369,6 +400,7 @@ int prepare_slot(vrhip_renderer *r, const uint32_t res[3], int format, uint32_t 
     r->skip_dirty = true;
     r->pt_dirty = true;
     r->fp_valid = false;
+    r->fp_failed_bytes = 0;
     s.pt_minmax_valid = false;
     s.fine_minmax_valid = false;
     *slot = &s;
@@ -485,16 +517,22 @@ int ensure_footprint(vrhip_renderer *r)
             if (r->fp_candidate != r->timestep) { r->fp_candidate = r->timestep; r->fp_candidate_frames = 0; }
             if (++r->fp_candidate_frames < 3u) return VRHIP_OK;
         }
-        // (renderers that share this one's volumes may be reading the old one on their own streams)
-        VR_HIP(r, hipDeviceSynchronize());
+        if (bytes == r->fp_failed_bytes) return VRHIP_OK;   // this allocation failed before: plain layout
+        // renderers that share this one's volumes may be reading the old one on their own streams
+        if (r->fp)
+            for (vrhip_renderer *sh : r->sharers) VR_HIP(r, hipStreamSynchronize(sh->stream));
         r->fp_valid = false;
         if (bytes > r->fp_cap) {
-            if (r->fp) VR_HIP(r, hipFree(r->fp));
+            if (r->fp) {
+                VR_HIP(r, hipStreamSynchronize(r->stream));
+                VR_HIP(r, hipFree(r->fp));
+            }
             r->fp = nullptr;
             r->fp_cap = 0;
             if (hipMalloc(&r->fp, bytes) != hipSuccess) {   // not enough HBM left: plain layout
                 (void)hipGetLastError();
                 r->fp = nullptr;
+                r->fp_failed_bytes = bytes;   // (reset by a new volume or a new cap)
                 return VRHIP_OK;
             }
             r->fp_cap = bytes;
@@ -1013,7 +1051,7 @@ int vrhip_create(int device_id, vrhip_renderer **out)
     }
     if (const char *e = getenv("VRHIP_FOOTPRINT_MAX_GB")) {
         const double gb = atof(e);
-        if (gb >= 0.0) r->fp_max_bytes = (size_t)(gb * 1073741824.0);
+        if (gb >= 0.0) r->fp_max_bytes = (size_t)(gb * 1073741824.0);   // (fp_failed_bytes starts at 0)
     }
     r->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     r->devname = std::string(prop.name) + " (" + prop.gcnArchName + ")";
@@ -1263,6 +1301,8 @@ int vrhip_clear_volumes(vrhip_renderer *r)
     if (!r) return VRHIP_ERR_INVALID;
     (void)hipSetDevice(r->device);
     (void)hipStreamSynchronize(r->stream);
+    // renderers that render from these voxels (vrhip_share_volumes) stop doing so before they are freed
+    detach_sharers(r);
     for (VolumeSlot &s : r->vols) {
         if (!s.borrowed) {
             if (s.dev) (void)hipFree(s.dev);
@@ -1275,7 +1315,12 @@ int vrhip_clear_volumes(vrhip_renderer *r)
     }
     r->vols.clear();
     r->fp_valid = false;
-    r->vol_owner = nullptr;
+    r->fp_failed_bytes = 0;
+    if (r->vol_owner) {   // a sharer leaves its owner's list
+        std::vector<vrhip_renderer *> &v = r->vol_owner->sharers;
+        v.erase(std::remove(v.begin(), v.end(), r), v.end());
+        r->vol_owner = nullptr;
+    }
 
     r->bricks_valid = false;
     r->skip_dirty = true;
@@ -1332,6 +1377,7 @@ int vrhip_share_volumes(vrhip_renderer *r, vrhip_renderer *owner)
     r->timestep = owner->timestep < r->vols.size() ? owner->timestep : 0;
     r->fp_valid = false;   // (its own footprint volume is not used while it shares: ensure_footprint)
     r->vol_owner = owner;
+    owner->sharers.push_back(r);
     r->skip_dirty = true;
     r->pt_dirty = true;
     return VRHIP_OK;
@@ -1425,10 +1471,17 @@ int vrhip_build_bricks(vrhip_renderer *r)
     // the pointer: an allocation is made once per slot and lives as long as the voxels do, and a
     // slot whose voxels have not changed since its last build is left alone (the reference
     // rebuilds on every setTransferFunction, :877 -- same values).
-    for (VolumeSlot &s : r->vols) {
+    for (size_t t = 0; t < r->vols.size(); ++t) {
+        VolumeSlot &s = r->vols[t];
         if (!s.dev) return fail(r, VRHIP_ERR_NODATA,
                                 "Error loading timeseries data: size mismatch.");   // :227
-        if (s.borrowed) continue;   // shared voxels come with their bricks (they depend on nothing else)
+        if (s.borrowed) {   // shared voxels come with their bricks (they depend on nothing else)
+            const vrhip_renderer *o = r->vol_owner;
+            VR_REQUIRE(r, o && t < o->vols.size() && o->vols[t].bricks && o->vols[t].bricks_built, VRHIP_ERR_NODATA,
+                       "vrhip_build_bricks: the owner of the shared volumes has to build its bricks first.");
+            s.bricks = o->vols[t].bricks;
+            continue;
+        }
         if (!s.bricks) {
             VR_HIP(r, hipMalloc(&s.bricks, bricks_bytes(r)));
             s.bricks_built = false;
