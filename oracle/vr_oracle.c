@@ -937,6 +937,24 @@ static float hybrid_rand(uint32_t st[4])
     return (float)(2.3283064365387e-10 * (double)(float)(a ^ b ^ c ^ d));
 }
 
+/* the three above and the box-edge test below as the reference exposes them, for the pin against
+ * the compiled volumeraycast.cl (tests/test_oracle_golden.py, oracle/_ref/libref_kernel.so) */
+uint32_t vro_ui_rand_step(uint32_t st[4], uint32_t p, int s1, int s2, int s3, uint32_t m)
+{
+    /* ui_randStep, :50-64: component p of the state (p > 2: locZ is never assigned in the
+     * reference -- undefined, not called that way) */
+    return p < 3 ? taus_step(&st[p], s1, s2, s3, m) : 0u;
+}
+
+uint32_t vro_lcg_step(uint32_t st[4], uint32_t a, uint32_t c)
+{
+    uint32_t old = st[3]; /* lcgStep, :67-72 */
+    st[3] = a * st[3] + c;
+    return old;
+}
+
+float vro_hybrid_rand(uint32_t st[4]) { return hybrid_rand(st); }
+
 /* getUniformRandomSampleDirectionUpper, :353-364 */
 static f3 ao_sample_dir(f3 n, uint32_t st[4])
 {
@@ -1003,6 +1021,11 @@ static int check_bounding_box(f3 pos, f3 voxLen, float b0, float b1)
            (pos.x > 1.f - voxLen.x && pos.y < voxLen.y) ||
            (pos.x > 1.f - voxLen.x && pos.y > 1.f - voxLen.y) ||
            (pos.x < voxLen.x && pos.y > 1.f - voxLen.y);
+}
+
+int vro_check_bounding_box(const float pos[3], const float voxLen[3], float b0, float b1)
+{
+    return check_bounding_box(mk3(pos[0], pos[1], pos[2]), mk3(voxLen[0], voxLen[1], voxLen[2]), b0, b1);
 }
 
 /* getLastHit (:513-526): 3x3 sum around the work-group; reads outside the image (undefined for

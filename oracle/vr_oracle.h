@@ -97,6 +97,13 @@ uint32_t vro_parallel_rng(uint32_t x);
 uint32_t vro_parallel_rng3(uint32_t x, uint32_t y, uint32_t z);
 float vro_map_uint_float(uint32_t v);
 
+/* hybrid Tausworthe / LCG generator behind calcAO (volumeraycast.cl:50-80) and the box-edge test
+ * behind showEss (:323-343): exported for the pin against the compiled reference kernel file */
+uint32_t vro_ui_rand_step(uint32_t st[4], uint32_t p, int s1, int s2, int s3, uint32_t m);
+uint32_t vro_lcg_step(uint32_t st[4], uint32_t a, uint32_t c);
+float vro_hybrid_rand(uint32_t st[4]);
+int vro_check_bounding_box(const float pos[3], const float voxLen[3], float b0, float b1);
+
 /* volumeraycast.cl:122-142. Returns hit flag. */
 int vro_intersect_bbox(const float orig[3], const float dir[3], const float lower[3],
                        const float upper[3], float *tnear, float *tfar);

@@ -63,7 +63,7 @@ def build(force=False):
             os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "vr_oracle.c"))):
         subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference/src") and not os.path.exists(
-            os.path.join(_HERE, "_ref", "libref_hdr.so")):
+            os.path.join(_HERE, "_ref", "libref_kernel.so")):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
 
 
@@ -110,6 +110,15 @@ def lib():
         L.vro_atan2f.argtypes = [C.c_float, C.c_float]
         L.vro_acosf.restype = C.c_float
         L.vro_acosf.argtypes = [C.c_float]
+        U4 = C.POINTER(C.c_uint32)
+        L.vro_ui_rand_step.restype = C.c_uint32
+        L.vro_ui_rand_step.argtypes = [U4, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_uint32]
+        L.vro_lcg_step.restype = C.c_uint32
+        L.vro_lcg_step.argtypes = [U4, C.c_uint32, C.c_uint32]
+        L.vro_hybrid_rand.restype = C.c_float
+        L.vro_hybrid_rand.argtypes = [U4]
+        L.vro_check_bounding_box.restype = C.c_int
+        L.vro_check_bounding_box.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float]
         _lib = L
     return _lib
 

@@ -81,3 +81,91 @@ def test_view_matrix_against_an_independent_composition():
         np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-6)
     # the default camera of SURVEY 8(d): rot = identity, translation (0, 0, 2)
     assert frontend.view_matrix() == [2, 0, 0, 0, 0, 2, 0, 0, 0, 0, 2, 2, 0, 0, 0, 1]
+
+
+# ---- transfer-function table from gradient stops: known answers derived by hand ----------
+#
+# Semantics (Qt 5 sources, restated from their documented behaviour; Qt is not installed here):
+#  * updateTransferFunction (volumerenderwidget.cpp:916-938): duration 8192, entry i is sampled at
+#    currentTime = qRound(i / 1024 * 8192) = 8 i, i.e. progress = easing(i / 1024) -- exact in binary;
+#  * QVariantAnimation: the key values either side of `progress` give localProgress = (progress - start)
+#    / (end - start) in double; QColor is interpolated per channel with _q_interpolate<int>:
+#    int(f + (t - f) * localProgress) -- truncation, no rounding -- bounded to [0, 255];
+#  * every channel then max(0, c - 3) (:933-936).
+# Default stops (transferfunctionwidget.cpp:340-343): 0 -> (0,0,0,0), 0.1 -> (125,125,125,0),
+# 1 -> (0,0,0,255).  Worked by hand, e.g.
+#  i = 102: progress 0.099609375 < 0.1 -> local 0.99609375: 125 * 0.99609375 = 124.51 -> 124 -> 121
+#  i = 103: progress 0.1005859375 -> local 0.0005859375 / 0.9 = 0.000651: 125 - 0.081 = 124.92 -> 124 -> 121,
+#           alpha 255 * 0.000651 = 0.166 -> 0 -> 0
+#  i = 512: local 0.4 / 0.9 = 0.4444: 125 - 55.56 = 69.44 -> 69 -> 66; alpha 113.33 -> 113 -> 110
+#  i = 1000: local 0.8765625 / 0.9 = 0.973958: 125 - 121.745 = 3.255 -> 3 -> 0; alpha 248.36 -> 248 -> 245
+#  i = 1023: local 0.8990234375 / 0.9 = 0.998915: 0.136 -> 0 -> 0; alpha 254.72 -> 254 -> 251
+TFF_KATS_DEFAULT = {0: (0, 0, 0, 0), 1: (0, 0, 0, 0), 4: (1, 1, 1, 0), 51: (59, 59, 59, 0), 102: (121, 121, 121, 0),
+                    103: (121, 121, 121, 0), 512: (66, 66, 66, 110), 1000: (0, 0, 0, 245), 1023: (0, 0, 0, 251)}
+# Four stops, two of them hit exactly by a sample (progress == stop position returns the stop's colour):
+#  i = 100: local 0.390625 in [0, 0.25]: 10 + 93.75 = 103.75 -> 103; 20 - 7.8125 = 12.19 -> 12; 30 + 27.34 = 57.34 -> 57
+#  i = 384: local 0.5 in [0.25, 0.5]: 150, 100, 100, 40 + 107.5 = 147.5 -> 147
+#  i = 768: local 0.5 in [0.5, 1]: 152.5 -> 152, 227.5 -> 227, 177.5 -> 177, 127.5 -> 127
+#  i = 1023: local 0.998046875: 254.60 -> 254, 254.89 -> 254, 254.70 -> 254, 0.498 -> 0
+STOPS4 = [(0.0, (10, 20, 30, 40)), (0.25, (250, 0, 100, 40)), (0.5, (50, 200, 100, 255)), (1.0, (255, 255, 255, 0))]
+TFF_KATS_STOPS4 = {0: (7, 17, 27, 37), 100: (100, 9, 54, 37), 128: (127, 7, 62, 37), 256: (247, 0, 97, 37),
+                   384: (147, 97, 97, 144), 512: (47, 197, 97, 252), 768: (149, 224, 174, 124), 1023: (251, 251, 251, 0)}
+# Easing curves on the default stops (QEasingCurve InOutQuad / InOutCubic, mainwindow.cpp:945-957):
+#  quad  i = 256: t = 0.5 -> 0.5 * 0.5 / 2 = 0.125 -> local 0.025 / 0.9: 121.53 -> 121 -> 118; alpha 7.08 -> 7 -> 4
+#  quad  i = 768: t = 1.5 - 1 = 0.5 -> -0.5 (0.5 (0.5 - 2) - 1) = 0.875 -> local 0.86111: 17.36 -> 17 -> 14; 219.58 -> 219 -> 216
+#  cubic i = 256: 0.5 * 0.125 = 0.0625 -> local 0.625: 78.125 -> 78 -> 75; alpha 0
+#  cubic i = 768: t = -0.5 -> 0.5 (-0.125 + 2) = 0.9375 -> local 0.930556: 8.68 -> 8 -> 5; alpha 237.29 -> 237 -> 234
+TFF_KATS_EASING = {("quad", 256): (118, 118, 118, 4), ("quad", 768): (14, 14, 14, 216),
+                   ("cubic", 256): (75, 75, 75, 0), ("cubic", 768): (5, 5, 5, 234),
+                   ("quad", 0): (0, 0, 0, 0), ("cubic", 512): (66, 66, 66, 110), ("quad", 512): (66, 66, 66, 110)}
+
+
+def test_tff_from_stops_known_answers():
+    t = frontend.tff_from_stops()
+    assert t.shape == (1024, 4) and t.dtype == np.uint8
+    for i, want in TFF_KATS_DEFAULT.items():
+        assert tuple(int(v) for v in t[i]) == want, i
+    t4 = frontend.tff_from_stops(STOPS4)
+    for i, want in TFF_KATS_STOPS4.items():
+        assert tuple(int(v) for v in t4[i]) == want, i
+    for (easing, i), want in TFF_KATS_EASING.items():
+        assert tuple(int(v) for v in frontend.tff_from_stops(easing=easing)[i]) == want, (easing, i)
+    # setKeyValueAt replaces an earlier key at the same position
+    dup = frontend.tff_from_stops([(0.0, (9, 9, 9, 9)), (0.0, (10, 20, 30, 40))] + STOPS4[1:])
+    np.testing.assert_array_equal(dup, t4)
+    # the table is monotone where the stops are: alpha of the default table never decreases
+    assert (np.diff(t[:, 3].astype(int)) >= 0).all()
+
+
+def test_cpp_host_tff_from_stops_known_answers(tmp_path):
+    """The headless C++ host's twin of the same formula (vrhip_render --dump-tf: no GPU involved),
+    against the same hand-derived values and, entry for entry, against the Python front end."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "volumerenderercl_amd", "vrhip_render")
+    if not os.path.exists(exe):
+        pytest.skip("vrhip_render not built")
+
+    def dump(*args):
+        out = tmp_path / "tf.bin"
+        subprocess.run([exe, "--dump-tf", str(out)] + list(args), check=True, timeout=60)
+        return np.fromfile(str(out), dtype=np.uint8).reshape(-1, 4)
+
+    t = dump()
+    for i, want in TFF_KATS_DEFAULT.items():
+        assert tuple(int(v) for v in t[i]) == want, i
+    np.testing.assert_array_equal(t, frontend.tff_from_stops())
+    p = tmp_path / "s4.tff"
+    frontend.write_tff_stops(str(p), STOPS4)
+    t4 = dump("--tf-stops", str(p))
+    for i, want in TFF_KATS_STOPS4.items():
+        assert tuple(int(v) for v in t4[i]) == want, i
+    np.testing.assert_array_equal(t4, frontend.tff_from_stops(STOPS4))
+    for easing in ("quad", "cubic"):
+        te = dump("--tf-easing", easing)
+        for (e, i), want in TFF_KATS_EASING.items():
+            if e == easing:
+                assert tuple(int(v) for v in te[i]) == want, (e, i)
+        np.testing.assert_array_equal(te, frontend.tff_from_stops(easing=easing))
+        np.testing.assert_array_equal(dump("--tf-stops", str(p), "--tf-easing", easing),
+                                      frontend.tff_from_stops(STOPS4, easing=easing))

@@ -141,3 +141,90 @@ def test_prefix_sum():
     tff = np.zeros((1024, 4), np.uint8)
     tff[:, 3] = np.arange(1024) % 251
     np.testing.assert_array_equal(vro.prefix_sum(tff), np.cumsum(tff[:, 3].astype(np.uint32)))
+
+
+# ---- the builtin-free functions of the reference's kernel file itself -----------------
+REF_KERNEL = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "libref_kernel.so")
+KFREE = json.load(open(os.path.join(HERE, "golden", "kernel_free.json")))
+
+
+def _u4(st):
+    return (C.c_uint32 * 4)(*[int(v) for v in st])
+
+
+def test_hybrid_rng_and_box_edges_match_the_committed_reference_outputs():
+    """tests/golden/kernel_free.json: what volumeraycast.cl's own ui_randStep / lcgStep /
+    hybridui_rand (:48-80, calcAO's generator) and checkBoundingBox (:323-343, showEss) returned when
+    the compiled reference was run here (oracle/gen_kernel_golden.py)."""
+    L = vro.lib()
+    for ch in KFREE["hybridui_rand_chains"]:
+        st = _u4(ch["state"])
+        for want in ch["draws_hex"]:
+            got = L.vro_hybrid_rand(st)
+            assert float(np.float32(got)).hex() == want
+        assert list(st) == ch["final_state"]
+    for k in KFREE["steps"]:
+        st = _u4(k["state"])
+        r = L.vro_ui_rand_step(st, *k["args"]) if k["fn"] == "ui_randStep" else L.vro_lcg_step(st, *k["args"])
+        assert r == k["ret"] and list(st) == k["after"], k
+    f3 = lambda v: (C.c_float * 3)(*v)
+    for k in KFREE["checkBoundingBox"]:
+        assert L.vro_check_bounding_box(f3(k["pos"]), f3(k["voxLen"]), k["bound"][0], k["bound"][1]) == k["ret"], k
+
+
+@pytest.mark.skipif(not os.path.exists(REF_KERNEL), reason="oracle/_ref not built (no /root/reference)")
+def test_hybrid_rng_bit_exact_vs_compiled_reference_kernel_file():
+    """volumeraycast.cl compiled from the reference's own source (66 OpenCL builtins left undefined,
+    RTLD_LAZY, nothing stands in for them): the functions that reach none of them, over 10^5 states."""
+    ref = C.CDLL(REF_KERNEL, mode=1)
+    U4 = C.POINTER(C.c_uint32)
+    ref.refk_hybrid_rand.restype = C.c_float
+    ref.refk_hybrid_rand.argtypes = [U4]
+    ref.refk_ui_rand_step.restype = C.c_uint32
+    ref.refk_ui_rand_step.argtypes = [U4, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_uint32]
+    ref.refk_lcg_step.restype = C.c_uint32
+    ref.refk_lcg_step.argtypes = [U4, C.c_uint32, C.c_uint32]
+    ref.refk_check_bounding_box.restype = C.c_int
+    ref.refk_check_bounding_box.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float]
+    for name, n in (("ParallelRNG", 1), ("ParallelRNG3", 3)):   # the #include of random.cl, once more
+        getattr(ref, name).restype = C.c_uint32
+        getattr(ref, name).argtypes = [C.c_uint32] * n
+    L = vro.lib()
+    rng = np.random.default_rng(7)
+    states = rng.integers(0, 2 ** 32, (100000, 4), dtype=np.uint64)
+    states[:64, :] = np.arange(64, dtype=np.uint64)[:, None]           # small states
+    states[64:128, 1:] = 0xFFFFFFFF
+    for i, st in enumerate(states):
+        a, b = _u4(st), _u4(st)
+        ra, rb = L.vro_hybrid_rand(a), ref.refk_hybrid_rand(b)
+        assert np.float32(ra).tobytes() == np.float32(rb).tobytes() and list(a) == list(b), (i, list(st))
+        if i % 8 == 0:     # a second draw from the advanced state, and the single steps
+            assert np.float32(L.vro_hybrid_rand(a)).tobytes() == np.float32(ref.refk_hybrid_rand(b)).tobytes()
+            for args in ((0, 13, 19, 12, 4294967294), (1, 2, 25, 4, 4294967288), (2, 3, 11, 17, 4294967280)):
+                a, b = _u4(st), _u4(st)
+                assert L.vro_ui_rand_step(a, *args) == ref.refk_ui_rand_step(b, *args) and list(a) == list(b)
+            a, b = _u4(st), _u4(st)
+            assert L.vro_lcg_step(a, 1664525, 1013904223) == ref.refk_lcg_step(b, 1664525, 1013904223)
+            assert list(a) == list(b)
+            x, y, z = int(st[0]), int(st[1]), int(st[2])
+            assert L.vro_parallel_rng(x) == ref.ParallelRNG(x)
+            assert L.vro_parallel_rng3(x, y, z) == ref.ParallelRNG3(x, y, z)
+    f3 = lambda v: (C.c_float * 3)(*v)
+    for _ in range(20000):
+        vox = rng.choice([1 / 32, 1 / 48, 1 / 256, 1 / 100], 3).astype(np.float32)
+        pos = (rng.choice([0.0, 1.0, 0.5], 3) + rng.normal(0, 1.5, 3) * vox).astype(np.float32)
+        b0, b1 = float(np.float32(rng.random() * 0.3)), float(np.float32(0.7 + rng.random() * 0.3))
+        assert L.vro_check_bounding_box(f3(pos), f3(vox), b0, b1) == ref.refk_check_bounding_box(f3(pos), f3(vox), b0, b1)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(REF_KERNEL), "ref_kernel.o")),
+                    reason="oracle/_ref not built (no /root/reference)")
+def test_list_of_builtin_free_reference_functions():
+    """What can be pinned is exactly what oracle/ref_kernel_free.py finds in the compiled object: nothing
+    that needs an OpenCL builtin is executed, and nothing executable is left out."""
+    from oracle import ref_kernel_free
+    res = ref_kernel_free.analyse(os.path.join(os.path.dirname(REF_KERNEL), "ref_kernel.o"))
+    free = sorted(f for f, undefined in res.items() if not undefined)
+    assert free == sorted(["ParallelRNG", "ParallelRNG2", "ParallelRNG3", "map256", "mapUintFloat", "ui_randStep",
+                           "lcgStep", "hybridui_rand", "getf4", "checkBoundingBox"])
+    assert len(res["volumeRender"]) >= 50 and res["generateBricks"] and res["intersectBBox"]

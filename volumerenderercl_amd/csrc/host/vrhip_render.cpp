@@ -27,17 +27,45 @@ namespace {
 
 struct Stop { double pos; int c[4]; };
 
-// updateTransferFunction (volumerenderwidget.cpp:916-938), linear easing: 1024 entries sampled
-// at time qRound(i/1024*8192) of 8192; QColor channels interpolate as int(f + (t-f)*p); c - 3.
-std::vector<unsigned char> tff_from_stops(std::vector<Stop> stops, int n = 1024)
+// QEasingCurve::valueForProgress for the three curves the GUI offers (mainwindow.cpp:945-957), with the
+// operation order of Qt's src/3rdparty/easing/easing.cpp (easeNone, easeInOutQuad, easeInOutCubic)
+double ease(const std::string &kind, double t)
 {
-    std::sort(stops.begin(), stops.end(), [](const Stop &a, const Stop &b) { return a.pos < b.pos; });
+    t = std::min(1.0, std::max(0.0, t));
+    if (kind == "quad") {
+        t *= 2.0;
+        if (t < 1) return t * t / 2.0;
+        --t;
+        return -0.5 * (t * (t - 2) - 1);
+    }
+    if (kind == "cubic") {
+        t *= 2.0;
+        if (t < 1) return 0.5 * t * t * t;
+        t -= 2.0;
+        return 0.5 * (t * t * t + 2);
+    }
+    return t;
+}
+
+// updateTransferFunction (volumerenderwidget.cpp:916-938): 1024 entries, entry i = the key-value
+// animation over the stops at time qRound(i/1024*8192) of 8192; QVariantAnimation interpolates QColor
+// per channel as qBound(0, int(f + (t - f) * localProgress), 255) with localProgress = (progress -
+// start) / (end - start) in double; then max(0, c - 3).  setKeyValueAt replaces an earlier key at the
+// same position; missing end stops (the GUI always has them) repeat the nearest stop's colour.
+std::vector<unsigned char> tff_from_stops(std::vector<Stop> in, int n = 1024, const std::string &easing = "linear")
+{
+    std::stable_sort(in.begin(), in.end(), [](const Stop &a, const Stop &b) { return a.pos < b.pos; });
+    std::vector<Stop> stops;
+    for (const Stop &s : in) {
+        if (!stops.empty() && stops.back().pos == s.pos) stops.back() = s;
+        else stops.push_back(s);
+    }
     if (stops.front().pos > 0.0) { Stop s = stops.front(); s.pos = 0.0; stops.insert(stops.begin(), s); }
     if (stops.back().pos < 1.0) { Stop s = stops.back(); s.pos = 1.0; stops.push_back(s); }
     std::vector<unsigned char> out(size_t(n) * 4, 0);
     for (int i = 0; i < n; ++i) {
         const double time = std::floor(double(i) / n * 8192.0 + 0.5);
-        const double p = time / 8192.0;
+        const double p = ease(easing, time / 8192.0);
         size_t k = 0;
         while (k + 2 < stops.size() && p >= stops[k + 1].pos) ++k;
         const Stop &a = stops[k], &b = stops[k + 1];
@@ -64,7 +92,7 @@ std::vector<unsigned char> tff_from_raw_file(const std::string &path)
 }
 
 // `.tff` gradient-stop file (MainWindow::readTff, mainwindow.cpp:583-620): `pos r g b a` per line
-std::vector<unsigned char> tff_from_stops_file(const std::string &path)
+std::vector<unsigned char> tff_from_stops_file(const std::string &path, const std::string &easing)
 {
     std::ifstream in(path);
     if (!in) throw std::invalid_argument("Could not open transfer function file " + path);
@@ -82,7 +110,7 @@ std::vector<unsigned char> tff_from_stops_file(const std::string &path)
         stops.push_back(st);
     }
     if (stops.empty()) throw std::invalid_argument("Empty transfer function file.");
-    return tff_from_stops(stops);
+    return tff_from_stops(stops, 1024, easing);
 }
 
 // The GUI's JSON state (MainWindow::loadCamState, mainwindow.cpp:374-410; VolumeRenderWidget::read,
@@ -181,6 +209,8 @@ void write_ppm(const std::string &path, const std::vector<float> &rgba, size_t w
         "         [--pathtrace] [--extinction E]   (technique 1; --frames = samples per pixel)\n"
         "         [--downsample FACTOR]            (volumeDownsampling: writes <dat>_<N>.raw/.dat, no frame)\n"
         "         [--state FILE.json] [--tf-stops FILE.tff]   (files saved by the reference GUI)\n"
+        "         [--tf-easing linear|quad|cubic] [--dump-tf FILE]   (interpolation between the stops; --dump-tf\n"
+        "                                           writes the RGBA8 table the options select and exits, no GPU)\n"
         "         [--contours] [--aerial] [--ao] [--show-ess] [--img-ess]   (--img-ess: state carried over --frames)\n"
         "         [--env FILE.hdr]                 (createEnvironmentMap: Radiance RGBE environment map)\n"
         "         [--ranks N [--tile T] [--loopback]]   (image tiles over N GPUs, devices D .. D+N-1, volume\n"
@@ -202,7 +232,7 @@ int main(int argc, char **argv)
     bool pathtrace = false;
     double extinction = 100.0;
     int downsample = 0;
-    std::string state_file, tf_stops;
+    std::string state_file, tf_stops, tf_easing = "linear", dump_tf;
     bool contours = false, aerial = false, use_ao_flag = false, show_ess_flag = false, img_ess = false;
     std::array<float, 16> view{};
     unsigned illum = 1, seed = 0;
@@ -240,6 +270,8 @@ int main(int argc, char **argv)
         else if (a == "--downsample") { need(i, 1); downsample = std::atoi(argv[++i]); }
         else if (a == "--state") { need(i, 1); state_file = argv[++i]; }
         else if (a == "--tf-stops") { need(i, 1); tf_stops = argv[++i]; }
+        else if (a == "--tf-easing") { need(i, 1); tf_easing = argv[++i]; }
+        else if (a == "--dump-tf") { need(i, 1); dump_tf = argv[++i]; }
         else if (a == "--contours") contours = true;
         else if (a == "--aerial") aerial = true;
         else if (a == "--ao") use_ao_flag = true;
@@ -253,6 +285,26 @@ int main(int argc, char **argv)
         else if (a == "--loopback") loopback = true;
         else if (a == "--out") { need(i, 1); out = argv[++i]; }
         else usage();
+    }
+    if (tf_easing != "linear" && tf_easing != "quad" && tf_easing != "cubic") usage();
+    // the transfer-function table the options select (TransferFunctionWidget's default stops,
+    // transferfunctionwidget.cpp:338-346, unless a file is given)
+    auto make_table = [&]() -> std::vector<unsigned char> {
+        return !tf_stops.empty() ? tff_from_stops_file(tf_stops, tf_easing)
+               : tf == "default" ? tff_from_stops({{0.0, {0, 0, 0, 0}}, {0.1, {125, 125, 125, 0}}, {1.0, {0, 0, 0, 255}}},
+                                                  1024, tf_easing)
+                                 : tff_from_raw_file(tf);
+    };
+    if (!dump_tf.empty()) {   // front-end formula only: nothing below touches a GPU
+        try {
+            const std::vector<unsigned char> table = make_table();
+            std::ofstream f(dump_tf, std::ios::binary);
+            f.write(reinterpret_cast<const char *>(table.data()), std::streamsize(table.size()));
+            return f ? 0 : 1;
+        } catch (const std::exception &e) {
+            std::cerr << e.what() << std::endl;
+            return 1;
+        }
     }
     if ((dat.empty() && synth_kind.empty()) || (out.empty() && !downsample)) usage();
 
@@ -291,10 +343,7 @@ int main(int argc, char **argv)
             if (st.flag.count("useAO")) use_ao = st.flag.at("useAO");
             if (st.flag.count("showBox")) show_box = st.flag.at("showBox");
         }
-        std::vector<unsigned char> table =
-            !tf_stops.empty() ? tff_from_stops_file(tf_stops)
-            : tf == "default" ? tff_from_stops({{0.0, {0, 0, 0, 0}}, {0.1, {125, 125, 125, 0}}, {1.0, {0, 0, 0, 255}}})
-                              : tff_from_raw_file(tf);
+        std::vector<unsigned char> table = make_table();
         vr.setTransferFunction(table);
         vr.setIllumination(illum);
         vr.setObjEss(ess);

@@ -86,21 +86,42 @@ def view_matrix(rotation=DEFAULT_ROTATION, translation=DEFAULT_TRANSLATION):
     return [float(np.float32(v)) for v in M.reshape(-1)]
 
 
-def _ease(kind, p):
+def _ease(kind, t):
+    """QEasingCurve::valueForProgress for the curves the GUI offers (mainwindow.cpp:945-957), with the
+    operation order of Qt's src/3rdparty/easing/easing.cpp (easeNone, easeInOutQuad, easeInOutCubic)."""
+    t = min(1.0, max(0.0, t))
     if kind == "linear":
-        return p
+        return t
     if kind == "quad":     # QEasingCurve::InOutQuad
-        return 2 * p * p if p < 0.5 else -2 * p * p + 4 * p - 1
+        t *= 2.0
+        if t < 1:
+            return t * t / 2.0
+        t -= 1
+        return -0.5 * (t * (t - 2) - 1)
     if kind == "cubic":    # QEasingCurve::InOutCubic
-        return 4 * p * p * p if p < 0.5 else 0.5 * ((2 * p - 2) ** 3) + 1
+        t *= 2.0
+        if t < 1:
+            return 0.5 * t * t * t
+        t -= 2.0
+        return 0.5 * (t * t * t + 2)
     raise ValueError(kind)
 
 
 def tff_from_stops(stops=DEFAULT_STOPS, n=1024, easing="linear"):
     """updateTransferFunction, volumerenderwidget.cpp:916-938: entry i samples the key-value
-    animation at time qRound(i/n*8192) of 8192; QColor channels interpolate as
-    int(f + (t - f) * p) (QVariantAnimation's _q_interpolate), then max(0, c - 3)."""
-    stops = sorted(stops, key=lambda s: s[0])
+    animation at time qRound(i/n*8192) of 8192; QVariantAnimation interpolates QColor per channel as
+    qBound(0, int(f + (t - f) * localProgress), 255) (_q_interpolate<int> truncates) with
+    localProgress = (progress - start) / (end - start) in double; then max(0, c - 3).
+    setKeyValueAt replaces an earlier key at the same position; missing end stops (the GUI always
+    has them) repeat the nearest stop's colour.  Known answers derived by hand from these semantics:
+    tests/test_frontend_files.py."""
+    dedup = []
+    for s in sorted(stops, key=lambda s: s[0]):     # (stable)
+        if dedup and dedup[-1][0] == s[0]:
+            dedup[-1] = s
+        else:
+            dedup.append(s)
+    stops = dedup
     if stops[0][0] > 0.0:
         stops = [(0.0, stops[0][1])] + stops
     if stops[-1][0] < 1.0:
