@@ -180,10 +180,19 @@ def main():
     rehearsal = os.environ.get("VRHIP_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
+    # second rehearsal knob: VRHIP_BENCH_FORCE_GATHER=1 sends a world of ONE rank through everything a
+    # world of several runs -- RCCL process group (world size 1), tile buffers, batched gathers with one
+    # in flight, assembly, the collectives over the counters -- so that none of it executes for the
+    # first time on the 8-GPU node.  `multi` below = "the distributed code path".
+    force_gather = os.environ.get("VRHIP_BENCH_FORCE_GATHER") == "1" and world == 1
+    multi = world > 1 or force_gather
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if force_gather:
+            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29541")):
+                os.environ.setdefault(k, v)
         if rehearsal:
             dist.init_process_group(backend="gloo")
         else:
@@ -227,9 +236,9 @@ def main():
     throughput = fif > 1 or fpl > 1
     # (in throughput mode this driver only serves the warm-up and the untimed one-frame-at-a-time
     # passes; the timed loop has its own, below)
-    driver = vtiles.TileDriver(vr, split, dev, batch=1 if throughput else fpg)
+    driver = vtiles.TileDriver(vr, split, dev, batch=1 if throughput else fpg, force_gather=force_gather)
     frames = (torch.empty((fpg, H, W, 4), dtype=torch.float32, device=dev)
-              if rank == 0 and world > 1 else None)
+              if rank == 0 and multi else None)
 
     def render(seed, k=0):
         vr.setSeed(seed)
@@ -249,10 +258,11 @@ def main():
         twin = vr.shareVolumes()
         twin.set_stream(s2.cuda_stream)
         lanes.append((twin, s2, None))
-    if world == 1 and throughput:   # one output block of fpl frames per renderer
+    if not multi and throughput:   # one output block of fpl frames per renderer
         lanes = [(r, s_, torch.empty((fpl, H, W, 4), dtype=torch.float32, device=dev)) for r, s_, _ in lanes]
-    if world > 1 and throughput:
-        driver_mt = vtiles.TileDriver(vr, split, dev, batch=fpg, lanes=[(r, s_) for r, s_, _ in lanes])
+    if multi and throughput:
+        driver_mt = vtiles.TileDriver(vr, split, dev, batch=fpg, lanes=[(r, s_) for r, s_, _ in lanes],
+                                      force_gather=force_gather)
 
     def render_block(j, frame_ids):
         # renderer j % fif renders these frames (their own jitter seeds) with one set of launches
@@ -268,7 +278,7 @@ def main():
     n_sets = min(args.steps, -(-n_sets // fif) * fif)
     bounds = [round(i * args.steps / n_sets) for i in range(n_sets + 1)]
     blocks = [list(range(bounds[i], bounds[i + 1])) for i in range(n_sets) if bounds[i + 1] > bounds[i]]
-    drv = driver_mt if (world > 1 and throughput) else driver
+    drv = driver_mt if (multi and throughput) else driver
 
     def submit_chunk(chunk):
         if throughput:   # the rank's share of all the chunk's frames: one launch set per renderer
@@ -283,14 +293,14 @@ def main():
     for k in range(args.warmup):
         render(seeds[k])
     if throughput:   # every renderer once, untimed: buffers, work queue, skip bitmap, cell grid
-        if world == 1:
+        if not multi:
             for j in range(fif):
                 render_block(j, blocks[0])
         else:
             submit_chunk(chunks[0])
             drv.collect_batch(frames)
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if multi:
         dist.barrier()
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
@@ -298,10 +308,10 @@ def main():
     ev0.record(stream)
     for _, s2, _ in lanes[1:]:
         s2.wait_event(ev0)
-    if world == 1 and throughput:
+    if not multi and throughput:
         for j, blk in enumerate(blocks):
             render_block(j, blk)
-    elif world == 1:
+    elif not multi:
         for k in range(args.steps):
             render(seeds[args.warmup + k], k)
     else:
@@ -314,14 +324,14 @@ def main():
         stream.wait_stream(s2)       # the region ends when every lane's last frame has
     ev1.record(stream)
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if multi:
         dist.barrier()
     wall = time.perf_counter() - t0
     gpu_region_s = ev0.elapsed_time(ev1) * 1e-3
     last_kernel_s = vr.getLastExecTime()
     last_phases = vr.getLastPhaseTimes()
     wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
-    if world > 1:
+    if multi:
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
     wall = float(wall_t.item())
 
@@ -334,12 +344,12 @@ def main():
                 "avg_launch_ms": gpu_region_s / args.steps * 1e3,
                 "frames_in_flight": fif, "frames_per_launch": max(len(b_) for b_ in blocks) if throughput else 1,
                 "round_budget": args.round_budget if throughput else 10,
-                "launch_sets_in_region": len(blocks) if (world == 1 and throughput) else args.steps,
+                "launch_sets_in_region": len(blocks) if (not multi and throughput) else args.steps,
                 "note": "timed region only; work counters, roofline and cpu_baseline come from the full run"})
             print(line, flush=True)
             if args.out_json:
                 open(args.out_json, "w").write(line + "\n")
-        if world > 1:
+        if multi:
             dist.barrier()
             dist.destroy_process_group()
         vr.close()
@@ -349,7 +359,7 @@ def main():
     serial_s = None
     if throughput:
         vr.setRoundBudget(10)      # the single-frame schedule for everything that follows
-    if world == 1 and throughput:
+    if not multi and throughput:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
         for k in range(args.steps):
@@ -371,7 +381,7 @@ def main():
         tot += np.array([st[n] for n in names], dtype=np.int64)
     vr.setStatsEnabled(False)
     tot_t = torch.tensor(tot, dtype=torch.int64, device=dev)
-    if world > 1:
+    if multi:
         dist.all_reduce(tot_t, op=dist.ReduceOp.SUM)
     tot = tot_t.cpu().numpy()
     work = dict(zip(names, [int(x) for x in tot]))
@@ -397,9 +407,9 @@ def main():
         # budgeted march of every ray; phase 2: the suspended long rays, 4 lanes per ray).  Its
         # duration = HIP events over the timed region on the launch stream / K (world == 1; with
         # the gather in the region at world > 1 the vrhip events of the last pass are used).
-        kernel_s = gpu_region_s / args.steps if world == 1 else last_kernel_s
+        kernel_s = gpu_region_s / args.steps if not multi else last_kernel_s
         achieved = alg_bytes / kernel_s / 1e9
-        traffic = pmc_traffic(args.workload) if world == 1 else None
+        traffic = pmc_traffic(args.workload) if not multi else None
         roofline = {
             "kernel": ("vr_pathtrace_kernel <%s>, one launch per sample-per-pixel pass" % fmt_name.lower())
                       if technique == 1 else
@@ -439,7 +449,7 @@ def main():
         # What actually bounds the march: VALU issue.  A gfx950 SIMD issues one wave64 VALU
         # instruction per 2 cycles (MI355X_MICROARCH.md "Wave scheduling"; = the 157.3 TFLOP/s fp32
         # vector peak / 128 flops), so the chip peaks at 256 CUs x 4 SIMDs x 2.4 GHz / 2.
-        issue = pmc_issue(args.workload) if world == 1 else None
+        issue = pmc_issue(args.workload) if not multi else None
         if issue:
             peak_wi = 256 * 4 * 2.4e9 / 2.0
             ach_wi = issue["valu_wave_insts_per_frame"] / kernel_s
@@ -519,7 +529,7 @@ def main():
                 "parallelism": "tiles%dx%d/%d ranks, volume replicated, %d renderer(s) per rank, one RCCL "
                                "gather per %d frames (one gather in flight)" % (
                                    args.tile, args.tile, world, fif, fpg)
-                               if world > 1 else "single GPU, full frames, %d renderer(s) x %d frames per "
+                               if multi else "single GPU, full frames, %d renderer(s) x %d frames per "
                                                  "launch set" % (fif, fpl),
             },
             "value_note": "samples TAKEN = inner-loop bodies the reference executes after ESS/ERT; those that lie in "
@@ -546,7 +556,7 @@ def main():
         if parity and not (parity["max_abs_diff"] <= parity["tolerance"] and parity["counters_equal"]):
             sys.stderr.write("bench.py: PARITY FAILURE against the oracle: %s\n" % json.dumps(parity))
             parity_failed = True
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     vr.close()

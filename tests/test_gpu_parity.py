@@ -564,6 +564,10 @@ def test_cpp_host_cli_matches_oracle(tmp_path):
 
 
 @pytest.mark.parametrize("args,frames", [(["--ranks", "1"], 1), (["--ranks", "3", "--loopback", "--tile", "32"], 1),
+                                         # RCCL on one GPU: ncclCommInitAll over one device, the root's
+                                         # grouped ncclSend / ncclRecv to itself, assembly behind the receive
+                                         (["--ranks", "1", "--force-gather", "--tile", "32"], 2),
+                                         (["--ranks", "1", "--force-gather", "--tile", "48", "--pathtrace"], 2),
                                          (["--ranks", "2", "--loopback", "--tile", "16"], 3),
                                          (["--ranks", "4", "--loopback", "--tile", "48", "--pathtrace"], 2)])
 def test_cpp_host_tile_ranks_equal_single_renderer(tmp_path, args, frames):
@@ -588,6 +592,9 @@ def test_cpp_host_tile_ranks_equal_single_renderer(tmp_path, args, frames):
         outs.append(np.fromfile(out + ".rgba.f32", dtype=np.float32).reshape(H, W, 4))
         if name == "ranks":
             assert '"ranks": %s' % args[1] in res.stdout
+            want = "loopback" if "--loopback" in args else "RCCL send/recv (root included)" if "--force-gather" in args \
+                else "RCCL send/recv"
+            assert '"transport": "%s' % want in res.stdout, res.stdout
     assert np.isfinite(outs[0]).all() and outs[0].std() > 0
     np.testing.assert_array_equal(outs[0], outs[1])
 
@@ -1191,8 +1198,83 @@ def test_headline_size_volume_matches_oracle():
         n, bm = r.countTouched(W, H, want_bitmap=True)
         np.testing.assert_array_equal(bm, ref_bm)
         assert n == int(np.unpackbits(ref_bm).sum()) and n > 0
+        _config4_tile_split_at_size(r, vol, tff, ref_bricks)
     finally:
         r.close()
+
+
+def _config4_tile_split_at_size(r, vol, tff, ref_bricks):
+    """BASELINE config 4 as far as one GPU goes: the 2048^2 frame of the 2048^3 volume cut into 64 x 64
+    tiles for EIGHT ranks (diagonal interleave), the eight tile shares rendered one after the other on
+    this GPU through eight TileDrivers -- instrumented kernels (summed work counters) and production
+    kernels -- gathered by a stand-in collective that hands rank 0 the peers' blocks, assembled by rank
+    0's driver, and compared with the oracle's frame of the whole viewport."""
+    import torch
+    from volumerenderercl_amd import tiles
+
+    V, T, WORLD = 2048, 64, 8
+    dev = torch.device("cuda")
+    r.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    class SharedGather:          # one process plays all ranks: peers deposit, the root collects
+        def __init__(self):
+            self.blocks = {}
+
+        class _Done:
+            def wait(self):
+                pass
+
+        def for_rank(self, rank):
+            outer = self
+
+            class _D:
+                def gather(self, tensor, gather_list, dst=0, async_op=False):
+                    if rank != 0:
+                        outer.blocks[rank] = tensor.clone()
+                    else:
+                        gather_list[0].copy_(tensor)
+                        for k, t in outer.blocks.items():
+                            gather_list[k].copy_(t)
+                        outer.blocks = {}
+                    return outer._Done()
+            return _D()
+
+    hub = SharedGather()
+    splits = [tiles.TileSplit(V, V, T, T, WORLD, k) for k in range(WORLD)]
+    assert sum(len(s_.my_tiles) for s_ in splits) == (V // T) ** 2 and splits[0].cap == 128
+    drivers = [tiles.TileDriver(r, splits[k], dev, dist=hub.for_rank(k)) for k in range(WORLD)]
+    r.setSeed(SEED)
+    r.setIteration(0)
+    cam, rp, rc, pt = common.to_oracle_params(*r.params())
+    rp.seed, rp.iteration = SEED, 0
+    ref, rstats, _ = vro.render_tile(vol, UCHAR, tff, cam, rp, rc, pt, W=V, H=V, bricks=ref_bricks)
+    assert rstats["rays_hit"] > 3000000 and rstats["samples_shaded"] > 0
+    frame = torch.zeros((V, V, 4), dtype=torch.float32, device=dev)
+    try:
+        for stats in (True, False):
+            r.setStatsEnabled(stats)
+            total = dict.fromkeys(rstats, 0)
+            frame.zero_()
+            for k in list(range(1, WORLD)) + [0]:          # the peers first, the root last
+                r.setSeed(SEED)
+                r.setIteration(0)
+                drivers[k].submit()
+                if stats:
+                    for name, v in r.getStats().items():
+                        total[name] += v
+                if k:
+                    drivers[k].pending.pop(0)              # (a peer has nothing to collect)
+            drivers[0].collect(frame)
+            torch.cuda.synchronize()
+            got = frame.cpu().numpy()
+            d = np.abs(got.astype(np.float64) - ref)
+            assert d.max() <= TOL, "config 4 tile split, stats=%s: %g at %s" % (
+                stats, d.max(), np.unravel_index(d.argmax(), d.shape))
+            if stats:
+                assert total == rstats
+    finally:
+        r.setStatsEnabled(False)
+        r.set_stream(None, use_own=True)
 
 
 def test_config3_size_volume_matches_oracle():
@@ -1715,3 +1797,92 @@ def test_owner_going_away_detaches_its_sharers(vr):
     finally:
         twin.close()
         owner.close()
+
+
+def _run_py(code, env=None, timeout=600):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, **(env or {})),
+                          capture_output=True, text=True, timeout=timeout)
+
+
+def test_tile_driver_over_a_world_size_1_rccl_group():
+    """RCCL executes: TileDriver(force_gather=True) puts a world of ONE rank through the world > 1 code --
+    tile buffers, dist.gather on a world-size-1 `nccl` process group (asynchronous, one in flight), the
+    assembly on rank 0 -- with whole frames one by one (submit / collect), batches of frames rendered by
+    two renderers in flight (submit_frames) and the synchronous render_frame; every frame equals the
+    full-frame render with the same seed.  In a process of its own: the process group is global state."""
+    code = r"""
+import numpy as np, torch, torch.distributed as dist
+from tests import common
+from volumerenderercl_amd import UCHAR, VolumeRenderCL, tiles
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29547", rank=0, world_size=1, device_id=dev)
+vr = VolumeRenderCL(); vr.initialize()
+vol = common.noise_volume((56, 48, 40), UCHAR, seed=5, smooth=False)
+vr.loadVolumeArrays([vol], UCHAR)
+vr.setTransferFunction(common.tffs()["default"])
+vr.updateView(common.views()["rot30"])
+W, H, T = 200, 136, 32                     # ragged right / bottom tiles
+seeds = [3499211612, 581869302, 3890346734, 3586334585, 545404204]
+full = []
+for sd in seeds:
+    vr.setSeed(sd); vr.setIteration(0); full.append(vr.runRaycastNoGL(W, H))
+split = tiles.TileSplit(W, H, T, T, 1, 0)
+# (1) synchronous frames and the pipelined pair submit / collect on the renderer's own stream
+drv = tiles.TileDriver(vr, split, dev, force_gather=True)
+frame = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+vr.setSeed(seeds[0]); vr.setIteration(0)
+assert np.array_equal(drv.render_frame(frame).cpu().numpy(), full[0])
+vr.setSeed(seeds[1]); vr.setIteration(0); drv.submit()
+vr.setSeed(seeds[2]); vr.setIteration(0); drv.submit()          # two gathers in flight
+for k in (1, 2):
+    drv.collect(frame); torch.cuda.synchronize()
+    assert np.array_equal(frame.cpu().numpy(), full[k]), k
+# (2) batches of frames, two renderers in flight, one gather per batch
+twin = vr.shareVolumes()
+s1, s2 = torch.cuda.current_stream(dev), torch.cuda.Stream(dev)
+vr.set_stream(s1.cuda_stream); twin.set_stream(s2.cuda_stream)
+drv2 = tiles.TileDriver(vr, split, dev, batch=4, lanes=[(vr, s1), (twin, s2)], force_gather=True)
+frames = torch.zeros((4, H, W, 4), dtype=torch.float32, device=dev)
+drv2.submit_frames(seeds[:4]); drv2.submit_frames(seeds[1:5])
+for lo in (0, 1):
+    drv2.collect_batch(frames); torch.cuda.synchronize()
+    got = frames.cpu().numpy()
+    for i in range(4):
+        assert np.array_equal(got[i], full[lo + i]), (lo, i)
+# (3) the collectives bench.py issues around the timed region
+t = torch.tensor([1.5], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+c = torch.arange(6, dtype=torch.int64, device=dev); dist.all_reduce(c, op=dist.ReduceOp.SUM)
+dist.barrier(); assert float(t.item()) == 1.5 and c.tolist() == list(range(6))
+twin.close(); vr.close()
+dist.destroy_process_group()
+print("RCCL_WORLD1_OK")
+"""
+    p = _run_py(code, env={"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert p.returncode == 0 and "RCCL_WORLD1_OK" in p.stdout, (p.stdout[-1000:], p.stderr[-3000:])
+
+
+def test_bench_multi_gpu_path_rehearsed_over_rccl_on_one_gpu(tmp_path):
+    """bench.py's distributed code path end to end on one GPU (VRHIP_BENCH_FORCE_GATHER=1): RCCL process
+    group, batched gathers with one in flight, assembly, the barrier / all-reduce bracket, the JSON line --
+    with the bench's own parity check against the oracle (exit code 3 on a mismatch)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "line.json"
+    env = dict(os.environ, VRHIP_BENCH_FORCE_GATHER="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT="29549")
+    for extra in ([], ["--frames-in-flight", "1", "--frames-per-launch", "1"]):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "sphere64", "--viewport", "192",
+                            "--steps", "12", "--warmup", "2", "--frames-per-gather", "5", "--cpu-seconds", "0.5",
+                            "--out-json", str(out)] + extra, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-3000:])
+        d = json.loads(out.read_text())
+        assert d["n_gpus"] == 1 and "RCCL gather per 5 frames" in d["config"]["parallelism"]
+        assert d["parity"]["max_abs_diff"] <= TOL and d["parity"]["counters_equal"]
+        assert d["value"] > 0 and d["work_per_frame"]["samples_taken"] > 0

@@ -23,8 +23,9 @@ void nccl_check(ncclResult_t e, const char *what)
 } // namespace
 
 TileGather::TileGather(const std::vector<VolumeRenderCL *> &ranks, const std::vector<int> &devices, size_t width,
-                       size_t height, size_t tile, bool loopback)
-    : _ranks(ranks), _devices(devices), _W(width), _H(height), _tile(tile), _loopback(loopback)
+                       size_t height, size_t tile, bool loopback, bool force_gather)
+    : _ranks(ranks), _devices(devices), _W(width), _H(height), _tile(tile), _loopback(loopback),
+      _self_exchange(force_gather && !loopback)
 {
     const size_t n = _ranks.size();
     if (n == 0 || devices.size() != n) throw std::invalid_argument("TileGather: one device per rank");
@@ -55,7 +56,11 @@ TileGather::TileGather(const std::vector<VolumeRenderCL *> &ranks, const std::ve
     hip_check(hipMalloc(reinterpret_cast<void **>(&_slot_of_tile), slot.size() * sizeof(unsigned int)), "hipMalloc slots");
     hip_check(hipMemcpy(_slot_of_tile, slot.data(), slot.size() * sizeof(unsigned int), hipMemcpyHostToDevice),
               "hipMemcpy slots");
-    _local[0] = _staging;   // the root renders straight into its block
+    _local[0] = _staging;   // the root renders straight into its block ...
+    if (_self_exchange) {   // ... unless it is to send its tiles to itself like a peer (see tilegather.h)
+        hip_check(hipMalloc(reinterpret_cast<void **>(&_local[0]), block * sizeof(float)), "hipMalloc tiles");
+        hip_check(hipMemset(_local[0], 0, block * sizeof(float)), "hipMemset tiles");
+    }
     for (size_t r = 1; r < n; ++r) {
         hip_check(hipSetDevice(_devices[r]), "hipSetDevice");
         hip_check(hipMalloc(reinterpret_cast<void **>(&_local[r]), block * sizeof(float)), "hipMalloc tiles");
@@ -77,6 +82,7 @@ TileGather::~TileGather()
             (void)hipFree(_local[r]);
         }
     (void)hipSetDevice(_devices[0]);
+    if (_self_exchange && _local[0]) (void)hipFree(_local[0]);
     if (_staging) (void)hipFree(_staging);
     if (_frame) (void)hipFree(_frame);
     if (_slot_of_tile) (void)hipFree(_slot_of_tile);
@@ -90,7 +96,7 @@ double TileGather::renderFrame(std::vector<float> &out)
     // every rank: its tiles of this frame into its compact buffer, on its own stream
     for (size_t r = 0; r < n; ++r)
         if (!_tiles[r].empty()) _ranks[r]->renderTiles(_W, _H, _tile, _tile, _tiles[r], _local[r], true);
-    if (n > 1) {
+    if (n > 1 || _self_exchange) {
         if (_loopback) {
             // rehearsal on one device: the peers' blocks reach the root's staging by copies ordered
             // behind the peers' streams
@@ -103,7 +109,7 @@ double TileGather::renderFrame(std::vector<float> &out)
             // one point-to-point exchange per peer, all in one group: the root's receives and the
             // peers' sends progress together, each on the stream its renderer launched on
             nccl_check(ncclGroupStart(), "ncclGroupStart");
-            for (size_t r = 1; r < n; ++r) {
+            for (size_t r = _self_exchange ? 0 : 1; r < n; ++r) {   // (r = 0: the root's send to itself)
                 nccl_check(ncclRecv(_staging + r * block, block, ncclFloat, static_cast<int>(r),
                                     static_cast<ncclComm_t>(_comms[0]), static_cast<hipStream_t>(_streams[0])), "ncclRecv");
                 nccl_check(ncclSend(_local[r], block, ncclFloat, 0, static_cast<ncclComm_t>(_comms[r]),

@@ -16,8 +16,13 @@ class TileGather
 public:
     // ranks[r] renders on HIP device devices[r].  loopback: no RCCL -- the peers' tiles reach the root
     // by device-to-device copies (every rank on ONE device: rehearsal of everything but the transport).
+    // force_gather: the root does not render into its block of the staging buffer but into a buffer of
+    // its own and SENDS it to itself inside the same RCCL group as the peers' sends (one ncclSend /
+    // ncclRecv pair on the root's communicator and stream): with one rank this runs the transport --
+    // ncclCommInitAll, a grouped point-to-point exchange, the assembly behind the receive -- on a
+    // one-GPU box.
     TileGather(const std::vector<VolumeRenderCL *> &ranks, const std::vector<int> &devices, size_t width,
-               size_t height, size_t tile, bool loopback);
+               size_t height, size_t tile, bool loopback, bool force_gather = false);
     ~TileGather();
     TileGather(const TileGather &) = delete;
     TileGather &operator=(const TileGather &) = delete;
@@ -28,13 +33,16 @@ public:
     double renderFrame(std::vector<float> &out);
 
     size_t tilesOf(size_t rank) const { return _tiles[rank].size(); }
-    std::string transport() const { return _loopback ? "loopback (device copies)" : "RCCL send/recv"; }
+    std::string transport() const
+    {
+        return _loopback ? "loopback (device copies)" : _self_exchange ? "RCCL send/recv (root included)" : "RCCL send/recv";
+    }
 
 private:
     std::vector<VolumeRenderCL *> _ranks;
     std::vector<int> _devices;
     size_t _W, _H, _tile, _tiles_x, _tiles_y, _cap;
-    bool _loopback;
+    bool _loopback, _self_exchange;
     std::vector<std::vector<unsigned int>> _tiles;   // tile ids per rank
     std::vector<float *> _local;                     // per rank: its tiles (rank 0: block 0 of the staging)
     float *_staging = nullptr;                       // root: ranks x cap tile slots

@@ -213,9 +213,11 @@ void write_ppm(const std::string &path, const std::vector<float> &rgba, size_t w
         "                                           writes the RGBA8 table the options select and exits, no GPU)\n"
         "         [--contours] [--aerial] [--ao] [--show-ess] [--img-ess]   (--img-ess: state carried over --frames)\n"
         "         [--env FILE.hdr]                 (createEnvironmentMap: Radiance RGBE environment map)\n"
-        "         [--ranks N [--tile T] [--loopback]]   (image tiles over N GPUs, devices D .. D+N-1, volume\n"
-        "                                           replicated, RCCL gather to the first; --loopback: N\n"
-        "                                           renderers on device D, device copies instead of RCCL)\n"
+        "         [--ranks N [--tile T] [--loopback] [--force-gather]]   (image tiles over N GPUs, devices D .. D+N-1,\n"
+        "                                           volume replicated, RCCL gather to the first; --loopback: N\n"
+        "                                           renderers on device D, device copies instead of RCCL;\n"
+        "                                           --force-gather: the root sends its tiles to itself over RCCL\n"
+        "                                           too -- with --ranks 1 the transport runs on one GPU)\n"
         "writes PREFIX.rgba.f32 (W*H*4 float32, row 0 = top), PREFIX.ppm and prints one JSON line\n";
     std::exit(2);
 }
@@ -238,7 +240,7 @@ int main(int argc, char **argv)
     unsigned illum = 1, seed = 0;
     int frames = 1, device = 0, ranks = 0;
     size_t tile = 64;
-    bool loopback = false;
+    bool loopback = false, force_gather = false;
     double rate = 1.5;
     std::array<float, 4> bg = {{1, 1, 1, 1}};
 
@@ -283,6 +285,7 @@ int main(int argc, char **argv)
         else if (a == "--ranks") { need(i, 1); ranks = std::atoi(argv[++i]); }
         else if (a == "--tile") { need(i, 1); tile = size_t(std::atol(argv[++i])); }
         else if (a == "--loopback") loopback = true;
+        else if (a == "--force-gather") force_gather = true;
         else if (a == "--out") { need(i, 1); out = argv[++i]; }
         else usage();
     }
@@ -382,7 +385,7 @@ int main(int argc, char **argv)
                 if (!setup(*vrs.back(), devs.back())) return 0;
                 ptrs.push_back(vrs.back().get());
             }
-            TileGather tg(ptrs, devs, W, H, tile, loopback);
+            TileGather tg(ptrs, devs, W, H, tile, loopback, force_gather);
             std::vector<float> frame;
             double secs = 0.0;
             for (int f = 0; f < frames; ++f) secs += tg.renderFrame(frame);

@@ -37,7 +37,7 @@ class TileSplit:
 
 
 class TileDriver:
-    """Renders frames: full-frame launch at world == 1, tiles + gather otherwise.
+    """Renders frames: full-frame launch at world == 1 (unless `force_gather`), tiles + gather otherwise.
 
     `render_tiles_fn(tile_ids, out)` fills out[k] (tile_h x tile_w x 4 floats) for tile k;
     the default drives vrhip_render_tiles on the renderer's GPU.
@@ -63,12 +63,16 @@ class TileDriver:
     """
 
     def __init__(self, vr, split, device, render_tiles_fn=None, dist=None, image_ess=False,
-                 hit_io=None, batch=1, lanes=None):
+                 hit_io=None, batch=1, lanes=None, force_gather=False):
         import torch
         self.torch = torch
         self.vr, self.split, self.device = vr, split, device
         self.render_tiles_fn = render_tiles_fn
         s = split
+        # force_gather: a world of ONE rank goes through everything a world of several does -- tile
+        # buffers, the collective (a world-size-1 process group: RCCL on a one-GPU box), assembly --
+        # instead of the full-frame launch
+        self.gathering = s.world > 1 or bool(force_gather)
         # frames in flight on this rank: [(renderer, torch stream), ...]; the frames of a batch are
         # dealt to them in turn (renderers sharing one volume, VolumeRenderCL.shareVolumes)
         self.lanes = list(lanes) if lanes else None
@@ -89,13 +93,13 @@ class TileDriver:
                 if s.owner[t] == s.rank:
                     own[rect] = True
             self.hit_own, self.hit_owned_by_any = own, owned_by_any
-        if dist is None and s.world > 1:
+        if dist is None and self.gathering:
             import torch.distributed as dist
         self.dist = dist
         self.pending = []          # (buffer index, frames, work handle) of the gathers in flight
         self.next_buf = 0
         self.batch = B = max(1, int(batch))
-        if s.world > 1:
+        if self.gathering:
             # [frame of the batch, slot, th, tw, 4]
             self.local = [torch.zeros((B, s.cap, s.th, s.tw, 4), dtype=torch.float32, device=device)
                           for _ in range(2)]
@@ -147,7 +151,7 @@ class TileDriver:
         `lanes`: `before_frame(i, renderer)`) is called ahead of frame i (jitter seed, iteration,
         ...) -- and start ONE gather for all of them."""
         s = self.split
-        if s.world == 1:
+        if not self.gathering:
             raise RuntimeError("submit/collect are for world > 1; use render_frame")
         if not 1 <= n <= self.batch:
             raise ValueError("1 <= n <= batch (%d) frames per gather" % self.batch)
@@ -188,7 +192,7 @@ class TileDriver:
         tile share of several frames in one work queue), then ONE gather for all of them."""
         s = self.split
         n = len(seeds)
-        if s.world == 1:
+        if not self.gathering:
             raise RuntimeError("submit/collect are for world > 1; use render_frame")
         if not 1 <= n <= self.batch:
             raise ValueError("1 <= n <= batch (%d) frames per gather" % self.batch)
@@ -254,7 +258,7 @@ class TileDriver:
     def render_frame(self, frame):
         """Returns the assembled H x W x 4 frame on rank 0 (None elsewhere)."""
         s = self.split
-        if s.world == 1:
+        if not self.gathering:
             if self.render_tiles_fn is None:
                 streams = [self._stream_of(self.vr)]
                 cur = self._before_render(streams)
