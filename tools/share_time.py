@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""tools/share_time.py [WORLD] [VIEWPORT] -- GPU time per frame of rank 0's tile share of a WORLD-rank split
-(no gather), for several (renderers in flight, frames per launch set): what image-tile strong scaling
-can reach before the collective.  One GPU."""
+"""tools/share_time.py [WORLD] [VIEWPORT] [RANKS] [OUT.json] -- GPU time per frame of a rank's tile share of a
+WORLD-rank split (no gather; RANKS = comma-separated ranks, default 0), for several (renderers in flight,
+frames per launch set): what image-tile strong scaling can reach before the collective.  One GPU."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,6 +10,9 @@ from volumerenderercl_amd import VolumeRenderCL, frontend, tiles
 
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 V = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+ranks = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0]
+out_json = sys.argv[4] if len(sys.argv) > 4 else None
+results = []
 dev = torch.device("cuda", 0)
 vr = VolumeRenderCL(); vr.initialize()
 vr.synthVolume("shells", (2048,) * 3, 0)
@@ -22,8 +25,8 @@ twins = [vr] + [vr.shareVolumes() for _ in range(3)]
 streams = [torch.cuda.Stream(dev) for _ in twins]
 for r, s in zip(twins, streams):
     r.set_stream(s.cuda_stream)
-for w in sorted({1, world}):
-    split = tiles.TileSplit(V, V, 64, 64, w, 0)
+for w, rk in [(1, 0)] + [(world, r_) for r_ in ranks]:
+    split = tiles.TileSplit(V, V, 64, 64, w, rk)
     ids = None if w == 1 else split.my_tiles
     npix = V * V if w == 1 else len(ids) * 64 * 64
     for fif, fpl in ((1, 1), (2, 8), (2, 16), (2, 32), (3, 16), (4, 8), (1, 32), (4, 16)):
@@ -41,4 +44,10 @@ for w in sorted({1, world}):
         nsets = max(fif * 2, 256 // fpl)
         t0 = time.perf_counter(); run(nsets); torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) * 1e3 / (nsets * fpl)
-        print("world %d share (%d px)  %d renderer(s) x %2d frames/set: %.4f ms/frame" % (w, npix, fif, fpl, ms), flush=True)
+        print("world %d rank %d share (%d px)  %d renderer(s) x %2d frames/set: %.4f ms/frame" % (w, rk, npix, fif, fpl, ms), flush=True)
+        results.append({"world": w, "rank": rk, "pixels": npix, "renderers": fif, "frames_per_set": fpl, "ms_per_frame": ms})
+if out_json:
+    import json, subprocess
+    head = subprocess.run(["git", "rev-parse", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+    json.dump({"tool": "tools/share_time.py", "workload": "shells2048", "viewport": V, "world": world, "round_budget": 48,
+               "head": head, "results": results}, open(out_json, "w"), indent=1)
