@@ -42,7 +42,10 @@ WORKLOADS = {
     "sphere64": ("sphere", 64, "UCHAR", 1, "default", True),    # CI-sized
     # BASELINE config 5: Woodcock-tracking path tracer (technique 1); a step = one sample per
     # pixel of the progressive render (iteration k of the running mean), 64 steps = 64 spp
+    # -- on the field SURVEY 8(d) names for it (sphere), and on the shells field beside it
+    "pt1024f_sphere": ("sphere", 1024, "FLOAT", 1, "default", True, 1),
     "pt1024f": ("shells", 1024, "FLOAT", 1, "default", True, 1),
+    "pt256f_sphere": ("sphere", 256, "FLOAT", 1, "default", True, 1),
     "pt256f": ("shells", 256, "FLOAT", 1, "default", True, 1),
 }
 FMT = {"UCHAR": 0, "USHORT": 1, "FLOAT": 2}
@@ -118,36 +121,59 @@ def cpu_baseline(vr, vol_host, bricks_host, tff, fmt, W, H, target_s, seeds, use
     }
 
 
-def pmc_traffic(workload):
-    """HBM bytes per ray-cast pass from the committed rocprofv3 --pmc passes of this same
-    command (profiles/<round>/pmc_traffic.json, written by tools/pmc_traffic.py): FETCH_SIZE and
-    WRITE_SIZE collected in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md
-    prescribes for gfx950.  None when no profile of this workload is committed."""
+def source_hash():
+    """sha256 (16 hex digits) over the kernel sources the measured code is built from
+    (volumerenderercl_amd/csrc/*.hip, *.h and the C ABI header): a committed PMC profile is only used
+    for a roofline figure when it was taken from the same sources."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json")),
-                       reverse=True):
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "volumerenderercl_amd", "csrc")
+    files = sorted(glob.glob(os.path.join(base, "*.hip")) + glob.glob(os.path.join(base, "*.h")))
+    files.append(os.path.join(ROOT, "include", "vrhip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def schedule_key(workload, viewport, view, fif, fpl, round_budget):
+    return {"workload": workload, "viewport": int(viewport), "view": view, "frames_in_flight": int(fif),
+            "frames_per_launch": int(fpl), "round_budget": int(round_budget)}
+
+
+def find_profile(kind, key, src_hash):
+    """The committed rocprofv3 --pmc summary (profiles/r<N>/pmc_<kind>*.json, written by
+    tools/pmc_issue.py / tools/pmc_traffic.py from `bench.py --profile-region` runs, each entry carrying
+    the `meta` of the run it came from) whose workload, viewport, view, renderers in flight, frames per
+    launch set and round budget equal this run's AND whose kernel sources hash like this run's.
+    Returns (entry, None); (None, {...}) when only profiles of other sources / schedules exist."""
+    import glob
+    import re
+
+    def round_no(path):
+        m = re.search(r"profiles[/\\]r(\d+)[/\\]", path)
+        return int(m.group(1)) if m else -1
+
+    near = None
+    paths = glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_%s*.json" % kind))
+    for path in sorted(paths, key=lambda q: (-round_no(q), q)):
         try:
             d = json.load(open(path))
         except Exception:
             continue
-        if workload in d:
-            return d[workload]
-    return None
-
-
-def pmc_issue(workload):
-    """VALU wave-instructions per frame of the timed ray-cast launches, from the committed
-    rocprofv3 --pmc pass of `bench.py --profile-region` (profiles/<round>/pmc_issue.json, written
-    by tools/pmc_issue.py).  None when no profile of this workload is committed."""
-    import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_issue.json")), reverse=True):
-        try:
-            d = json.load(open(path))
-        except Exception:
-            continue
-        if workload in d:
-            return d[workload]
-    return None
+        for entry in d.values():
+            meta = entry.get("meta") if isinstance(entry, dict) else None
+            if not meta or meta.get("workload") != key["workload"]:
+                continue
+            same_schedule = all(meta.get(k) == v for k, v in key.items())
+            if same_schedule and meta.get("source_hash") == src_hash:
+                return dict(entry, file=os.path.relpath(path, ROOT)), None
+            if near is None or (same_schedule and not near["same_schedule"]):
+                near = {"file": os.path.relpath(path, ROOT), "same_schedule": same_schedule,
+                        "profile_meta": {k: meta.get(k) for k in list(key) + ["source_hash", "head"]},
+                        "this_run": dict(key, source_hash=src_hash)}
+    return None, near
 
 
 def host_cpu_share():
@@ -264,10 +290,17 @@ def main():
         driver_mt = vtiles.TileDriver(vr, split, dev, batch=fpg, lanes=[(r, s_) for r, s_, _ in lanes],
                                       force_gather=force_gather)
 
-    def render_block(j, frame_ids):
+    # the throughput warm-up renders frames of its OWN seeds (a second generator), not the timed ones:
+    # caches and the per-pixel cost map (phase 2's sort key) are primed by similar, not identical, frames
+    warm_mt = frontend.Mt19937(20261004)
+    warm_seeds = [warm_mt() for _ in range(max(fpl, fpg) * max(1, fif))]
+
+    def render_block(j, frame_ids, warm=False):
         # renderer j % fif renders these frames (their own jitter seeds) with one set of launches
         r, _, out = lanes[j % fif]
-        r.render_batch(W, H, [seeds[args.warmup + k] for k in frame_ids], out.data_ptr())
+        sd = ([warm_seeds[(j % fif) * fpl + i] for i in range(len(frame_ids))] if warm
+              else [seeds[args.warmup + k] for k in frame_ids])
+        r.render_batch(W, H, sd, out.data_ptr())
 
     # world > 1: one gather in flight -- the gather + assembly of a batch of frames overlap the
     # rendering of the next batch
@@ -280,9 +313,9 @@ def main():
     blocks = [list(range(bounds[i], bounds[i + 1])) for i in range(n_sets) if bounds[i + 1] > bounds[i]]
     drv = driver_mt if (multi and throughput) else driver
 
-    def submit_chunk(chunk):
+    def submit_chunk(chunk, warm=False):
         if throughput:   # the rank's share of all the chunk's frames: one launch set per renderer
-            drv.submit_frames([seeds[args.warmup + k] for k in chunk])
+            drv.submit_frames(warm_seeds[:len(chunk)] if warm else [seeds[args.warmup + k] for k in chunk])
             return
 
         def before(i, r=vr):
@@ -295,9 +328,9 @@ def main():
     if throughput:   # every renderer once, untimed: buffers, work queue, skip bitmap, cell grid
         if not multi:
             for j in range(fif):
-                render_block(j, blocks[0])
+                render_block(j, blocks[0], warm=True)
         else:
-            submit_chunk(chunks[0])
+            submit_chunk(chunks[0], warm=True)
             drv.collect_batch(frames)
     torch.cuda.synchronize(dev)
     if multi:
@@ -342,6 +375,8 @@ def main():
                 "profile_region": True, "workload": args.workload, "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
                 "avg_launch_ms": gpu_region_s / args.steps * 1e3,
+                "viewport": W, "view": args.view, "source_hash": source_hash(),
+                "head": os.environ.get("VRHIP_HEAD"),
                 "frames_in_flight": fif, "frames_per_launch": max(len(b_) for b_ in blocks) if throughput else 1,
                 "round_budget": args.round_budget if throughput else 10,
                 "launch_sets_in_region": len(blocks) if (not multi and throughput) else args.steps,
@@ -402,14 +437,32 @@ def main():
             n_pix = len(split.my_tiles) * args.tile * args.tile
         st1 = vr.getStats()
         # B_frame = b*64*|micro-bricks touched| + 2b*|bricks visited| + 16 B per pixel written
-        alg_bytes = b * 64 * mb + 2 * b * st1["bricks_visited"] + 16 * n_pix
+        ref_set_bytes = b * 64 * mb + 2 * b * st1["bricks_visited"] * (0 if technique == 1 else 1) + 16 * n_pix
+        alg_bytes, alg_note = ref_set_bytes, ("b*64*|micro-bricks touched by >= 1 fetch of the reference's sample set| + "
+                                              "2b*|bricks visited| + 16 B per pixel (SURVEY 8d B_frame)")
+        if technique == 1 and world == 1:
+            # The path tracer does not move the reference's fetch set: a tracking step whose cell bound is
+            # below the walk's threshold is a rejection whatever the voxels hold and is never fetched.  It is
+            # priced against the micro-bricks its OWN fetches touch (vrhip_count_fetched: culling on, no
+            # speculative steps) -- bytes the kernel can be shown to need.
+            mbf = vr.countFetched(W, H)
+            alg_bytes = b * 64 * mbf + 16 * n_pix
+            alg_note = ("b*64*|micro-bricks touched by the fetches the opacity-bound culling lets through| + 16 B per "
+                        "pixel; the reference's un-culled fetch set would be %d bytes" % ref_set_bytes)
         # The ray-cast pass is ONE logical kernel issued as two back-to-back launches (phase 1:
         # budgeted march of every ray; phase 2: the suspended long rays, 4 lanes per ray).  Its
         # duration = HIP events over the timed region on the launch stream / K (world == 1; with
         # the gather in the region at world > 1 the vrhip events of the last pass are used).
         kernel_s = gpu_region_s / args.steps if not multi else last_kernel_s
         achieved = alg_bytes / kernel_s / 1e9
-        traffic = pmc_traffic(args.workload) if not multi else None
+        src = source_hash()
+        key = schedule_key(args.workload, W, args.view, fif, max(len(b_) for b_ in blocks) if throughput else 1,
+                           args.round_budget if throughput else 10)
+        traffic, traffic_stale = find_profile("traffic", key, src) if not multi else (None, None)
+        hbm_traffic = traffic["hbm_bytes_per_pass"] if traffic else None
+        # a fraction of the HBM peak is only printed when the counters agree that the kernel moves at
+        # least its algorithmic bytes (otherwise the accounting, not the kernel, is what was measured)
+        frac_ok = hbm_traffic is None or hbm_traffic >= 0.95 * alg_bytes
         roofline = {
             "kernel": ("vr_pathtrace_kernel <%s>, one launch per sample-per-pixel pass" % fmt_name.lower())
                       if technique == 1 else
@@ -417,20 +470,23 @@ def main():
                       "(counting sort) + vr_raycast_split_kernel, back-to-back launches per set of frames"
                       % (fmt_name.lower(), ess),
             "bound": "hbm",
-            "achieved": achieved,
+            "achieved": achieved if frac_ok else None,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic["hbm_bytes_per_pass"] if traffic else None,
-            "traffic_detail": ({k: traffic.get(k) for k in ("source", "fetch_bytes_raw_per_pass",
+            "frac": achieved / HBM_PEAK_GBS if frac_ok else None,
+            "traffic": hbm_traffic,
+            "traffic_detail": ({k: traffic.get(k) for k in ("file", "source", "fetch_bytes_raw_per_pass",
                                                              "write_bytes_per_pass", "fetch_correction",
-                                                             "calibration", "note")}
+                                                             "calibration", "note", "meta")}
                                if traffic else None),
+            "stale_profile": traffic_stale,
             "algorithmic_bytes_per_launch": int(alg_bytes),
+            "algorithmic_bytes_note": alg_note,
             "avg_launch_ms": kernel_s * 1e3,
             "frames_in_flight": fif,
             "frames_per_launch": max(len(b_) for b_ in blocks) if throughput else 1,
             "round_budget": args.round_budget if throughput else 10,
+            "viewport": W, "view": args.view, "source_hash": src,
             "serial_launch_ms": serial_s * 1e3 if serial_s else None,
             "launch_note": ("%d renderer(s) on as many streams over one shared volume, each rendering up to %d independent "
                             "frames (own jitter seeds) per set of launches (vrhip_render_batch): avg_launch_ms = "
@@ -443,13 +499,14 @@ def main():
                                         "total": last_kernel_s * 1e3},
             "request_bytes_per_launch": int(b * 8 * (st1["samples_taken"] +
                                                     6 * st1["samples_shaded"])),
-            "note": "not HBM-bound: a latency/issue-bound march (DESIGN.md 'Kernels'); the "
-                    "streaming kernel of the path is vr_build_bricks (see bricks_build)",
+            "note": ("not HBM-bound: bound by VALU issue (roofline_valu_issue; DESIGN.md 'Kernels'); the "
+                     "streaming kernel of the path is vr_build_bricks (see bricks_build)") +
+                    ("" if frac_ok else "; no fraction printed: the counters' traffic is BELOW the algorithmic bytes"),
         }
         # What actually bounds the march: VALU issue.  A gfx950 SIMD issues one wave64 VALU
         # instruction per 2 cycles (MI355X_MICROARCH.md "Wave scheduling"; = the 157.3 TFLOP/s fp32
         # vector peak / 128 flops), so the chip peaks at 256 CUs x 4 SIMDs x 2.4 GHz / 2.
-        issue = pmc_issue(args.workload) if not multi else None
+        issue, issue_stale = find_profile("issue", key, src) if not multi else (None, None)
         if issue:
             peak_wi = 256 * 4 * 2.4e9 / 2.0
             ach_wi = issue["valu_wave_insts_per_frame"] / kernel_s
@@ -465,10 +522,16 @@ def main():
                 "frac_of_measured": ach_wi / 5.76e11,
                 "valu_wave_insts_per_frame": issue["valu_wave_insts_per_frame"],
                 "valu_lane_utilisation": issue.get("valu_lane_utilisation"),
-                "source": issue.get("source"),
-                "note": "SQ_INSTS_VALU of the timed launches (rocprofv3 --pmc of `bench.py --profile-region`, "
-                        "committed under profiles/) / frames, over this run's avg_launch_ms",
+                "source": issue.get("file"),
+                "profile_meta": issue.get("meta"),
+                "note": "SQ_INSTS_VALU of the timed launches (rocprofv3 --pmc of `bench.py --profile-region` with this "
+                        "run's workload, viewport, schedule and kernel sources, committed under profiles/) / frames, "
+                        "over this run's avg_launch_ms",
             }
+        elif issue_stale:
+            roofline_valu = {"bound": "valu_issue", "achieved": None, "frac": None, "stale_profile": issue_stale,
+                             "note": "no committed PMC profile matches this run's schedule and kernel sources "
+                                     "(tools/profile_region.sh regenerates it)"}
         if world == 1 and not args.no_cpu_baseline:
             vol_host = vr.downloadVolume()
             bricks_host = vr.downloadBricks()

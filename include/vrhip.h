@@ -262,6 +262,12 @@ int vrhip_get_stats(const vrhip_renderer *r, vrhip_stats *out);
  * SURVEY 8d B_frame). Optionally returns the bitmap (ceil(res/4)^3 bits). */
 int vrhip_count_touched(vrhip_renderer *r, uint32_t width, uint32_t height,
                         uint64_t *microbricks_touched, uint8_t *bitmap_host, size_t bitmap_bytes);
+/* Path tracer (technique 1): the micro-bricks touched by the voxel fetches the PRODUCT issues -- tracking
+ * steps the opacity bound of their cell cannot rule out (the others are rejections whatever the voxels
+ * hold and are never fetched) plus the gradient at the primary interaction; speculative steps of a batch
+ * excluded.  vrhip_count_touched counts the reference's fetch set (every step inside the volume).  The
+ * difference is the traffic the culling removes; bench.py prices the kernel against THIS set. */
+int vrhip_count_fetched(vrhip_renderer *r, uint32_t width, uint32_t height, uint64_t *microbricks_fetched);
 /* Same for a tile subset (arguments as vrhip_render_tiles); also fills vrhip_get_stats. */
 int vrhip_count_touched_tiles(vrhip_renderer *r, uint32_t width, uint32_t height,
                               uint32_t tile_w, uint32_t tile_h, const uint32_t *tile_ids,

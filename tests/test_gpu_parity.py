@@ -1315,6 +1315,57 @@ def test_config3_size_volume_matches_oracle():
         r.close()
 
 
+def test_config5_size_pathtrace_matches_oracle():
+    """BASELINE config 5's size and field: 1024^3 FLOAT sphere, technique 1 (Woodcock-tracking
+    path tracer, max_extinction 100).  Field generated in HBM, downloaded (4 GiB); iterations 0-2 of the
+    progressive render (running mean, std::mt19937 seed stream) of a small frame through the instrumented
+    and the production kernels against the oracle; the micro-bricks the product's own fetches touch are a
+    subset of the reference's fetch set."""
+    N = 1024
+    tff = common.tffs()["default"]
+    W, H = 96, 80
+    r = VolumeRenderCL()
+    r.initialize()
+    try:
+        r.synthVolume("sphere", (N, N, N), FLOAT)
+        vol = r.downloadVolume(0)
+        assert vol.shape == (N, N, N) and vol.dtype == np.float32
+        c = 2.0 * (np.arange(N) + 0.5) / N - 1.0          # the field on two slices (SURVEY 8d formula)
+        for z in (300, N // 2):
+            rr = np.sqrt(c[None, :] ** 2 + c[:, None] ** 2 + c[z] ** 2)
+            np.testing.assert_allclose(vol[z], np.maximum(1.0 - rr / 0.9, 0.0).astype(np.float32), atol=2e-7)
+        r.setTransferFunction(tff)
+        r.setTechnique(1)
+        r.setExtinction(100.0)
+        r.updateView(common.views()["rot30"])
+        for stats in (True, False):
+            r.setStatsEnabled(stats)
+            mt = frontend.Mt19937()
+            ref = None
+            for it in range(3):
+                seed = mt()
+                r.setSeed(seed)
+                r.setIteration(it)
+                got = r.runRaycastNoGL(W, H)
+                cam, rp, rc, pt = common.to_oracle_params(*r.params())
+                rp.seed, rp.iteration = seed, it
+                ref, rstats, _ = vro.render_tile(vol, FLOAT, tff, cam, rp, rc, pt, W=W, H=H, in_accum=ref)
+                assert np.abs(got.astype(np.float64) - ref).max() <= TOL, "stats=%s iteration %d" % (stats, it)
+                if stats:
+                    g = r.getStats()
+                    assert g["bricks_skipped"] <= g["bricks_visited"] <= g["samples_taken"]
+                    assert dict(g, bricks_visited=0, bricks_skipped=0) == rstats
+                    assert g["bricks_skipped"] > 0.9 * g["samples_taken"]     # the sphere culls too
+        r.setStatsEnabled(False)
+        r.setSeed(SEED)
+        r.setIteration(0)
+        n_ref, _ = r.countTouched(W, H)
+        n_fetched = r.countFetched(W, H)
+        assert 0 < n_fetched < n_ref
+    finally:
+        r.close()
+
+
 def test_shared_volume_twin_renders_the_same_frames(vr):
     """vrhip_share_volumes / VolumeRenderCL.shareVolumes: a second renderer on its own stream
     renders from the first one's voxels and bricks; frames of both equal the oracle's, also when

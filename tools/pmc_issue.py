@@ -64,6 +64,12 @@ def main():
     res["valu_wave_insts_per_frame"] = tot.get("SQ_INSTS_VALU", 0.0)
     if tot.get("SQ_THREAD_CYCLES_VALU") and tot.get("SQ_INSTS_VALU"):
         res["valu_lane_utilisation"] = min(1.0, tot["SQ_THREAD_CYCLES_VALU"] / max(tot["SQ_ACTIVE_INST_VALU"], 1.0) / 64.0)
+    # the run the counters belong to (bench.py --profile-region's own JSON line: workload, viewport, view,
+    # renderers in flight, frames per launch set, round budget, hash of the kernel sources): bench.py
+    # uses a profile only for a run with the same meta
+    meta_path = os.path.join(prof, "bench.json")
+    if os.path.exists(meta_path):
+        res["meta"] = json.load(open(meta_path))
     allj = {}
     if os.path.exists(out_path):
         allj = json.load(open(out_path))

@@ -68,6 +68,12 @@ def main():
     res["note"] = ("per frame: FETCH_SIZE x2 (gfx950 rule for wide streams; byte gathers uncalibrated, so an "
                    "estimate) + WRITE_SIZE, summed over every launch of the ray-cast pass in the region and "
                    "divided by the frames those launches rendered")
+    # the run the counters belong to (bench.py --profile-region's own JSON line: workload, viewport, view,
+    # renderers in flight, frames per launch set, round budget, hash of the kernel sources): bench.py
+    # uses a profile only for a run with the same meta
+    meta_path = os.path.join(prof, "bench.json")
+    if os.path.exists(meta_path):
+        res["meta"] = json.load(open(meta_path))
     allj = {}
     if os.path.exists(out_path):
         allj = json.load(open(out_path))

@@ -107,6 +107,7 @@ SYMBOLS = {
     "vrhip_get_stats": (C.c_int, [_H, C.POINTER(Stats)]),
     "vrhip_count_touched": (C.c_int, [_H, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64),
                                       C.c_void_p, C.c_size_t]),
+    "vrhip_count_fetched": (C.c_int, [_H, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
     "vrhip_count_touched_tiles": (C.c_int, [_H, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                             C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]),
 }

@@ -101,9 +101,12 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
     const uint32_t lane = threadIdx.x & 63u;
     const int tffn = (int)tf.tff_n;
     unsigned long long c_taken = 0, c_hit = 0, c_culled = 0;
-    // The instrumented traffic variant reproduces the reference's fetch set: no culling.
+    // The instrumented traffic variant (INSTR 2) reproduces the reference's fetch set: no culling.
+    // INSTR 3 records the micro-bricks of the fetches the culling lets through -- what the production
+    // kernel needs from the volume (vrhip_count_fetched).
     const bool cull = INSTR != 2 && grid.bound != nullptr;
-    Vol<VT, INSTR> vol;
+    constexpr int VI = INSTR == 3 ? 2 : INSTR;   // the sampler's instrumentation level
+    Vol<VT, VI> vol;
     vol.p = (const VT *)vv.data;
     vol.w1 = vv.w - 1; vol.h1 = vv.h - 1; vol.d1 = vv.d - 1;
     vol.fw = vv.fw; vol.fh = vv.fh; vol.fd = vv.fd;
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
     vol.ystride = vv.ystride; vol.zstride = (uint32_t)vv.zstride;
     vol.touched = touched;
     // the traffic-instrumented variant must not touch speculative voxels: one step per round
-    constexpr int B = INSTR == 2 ? 1 : kPtBatch;
+    constexpr int B = INSTR >= 2 ? 1 : kPtBatch;
 
     PtPixel px = {};
     int state = P_FETCH;
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
 #pragma unroll
             for (int k = 0; k < B; ++k) {
                 dens[k] = 0.f;
-                if (need[k] || (INSTR != 2 && !cull))
+                if (need[k] || (INSTR < 2 && !cull))
                     dens[k] = vol.linear(pk[k].x * 0.5f + 0.5f, pk[k].y * 0.5f + 0.5f, pk[k].z * 0.5f + 0.5f);
             }
             // (the opacity only matters where the step was fetched: :432 below tests `need` first)
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
                     px.hit_pos = px.apos;
                     const f3 sp = mk3(px.apos.x * 0.5f + 0.5f, px.apos.y * 0.5f + 0.5f,
                                       px.apos.z * 0.5f + 0.5f);
-                    const float4 gq = gradient_tff<VT, INSTR>(vol, s_tff, tffn, sp);
+                    const float4 gq = gradient_tff<VT, VI>(vol, s_tff, tffn, sp);
                     const float g0 = -gq.x, g1 = -gq.y, g2 = -gq.z, g3 = -gq.w;
                     const float glen = sqrtf((((g0 * g0) + (g1 * g1)) + (g2 * g2)) + (g3 * g3));
                     if (glen > 0.5f) {   // :483-486 high gradient: Phong
@@ -366,6 +369,7 @@ hipError_t launch_pt_typed(const RaycastLaunch &a, hipStream_t stream)
 {
     if (a.instr == 0) return launch_pt<VT, 0>(a, stream);
     if (a.instr == 1) return launch_pt<VT, 1>(a, stream);
+    if (a.instr == 3) return launch_pt<VT, 3>(a, stream);
     return launch_pt<VT, 2>(a, stream);
 }
 

@@ -937,7 +937,8 @@ int prepare_render(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t 
 
 int count_touched_impl(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t tile_w,
                        uint32_t tile_h, const uint32_t *tile_ids, uint32_t n_tiles,
-                       uint64_t *microbricks_touched, uint8_t *bitmap_host, size_t bitmap_bytes)
+                       uint64_t *microbricks_touched, uint8_t *bitmap_host, size_t bitmap_bytes,
+                       bool fetched_only = false)
 {
     if (!r) return VRHIP_ERR_INVALID;
     if (set_device(r)) return VRHIP_ERR_HIP;
@@ -952,7 +953,7 @@ int count_touched_impl(vrhip_renderer *r, uint32_t width, uint32_t height, uint3
     hipError_t e = hipMemsetAsync(bits, 0, words * sizeof(uint32_t), r->stream);
     RaycastLaunch a;
     fill_launch(r, width, height, tile_ids ? tile_w : width, &a);
-    a.instr = 2;
+    a.instr = fetched_only ? 3 : 2;
     a.touched = bits;
     // the instrumented pass must not disturb the accumulate buffer: render into a scratch
     float4 *scratch = nullptr;
@@ -1759,6 +1760,13 @@ int vrhip_count_touched(vrhip_renderer *r, uint32_t width, uint32_t height,
 {
     return count_touched_impl(r, width, height, 0, 0, nullptr, 0, microbricks_touched,
                               bitmap_host, bitmap_bytes);
+}
+
+int vrhip_count_fetched(vrhip_renderer *r, uint32_t width, uint32_t height, uint64_t *microbricks_fetched)
+{
+    if (r && r->render.technique != 1)
+        return fail(r, VRHIP_ERR_UNSUPPORTED, "vrhip_count_fetched: technique 1 (path tracer) only");
+    return count_touched_impl(r, width, height, 0, 0, nullptr, 0, microbricks_fetched, nullptr, 0, true);
 }
 
 int vrhip_count_touched_tiles(vrhip_renderer *r, uint32_t width, uint32_t height,

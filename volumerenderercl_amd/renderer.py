@@ -567,6 +567,13 @@ class VolumeRenderCL:
             bm.nbytes if bm is not None else 0))
         return int(n.value), bm
 
+    def countFetched(self, width, height):
+        """technique 1: micro-bricks the product's own fetches touch (vrhip_count_fetched)."""
+        n = C.c_uint64()
+        self._push_params()
+        self._check(self._lib.vrhip_count_fetched(self._h, int(width), int(height), C.byref(n)))
+        return int(n.value)
+
     def countTouchedTiles(self, width, height, tile_w, tile_h, tile_ids):
         n = C.c_uint64()
         ids = np.ascontiguousarray(tile_ids, dtype=np.uint32)
