@@ -234,50 +234,186 @@ __global__ __launch_bounds__(kThreads) void vr_downsample_kernel(VolView vol, in
     }
 }
 
-// Footprint volume: entries in memory order (coalesced 8/16/32-byte stores), grid-stride (a launch
-// is limited to 2^32 threads; 2048^3 has 8.6e9 entries); the eight source voxels come from at
-// most eight micro-bricks of the volume (cached gathers).
+// Footprint volume (VolView::fp): entry (ex, ey, ez) = the 8 voxels (ex - 1 + dx, ey - 1 + dy, ez - 1 + dz),
+// edge-clamped, value j = dx + 2 dy + 4 dz; entries in 4x4x4 micro-bricks like the voxels.  A pure stream:
+// b N^3 bytes read, 8 b N^3 written (69 GB at 2048^3 UCHAR), so the kernel must be bound by HBM, not by
+// address arithmetic or by the load path.
+//
+// A thread makes one z slice of an output micro-brick: 16 entries = 128 b contiguous bytes, from two voxel
+// slices (z - 1, z) of 5 x 5 voxels each.  Per slice it loads the source micro-brick's slice whole (16
+// voxels, one 16 b-byte load; four lanes cover a 64 b-byte brick), the slice of the brick on its left (for
+// its last column), row 3 of the brick below in y and one voxel of the diagonal one: 8 loads for 16 entries
+// where an entry per thread needed 8 byte gathers each (and was bound by instruction issue: 40.6 ms at
+// 2048^3, 24 % of the HBM peak).  Clamping is a fix-up of the loaded slices -- columns, rows and slices
+// beyond the volume take the last valid one's values -- so there is no slow path.  The wave's 64 x 128 b
+// bytes are contiguous (16 bricks along x); they go through LDS once so that every store instruction writes
+// 1 KB of whole lines (half-written lines cost a read-modify-write in the L2: +20 %).
+constexpr int kFpThreads = 64;   // one wave per workgroup: its LDS staging is its own, no barriers
+template <typename VT> struct Vox4;   // four voxels as one load
+template <> struct Vox4<uint8_t> { using type = uint32_t; };
+template <> struct Vox4<uint16_t> { using type = uint2; };
+template <> struct Vox4<float> { using type = uint4; };
+
 template <typename VT>
-__global__ __launch_bounds__(kThreads) void vr_build_footprint_kernel(VolView vv)
+__global__ __launch_bounds__(kFpThreads) void vr_build_footprint_kernel(VolView vv, int nbz_fp)
 {
-    const unsigned long long n = (unsigned long long)vv.fp_nbx * vv.fp_nby *
-                                 (unsigned long long)((vv.d + 4) >> 2) * 64ull;
-    const unsigned long long stride = (unsigned long long)gridDim.x * kThreads;
+    constexpr int SV = (int)(16 * sizeof(VT) / 16);   // uint4 per 16-voxel slice: 1 / 2 / 4
+    constexpr int C = 8 * (int)sizeof(VT);            // 16-byte chunks a thread makes: 8 / 16 / 32
+    __shared__ uint4 s_w[kFpThreads * C];
     const VT *p = (const VT *)vv.data;
     VT *out = (VT *)const_cast<void *>(vv.fp);
-    for (unsigned long long i = (unsigned long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
-        const unsigned long long brick = i >> 6;
-        const int in = (int)(i & 63ull);
-        const int bx = (int)(brick % vv.fp_nbx), by = (int)((brick / vv.fp_nbx) % vv.fp_nby);
-        const int bz = (int)(brick / ((unsigned long long)vv.fp_nbx * vv.fp_nby));
-        const int ex = bx * 4 + (in & 3), ey = by * 4 + ((in >> 2) & 3), ez = bz * 4 + (in >> 4);
-        VT e[8];
+    const int lane = (int)threadIdx.x;
+    const int lz = lane & 3;
+    const int wave_bx0 = (int)blockIdx.x * 16;
+    const int bxo = wave_bx0 + (lane >> 2);           // output brick (entries 4 bxo .. 4 bxo + 3)
+    const int by = (int)blockIdx.y, bz = (int)blockIdx.z;
+    const int nbx = (int)vv.nbx, nby = (int)vv.nby;
+    // source bricks, clamped into the volume (a clamped brick's values are replaced by the fix-ups below)
+    const int bx = min(bxo, nbx - 1), bxl = max(min(bxo - 1, nbx - 1), 0);
+    const int byc = min(by, nby - 1), byl = max(min(by - 1, nby - 1), 0);
+    // valid columns / rows of the CURRENT source brick as seen from this output brick: voxel 4 bxo + x
+    // exists for x < mx (0: the output brick lies beyond the volume, everything clamps to the left one)
+    const int mx = min(max(vv.w - 4 * bxo, 0), 4), my = min(max(vv.h - 4 * by, 0), 4);
+    uint4 src[C];   // the thread's 16 entries [ly][lx][j], 128 b bytes
+    // UCHAR bricks that need no clamping (all but the volume's faces): the rows stay packed -- a row of a
+    // slice IS a dword of the 16-byte load -- and v_perm_b32 cuts the byte pairs out of them: 52 permutes
+    // per thread where the compiler's byte-by-byte packing of the generic code below takes ~250 instructions
+    const bool plain = sizeof(VT) == 1 && bxo >= 1 && mx == 4 && by >= 1 && my == 4;
+    if (sizeof(VT) == 1 && plain) {
+        uint32_t o32[32];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int x = min(max(ex - 1 + (j & 1), 0), vv.w - 1);
-            const int y = min(max(ey - 1 + ((j >> 1) & 1), 0), vv.h - 1);
-            const int z = min(max(ez - 1 + (j >> 2), 0), vv.d - 1);
-            e[j] = p[vr_voxel_index(vv, x, y, z)];
+        for (int dz = 0; dz < 2; ++dz) {
+            const int z = min(max(bz * 4 + lz - 1 + dz, 0), vv.d - 1);
+            const unsigned long long zoff = (unsigned long long)(z >> 2) * vv.zstride + (unsigned long long)((z & 3) << 4);
+            const unsigned long long a_cur = zoff + (unsigned long long)by * vv.ystride + ((unsigned long long)bxo << 6);
+            const unsigned long long a_down = a_cur - vv.ystride;
+            const uint4 A4 = *reinterpret_cast<const uint4 *>(p + a_cur);
+            const uint4 L4 = *reinterpret_cast<const uint4 *>(p + a_cur - 64);
+            const uint32_t D1 = *reinterpret_cast<const uint32_t *>(p + a_down + 12);
+            const uint32_t dg1 = (uint32_t)p[a_down - 64 + 15];
+            const uint32_t Aw[5] = {D1, A4.x, A4.y, A4.z, A4.w};
+            const uint32_t Lw[5] = {dg1, L4.x, L4.y, L4.z, L4.w};
+            uint32_t Q0[5], Q1[5];   // byte pairs (c0 c1)(c1 c2) and (c2 c3)(c3 c4) of the five-voxel rows
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                Q0[r] = __builtin_amdgcn_perm(Aw[r], Lw[r], r == 0 ? 0x05040400u : 0x05040403u);
+                Q1[r] = __builtin_amdgcn_perm(Aw[r], Aw[r], 0x03020201u);
+            }
+#pragma unroll
+            for (int ly = 0; ly < 4; ++ly)
+#pragma unroll
+                for (int lx = 0; lx < 4; ++lx) {
+                    const uint32_t lo = lx < 2 ? Q0[ly] : Q1[ly], hi = lx < 2 ? Q0[ly + 1] : Q1[ly + 1];
+                    o32[(ly * 4 + lx) * 2 + dz] = __builtin_amdgcn_perm(hi, lo, (lx & 1) ? 0x07060302u : 0x05040100u);
+                }
+        }
+        __builtin_memcpy(src, o32, sizeof src);
+    } else {
+    VT o[128];   // [ly][lx][j]
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz) {
+        const int z = min(max(bz * 4 + lz - 1 + dz, 0), vv.d - 1);   // the slice, clamped in z
+        const unsigned long long zoff = (unsigned long long)(z >> 2) * vv.zstride + (unsigned long long)((z & 3) << 4);
+        const unsigned long long a_cur = zoff + (unsigned long long)byc * vv.ystride + ((unsigned long long)bx << 6);
+        const unsigned long long a_left = zoff + (unsigned long long)byc * vv.ystride + ((unsigned long long)bxl << 6);
+        const unsigned long long a_down = zoff + (unsigned long long)byl * vv.ystride + ((unsigned long long)bx << 6);
+        const unsigned long long a_diag = zoff + (unsigned long long)byl * vv.ystride + ((unsigned long long)bxl << 6);
+        VT A[16], L[16], D[4];   // current slice [y][x]; left brick's slice; row 3 of the brick below
+        {
+            uint4 t[SV];
+#pragma unroll
+            for (int q = 0; q < SV; ++q) t[q] = reinterpret_cast<const uint4 *>(p + a_cur)[q];
+            __builtin_memcpy(A, t, sizeof A);
+#pragma unroll
+            for (int q = 0; q < SV; ++q) t[q] = reinterpret_cast<const uint4 *>(p + a_left)[q];
+            __builtin_memcpy(L, t, sizeof L);
+        }
+        {
+            const typename Vox4<VT>::type t = *reinterpret_cast<const typename Vox4<VT>::type *>(p + a_down + 12);
+            __builtin_memcpy(D, &t, sizeof D);
+        }
+        const VT dg = p[a_diag + 15];
+        // rows y = -1 .. 3 of five voxels x = -1 .. 3 (relative to the output brick's first voxel)
+        VT R[5][5];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) R[0][x + 1] = D[x];
+        R[0][0] = dg;
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            R[y + 1][0] = L[y * 4 + 3];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) R[y + 1][x + 1] = A[y * 4 + x];
+        }
+        // ---- clamping as fix-ups (uniform per brick, rare): what lies beyond the volume repeats the last
+        // voxel inside.  x: the left column is voxel 4 bxo - 1 (or voxel 0 for the first brick: clamp of -1)
+        // (voxel 4 bxo - 1 itself always exists: entries stop at ex = w, i.e. bxo <= ceil((w + 1) / 4) - 1)
+        if (bxo == 0) {
+#pragma unroll
+            for (int y = 0; y < 5; ++y) R[y][0] = R[y][1];
+        }
+        if (mx < 4) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+                if (x >= mx) {
+#pragma unroll
+                    for (int y = 0; y < 5; ++y) R[y][x + 1] = R[y][x];   // (x ascending: the last valid value runs on)
+                }
+        }
+        // y: row -1 of the first brick row clamps to row 0; rows beyond the volume repeat the last one inside
+        if (by == 0) {
+#pragma unroll
+            for (int x = 0; x < 5; ++x) R[0][x] = R[1][x];
+        }
+        if (my < 4) {
+#pragma unroll
+            for (int y = 0; y < 4; ++y)
+                if (y >= my) {
+#pragma unroll
+                    for (int x = 0; x < 5; ++x) R[y + 1][x] = R[y][x];
+                }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) out[i * 8ull + j] = e[j];
+        for (int ly = 0; ly < 4; ++ly)
+#pragma unroll
+            for (int lx = 0; lx < 4; ++lx)
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) o[(ly * 4 + lx) * 8 + dx + 2 * dy + 4 * dz] = R[ly + dy][lx + dx];
+    }
+    __builtin_memcpy(src, o, sizeof src);
+    }
+    // thread t of the wave owns chunks [t C, t C + C) of the wave's 64 C contiguous chunks; chunk k 64 + lane
+    // goes out with store k
+#pragma unroll
+    for (int k = 0; k < C; ++k) s_w[lane * C + k] = src[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (one wave: LDS operations execute in order)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const unsigned long long brick0 = ((unsigned long long)bz * vv.fp_nby + (unsigned long long)by) * vv.fp_nbx +
+                                      (unsigned long long)wave_bx0;
+    uint4 *dst = reinterpret_cast<uint4 *>(out + brick0 * 512ull);   // 64 entries x 8 values per brick
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+        const int chunk = k * 64 + lane;                  // 4 C chunks per brick
+        if (wave_bx0 + chunk / (4 * C) < (int)vv.fp_nbx) dst[chunk] = s_w[chunk];
     }
 }
 
 hipError_t vr_launch_build_footprint(const VolView &vol, int format, hipStream_t stream)
 {
-    const unsigned long long n = (unsigned long long)vol.fp_nbx * vol.fp_nby *
-                                 (unsigned long long)((vol.d + 4) >> 2) * 64ull;
-    dim3 grid((unsigned)std::min<unsigned long long>((n + kThreads - 1) / kThreads, 1ull << 22)), block(kThreads);
+    const int nbz = (vol.d + 4) >> 2;
+    dim3 grid((vol.fp_nbx + 15) / 16, vol.fp_nby, (unsigned)nbz), block(kFpThreads);
+    if (grid.y > 65535u || grid.z > 65535u) return hipErrorInvalidValue;   // (8192^3 voxels: 2049 bricks per axis)
     switch (format) {
     case VRHIP_UCHAR:
-        hipLaunchKernelGGL(vr_build_footprint_kernel<uint8_t>, grid, block, 0, stream, vol);
+        hipLaunchKernelGGL(vr_build_footprint_kernel<uint8_t>, grid, block, 0, stream, vol, nbz);
         break;
     case VRHIP_USHORT:
-        hipLaunchKernelGGL(vr_build_footprint_kernel<uint16_t>, grid, block, 0, stream, vol);
+        hipLaunchKernelGGL(vr_build_footprint_kernel<uint16_t>, grid, block, 0, stream, vol, nbz);
         break;
     case VRHIP_FLOAT:
-        hipLaunchKernelGGL(vr_build_footprint_kernel<float>, grid, block, 0, stream, vol);
+        hipLaunchKernelGGL(vr_build_footprint_kernel<float>, grid, block, 0, stream, vol, nbz);
         break;
     default: return hipErrorInvalidValue;
     }
