@@ -60,9 +60,10 @@ def parse():
     ap.add_argument("--workload", default="shells2048", choices=sorted(WORKLOADS))
     ap.add_argument("--viewport", type=int, default=1024)
     ap.add_argument("--tile", type=int, default=64, help="tile edge for the multi-GPU split")
-    ap.add_argument("--frames-per-gather", type=int, default=64,
+    ap.add_argument("--frames-per-gather", type=int, default=0,
                     help="multi-GPU: independent frames per RCCL gather (each renderer of a rank renders "
-                         "its half of them in one set of launches: <= 32 frames per set)")
+                         "its half of them in one set of launches: <= 256 frames per set); 0 = 32 per rank, "
+                         "at least 64: a rank's share of a set is then worth four whole frames or more")
     ap.add_argument("--frames-per-launch", type=int, default=16,
                     help="independent frames (own jitter seeds) rendered by one set of launches "
                          "(vrhip_render_batch); 1 = one frame per launch set")
@@ -256,7 +257,8 @@ def main():
     frame = torch.empty((H, W, 4), dtype=torch.float32, device=dev) if rank == 0 else None
     # world > 1: `--frames-per-gather` independent frames share one collective (fewer, larger
     # gathers: the host-side cost of a collective is comparable to a rank's rendering time)
-    fpg = max(1, min(args.frames_per_gather, args.steps))
+    fpg_want = args.frames_per_gather if args.frames_per_gather > 0 else max(64, 32 * world)
+    fpg = max(1, min(fpg_want, args.steps, 256 * max(1, args.frames_in_flight)))
     fif = max(1, args.frames_in_flight) if technique == 0 else 1
     fpl = max(1, min(args.frames_per_launch, 32)) if technique == 0 else 1
     throughput = fif > 1 or fpl > 1

@@ -232,7 +232,7 @@ int vrhip_assemble_frame(vrhip_renderer *r, const float *staging_dev, const uint
                          uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h,
                          float *frame_dev);
 
-/* A batch of n_frames <= 32 INDEPENDENT frames -- same camera and parameters, frame f with jitter
+/* A batch of n_frames <= 256 INDEPENDENT frames (n_frames x pixels per frame < 2^32) -- same camera and parameters, frame f with jitter
  * seed seeds[f] (rendering_params.seed is not used) -- in ONE set of launches: the work queue holds
  * every patch once per frame, so a small tile share still fills the GPU and the latency chain of
  * a frame (pre-pass, phase-1 rounds, sort, the longest rays of phase 2) is paid once per batch.

@@ -1205,7 +1205,7 @@ def test_headline_size_volume_matches_oracle():
 
 def _config4_tile_split_at_size(r, vol, tff, ref_bricks):
     """BASELINE config 4 as far as one GPU goes: the 2048^2 frame of the 2048^3 volume cut into 64 x 64
-    tiles for EIGHT ranks (diagonal interleave), the eight tile shares rendered one after the other on
+    tiles for EIGHT ranks (dealt by distance from the centre), the eight tile shares rendered one after the other on
     this GPU through eight TileDrivers -- instrumented kernels (summed work counters) and production
     kernels -- gathered by a stand-in collective that hands rank 0 the peers' blocks, assembled by rank
     0's driver, and compared with the oracle's frame of the whole viewport."""
@@ -1696,11 +1696,13 @@ def test_tile_driver_submit_frames_on_one_gpu(vr):
     twin.set_stream(s2.cuda_stream)
     vr.set_stream(torch.cuda.current_stream().cuda_stream)
     try:
-        # the share of "rank 3 of 4", which has fewer tiles than the slot count of the gather
-        split = tiles.TileSplit(W, H, T, T, 4, 3)
+        # the share of a rank of 4 that has fewer tiles than the slot count of the gather
+        probe = tiles.TileSplit(W, H, T, T, 4, 0)
+        short = min(range(4), key=lambda k: len(probe.tiles_of[k]))
+        split = tiles.TileSplit(W, H, T, T, 4, short)
         assert len(split.my_tiles) < split.cap
-        split.rank = 0          # assemble locally; the stand-in puts the block where rank 3's goes
-        drv = tiles.TileDriver(vr, split, dev, dist=OneRankDist(3), batch=6,
+        split.rank = 0          # assemble locally; the stand-in puts the block where that rank's goes
+        drv = tiles.TileDriver(vr, split, dev, dist=OneRankDist(short), batch=6,
                                lanes=[(vr, torch.cuda.current_stream()), (twin, s2)])
         seeds = [SEED, 581869302, 3890346734, 3586334585, 545404204]
         frames = torch.zeros((6, H, W, 4), dtype=torch.float32, device=dev)
@@ -1721,7 +1723,8 @@ def test_tile_driver_submit_frames_on_one_gpu(vr):
 
 
 def test_batch_with_the_maximum_number_of_frames(vr):
-    """32 frames per batch: the frame index uses all five spare bits of the work items."""
+    """256 frames per batch: the frame index uses all ten spare bits of the work items (five of the
+    patch row, five of the patch column)."""
     import torch
     vol = common.noise_volume((40, 40, 40), UCHAR, seed=35, smooth=False)
     tff = common.tffs()["default"]
@@ -1729,17 +1732,32 @@ def test_batch_with_the_maximum_number_of_frames(vr):
     _setup(vr, vol, UCHAR, tff, common.views()["rot30"])
     vr.setStatsEnabled(False)
     mt = frontend.Mt19937()
-    seeds = [mt() for _ in range(32)]
-    out = torch.zeros((32, H, W, 4), dtype=torch.float32, device="cuda")
+    N = 256
+    seeds = [mt() for _ in range(N)]
+    out = torch.zeros((N, H, W, 4), dtype=torch.float32, device="cuda")
     vr.render_batch(W, H, seeds, out.data_ptr())
     torch.cuda.synchronize()
     got = out.cpu().numpy()
-    for f in (0, 1, 15, 16, 30, 31):
+    for f in (0, 1, 15, 16, 31, 32, 33, 63, 64, 127, 128, 200, 254, 255):
         vr.setSeed(seeds[f])
         vr.setIteration(0)
         assert np.array_equal(got[f], vr.runRaycastNoGL(W, H)), "frame %d" % f
     with pytest.raises(ValueError):
         vr.render_batch(W, H, seeds + [1], out.data_ptr())
+    # a tile share of many frames, frames apart by a stride (what a rank of a multi-GPU split renders)
+    from volumerenderercl_amd import tiles
+    split = tiles.TileSplit(W, H, 16, 16, 4, 1)
+    n = len(split.my_tiles)
+    stride = (n + 1) * 16 * 16
+    tout = torch.zeros((N, stride, 4), dtype=torch.float32, device="cuda")
+    vr.render_batch(W, H, seeds, tout.data_ptr(), 16, 16, split.my_tiles, frame_stride=stride)
+    torch.cuda.synchronize()
+    tg = tout.cpu().numpy()
+    for f in (0, 37, 255):
+        tl = tg[f, :n * 256].reshape(n, 16, 16, 4)
+        for k, t in enumerate(split.my_tiles):
+            x0, y0, w, h = split.tile_rect(t)
+            np.testing.assert_array_equal(tl[k, :h, :w], got[f, y0:y0 + h, x0:x0 + w])
 
 
 def test_anisotropic_grid_samples_before_the_entry_face(monkeypatch):

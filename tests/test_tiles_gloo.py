@@ -208,3 +208,31 @@ def test_tile_split_is_a_partition():
         assert s0.cap == max(counts)
     with pytest.raises(ValueError):
         tiles.TileSplit(64, 64, 24, 16, 2, 0)
+
+
+def test_tiles_are_dealt_by_distance_and_the_cpp_host_deals_the_same():
+    """deal_tiles: every tile has one owner, the counts differ by at most one pair of deals, every rank gets
+    tiles near the centre and far from it, and the headless C++ host (vr_deal_tiles behind
+    vrhost_deal_tiles) produces the same assignment."""
+    import ctypes as C
+    import os
+    from volumerenderercl_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    _lib.load()
+    host = C.CDLL(os.path.join(root, "volumerenderercl_amd", "libvrhost.so"))
+    for W, H, T, n in ((1024, 1024, 64, 8), (2048, 2048, 64, 8), (1024, 1024, 32, 4), (200, 136, 32, 3),
+                       (200, 136, 16, 2), (640, 360, 48, 5), (64, 64, 64, 8), (1024, 1024, 64, 1)):
+        owner = tiles.deal_tiles(W, H, T, T, n)
+        tx, ty = (W + T - 1) // T, (H + T - 1) // T
+        assert owner.shape == (tx * ty,) and owner.min() >= 0 and owner.max() <= n - 1
+        counts = np.bincount(owner, minlength=n)
+        assert counts.max() - counts.min() <= 2
+        out = (C.c_uint32 * (tx * ty))()
+        assert host.vrhost_deal_tiles(W, H, T, n, out, tx * ty) == 0
+        np.testing.assert_array_equal(np.array(out[:], dtype=np.int64), owner)
+    # the headline split: the four central tiles and the four corner tiles go to different ranks each
+    owner = tiles.deal_tiles(1024, 1024, 64, 64, 8).reshape(16, 16)
+    assert len({owner[7, 7], owner[7, 8], owner[8, 7], owner[8, 8]}) == 4
+    ring = [(ty_, tx_) for ty_ in range(16) for tx_ in range(16) if 4 <= (2 * tx_ - 15) ** 2 + (2 * ty_ - 15) ** 2 <= 60]
+    per_rank = np.bincount([owner[p] for p in ring], minlength=8)
+    assert per_rank.min() >= 1 and per_rank.max() - per_rank.min() <= 2

@@ -13,6 +13,8 @@ V = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 ranks = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0]
 out_json = sys.argv[4] if len(sys.argv) > 4 else None
 results = []
+T = int(os.environ.get("TILE", "64"))
+only = os.environ.get("ONLY")   # e.g. "2x128": one schedule only
 dev = torch.device("cuda", 0)
 vr = VolumeRenderCL(); vr.initialize()
 vr.synthVolume("shells", (2048,) * 3, 0)
@@ -20,16 +22,21 @@ vr.setTransferFunction(frontend.tff_from_stops())
 vr.updateView(frontend.view_matrix(frontend.quat_from_axis_angle((1, 1, 0), 30.0)))
 vr.setRoundBudget(48)
 mt = frontend.Mt19937()
-seeds = [mt() for _ in range(4096)]
+seeds = [mt() for _ in range(16384)]
 twins = [vr] + [vr.shareVolumes() for _ in range(3)]
 streams = [torch.cuda.Stream(dev) for _ in twins]
 for r, s in zip(twins, streams):
     r.set_stream(s.cuda_stream)
 for w, rk in [(1, 0)] + [(world, r_) for r_ in ranks]:
-    split = tiles.TileSplit(V, V, 64, 64, w, rk)
+    split = tiles.TileSplit(V, V, T, T, w, rk)
     ids = None if w == 1 else split.my_tiles
-    npix = V * V if w == 1 else len(ids) * 64 * 64
-    for fif, fpl in ((1, 1), (2, 8), (2, 16), (2, 32), (3, 16), (4, 8), (1, 32), (4, 16)):
+    npix = V * V if w == 1 else len(ids) * T * T
+    cfgs = [(1, 1), (2, 8), (2, 16), (2, 32), (3, 16), (4, 8), (1, 32), (4, 16)]
+    if w > 1:
+        cfgs += [(2, 64), (2, 128), (1, 256), (2, 256)]
+    if only:
+        cfgs = [tuple(int(x) for x in only.split("x"))]
+    for fif, fpl in cfgs:
         outs = [torch.empty((fpl, npix, 4), dtype=torch.float32, device=dev) for _ in range(fif)]
         def run(nsets):
             k = 0
@@ -39,9 +46,9 @@ for w, rk in [(1, 0)] + [(world, r_) for r_ in ranks]:
                 if ids is None:
                     twins[j].render_batch(V, V, sd, outs[j].data_ptr())
                 else:
-                    twins[j].render_batch(V, V, sd, outs[j].data_ptr(), 64, 64, ids, frame_stride=npix)
+                    twins[j].render_batch(V, V, sd, outs[j].data_ptr(), T, T, ids, frame_stride=npix)
         run(fif); torch.cuda.synchronize()
-        nsets = max(fif * 2, 256 // fpl)
+        nsets = max(fif * 2, 512 // fpl)
         t0 = time.perf_counter(); run(nsets); torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) * 1e3 / (nsets * fpl)
         print("world %d rank %d share (%d px)  %d renderer(s) x %2d frames/set: %.4f ms/frame" % (w, rk, npix, fif, fpl, ms), flush=True)
@@ -49,5 +56,5 @@ for w, rk in [(1, 0)] + [(world, r_) for r_ in ranks]:
 if out_json:
     import json, subprocess
     head = subprocess.run(["git", "rev-parse", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
-    json.dump({"tool": "tools/share_time.py", "workload": "shells2048", "viewport": V, "world": world, "round_budget": 48,
+    json.dump({"tool": "tools/share_time.py", "workload": "shells2048", "viewport": V, "world": world, "tile": T, "round_budget": 48,
                "head": head, "results": results}, open(out_json, "w"), indent=1)

@@ -1,7 +1,9 @@
 // tilegather.cpp -- see tilegather.h.
 #include "tilegather.h"
 
+#include <algorithm>
 #include <chrono>
+#include <utility>
 #include <stdexcept>
 
 #include <hip/hip_runtime_api.h>
@@ -33,8 +35,8 @@ TileGather::TileGather(const std::vector<VolumeRenderCL *> &ranks, const std::ve
     _tiles_x = (_W + tile - 1) / tile;
     _tiles_y = (_H + tile - 1) / tile;
     _tiles.resize(n);
-    for (size_t t = 0; t < _tiles_x * _tiles_y; ++t)   // diagonal interleave: neighbours go to different ranks
-        _tiles[((t % _tiles_x) + (t / _tiles_x)) % n].push_back(static_cast<unsigned int>(t));
+    const std::vector<unsigned int> owner = vr_deal_tiles(_W, _H, tile, n);
+    for (size_t t = 0; t < owner.size(); ++t) _tiles[owner[t]].push_back(static_cast<unsigned int>(t));   // ids ascending
     _cap = 0;
     for (const auto &v : _tiles) _cap = std::max(_cap, v.size());
     const size_t slot_floats = tile * tile * 4, block = _cap * slot_floats;

@@ -1,6 +1,7 @@
 // tilegather.h -- image-tile decomposition of one frame over the GPUs of a node for the headless
 // C++ host (the reference is single-GPU, volumerendercl.cpp:140).  One process, one
-// renderer per GPU (volume replicated), tiles dealt to the ranks in a diagonal interleave; every rank
+// renderer per GPU (volume replicated), tiles dealt to the ranks by their distance from the frame's centre
+// (every rank gets tiles of every distance: load balance); every rank
 // renders its tiles into a compact device buffer and rank 0 receives them over RCCL point to point
 // (ncclGroupStart; ncclRecv from every peer on the root | ncclSend on the peers; ncclGroupEnd -- xGMI
 // is point to point, so the root's links carry one peer each) and assembles the frame with one kernel.
@@ -10,6 +11,12 @@
 #include <vector>
 
 class VolumeRenderCL;
+
+// owner[t] of the tiles of a width x height frame (numbered row-major) over n ranks: tiles sorted by the
+// distance of their centre from the frame's centre (integers, ties by id) and dealt like cards, back and
+// forth (0 1 .. n-1 n-1 .. 1 0 0 1 ..), so that every rank gets tiles of every distance (load balance:
+// a tile's cost follows the object in the middle of the view).  Same rule as tiles.py deal_tiles.
+std::vector<unsigned int> vr_deal_tiles(size_t width, size_t height, size_t tile, size_t n);
 
 class TileGather
 {

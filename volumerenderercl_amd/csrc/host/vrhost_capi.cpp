@@ -93,3 +93,38 @@ int vrdr_histogram(vrdr *h, uint64_t t, double out[256])
     return 0;
 }
 }
+
+// ---- tile dealing of the multi-GPU driver (tilegather.h), exported for the CPU test against tiles.py
+#include <algorithm>
+#include <utility>
+#include <vector>
+
+#include "tilegather.h"
+
+std::vector<unsigned int> vr_deal_tiles(size_t width, size_t height, size_t tile, size_t n)
+{
+    const size_t tiles_x = (width + tile - 1) / tile, tiles_y = (height + tile - 1) / tile, nt = tiles_x * tiles_y;
+    std::vector<std::pair<long long, unsigned int>> order(nt);
+    for (size_t t = 0; t < nt; ++t) {
+        const long long dx = (2 * static_cast<long long>(t % tiles_x) + 1) * static_cast<long long>(tile) - static_cast<long long>(width);
+        const long long dy = (2 * static_cast<long long>(t / tiles_x) + 1) * static_cast<long long>(tile) - static_cast<long long>(height);
+        order[t] = {dx * dx + dy * dy, static_cast<unsigned int>(t)};
+    }
+    std::sort(order.begin(), order.end());
+    std::vector<unsigned int> owner(nt);
+    for (size_t i = 0; i < nt; ++i) {
+        const size_t j = i % (2 * n);
+        owner[order[i].second] = static_cast<unsigned int>(j < n ? j : 2 * n - 1 - j);
+    }
+    return owner;
+}
+
+extern "C" int vrhost_deal_tiles(uint32_t width, uint32_t height, uint32_t tile, uint32_t ranks, uint32_t *owner_out,
+                                 uint32_t n_tiles)
+{
+    if (!owner_out || !tile || !ranks || !width || !height) return 1;
+    const std::vector<unsigned int> owner = vr_deal_tiles(width, height, tile, ranks);
+    if (owner.size() != n_tiles) return 1;
+    std::copy(owner.begin(), owner.end(), owner_out);
+    return 0;
+}

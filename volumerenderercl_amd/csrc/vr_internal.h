@@ -82,15 +82,27 @@ struct SkipView {
 
 // One 8x8-pixel patch (= one wave64) of the work queue.
 struct WaveTile {
-    uint16_t tx8, ty8;     // patch origin / 8 in the frame; ty8 bits 11..15: frame of the batch
+    uint16_t tx8, ty8;     // patch origin / 8 in the frame, bits 0..10; bits 11..15 of ty8 and of tx8: frame of the batch
     uint32_t out_base;     // index of its first pixel in FrameView::out
 };
 // Several independent frames (jitter seeds) in one set of launches: the work queue holds every
-// patch once per frame, the frame index rides in the upper bits of WaveTile::ty8 (patch rows need
-// 11 bits up to 16384 pixels) and of ContRec::state, FrameView::seeds gives each frame its seed.
-constexpr uint32_t kFrameShift = 11, kMaxBatchFrames = 32;
-__host__ __device__ inline uint32_t wt_row(const WaveTile &w) { return w.ty8 & ((1u << kFrameShift) - 1u); }
-__host__ __device__ inline uint32_t wt_frame(const WaveTile &w) { return w.ty8 >> kFrameShift; }
+// patch once per frame, the frame index rides in the upper bits of WaveTile::ty8 (low five bits) and
+// WaveTile::tx8 (high five bits) -- patch rows and columns need 11 bits up to 16384 pixels -- and of
+// ContRec::state, FrameView::seeds gives each frame its seed.  32 whole frames fill a GPU; a rank's tile
+// share of an 8-rank split needs 256 frames per set for the same work per launch.
+constexpr uint32_t kFrameShift = 11, kMaxBatchFrames = 256;
+constexpr uint32_t kPatchMask = (1u << kFrameShift) - 1u, kFrameLowBits = 16u - kFrameShift;
+__host__ __device__ inline uint32_t wt_row(const WaveTile &w) { return w.ty8 & kPatchMask; }
+__host__ __device__ inline uint32_t wt_col(const WaveTile &w) { return w.tx8 & kPatchMask; }
+__host__ __device__ inline uint32_t wt_frame(const WaveTile &w)
+{
+    return (uint32_t)(w.ty8 >> kFrameShift) | ((uint32_t)(w.tx8 >> kFrameShift) << kFrameLowBits);
+}
+__host__ __device__ inline void wt_set_frame(WaveTile &w, uint32_t f)
+{
+    w.ty8 = (uint16_t)((w.ty8 & kPatchMask) | ((f & ((1u << kFrameLowBits) - 1u)) << kFrameShift));
+    w.tx8 = (uint16_t)((w.tx8 & kPatchMask) | ((f >> kFrameLowBits) << kFrameShift));
+}
 
 // A patch with at least one ray that reaches a non-skipped brick (DDA pre-pass), and which rays.
 struct LiveTile {

@@ -149,8 +149,8 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
                 if (state == P_FETCH && rank < n_take) {
                     const uint32_t pi = patch_taken + rank;
                     const uint32_t lx = pi & 7u, ly = pi >> 3;
-                    px.gx = (uint32_t)wt.tx8 * 8u + lx;
-                    px.gy = (uint32_t)wt.ty8 * 8u + ly;
+                    px.gx = wt_col(wt) * 8u + lx;
+                    px.gy = wt_row(wt) * 8u + ly;
                     px.out_index = wt.out_base + ly * fr.out_stride + lx;
                     // pixels outside the frame (ragged right / bottom patches) are dropped
                     if (px.gx < fr.W && px.gy < fr.H) {

@@ -800,10 +800,10 @@ VR_DEV bool image_ess_patch(const FrameView &fr, const vrhip_rendering_params &r
                             const WaveTile &wt, uint32_t lane, bool inside, uint32_t gx, uint32_t gy,
                             size_t out_index)
 {
-    const bool unhit = group_unhit(fr, wt.tx8, wt_row(wt), lane);
+    const bool unhit = group_unhit(fr, wt_col(wt), wt_row(wt), lane);
     const unsigned long long valid = __ballot(c.valid);
     if (lane == 0)
-        fr.hit_status[(size_t)wt_row(wt) * fr.hit_w + wt.tx8] =
+        fr.hit_status[(size_t)wt_row(wt) * fr.hit_w + wt_col(wt)] =
             (uint8_t)(unhit ? HIT_SKIPPED : ((valid & 1ull) ? HIT_FIRST_ENDS : HIT_FIRST_MISSES));
     if (unhit && inside) {
         float4 o = make_float4(c.env0, c.env1, c.env2, c.env3);
@@ -990,7 +990,7 @@ __global__ __launch_bounds__(kBlockDim) void vr_dda_prepass_kernel(
     if (q >= fr.n_wave_tiles) return;
     const WaveTile wt = fr.queue[q];
     const uint32_t lx = lane & 7u, ly = lane >> 3;
-    const uint32_t gx = (uint32_t)wt.tx8 * 8u + lx, gy = wt_row(wt) * 8u + ly;
+    const uint32_t gx = wt_col(wt) * 8u + lx, gy = wt_row(wt) * 8u + ly;
     const uint32_t seed = fr.seeds ? fr.seeds[wt_frame(wt)] : rp.seed;
     const bool inside = gx < fr.W && gy < fr.H;
     const f3 resf = mk3(vv.fw, vv.fh, vv.fd);
@@ -1703,7 +1703,7 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_kernel(
         VR_STAMP(0);
         VR_COUNT(11);
         const uint32_t lx = lane & 7u, ly = lane >> 3;
-        const uint32_t gx = (uint32_t)wt.tx8 * 8u + lx, gy = wt_row(wt) * 8u + ly;
+        const uint32_t gx = wt_col(wt) * 8u + lx, gy = wt_row(wt) * 8u + ly;
         const uint32_t frame_idx = wt_frame(wt);
         const uint32_t seed = fr.seeds ? fr.seeds[frame_idx] : rp.seed;
         const bool inside = gx < fr.W && gy < fr.H;
@@ -1868,7 +1868,7 @@ __global__ __launch_bounds__(kBlockDim) void vr_raycast_staged_kernel(
         const WaveTile wt = fr.queue[q];
         if (lane == 0) q_next = atomicAdd(fr.queue_head, 1u);
         const uint32_t lx = lane & 7u, ly = lane >> 3;
-        const uint32_t gx = (uint32_t)wt.tx8 * 8u + lx, gy = wt_row(wt) * 8u + ly;
+        const uint32_t gx = wt_col(wt) * 8u + lx, gy = wt_row(wt) * 8u + ly;
         const uint32_t seed = fr.seeds ? fr.seeds[wt_frame(wt)] : rp.seed;
         const bool inside = gx < fr.W && gy < fr.H;
         RayCtx c;
@@ -2342,7 +2342,7 @@ __global__ __launch_bounds__(kBlockDim) void vr_hit_resolve_kernel(FrameView fr,
     const uint32_t i = blockIdx.x * kBlockDim + threadIdx.x;
     if (i >= fr.n_wave_tiles) return;
     const WaveTile wt = fr.queue[i];
-    const size_t g = (size_t)wt_row(wt) * fr.hit_w + wt.tx8;
+    const size_t g = (size_t)wt_row(wt) * fr.hit_w + wt_col(wt);
     hit_out[g] = fr.hit_status[g] == HIT_FIRST_ENDS ? fr.hit_any[g] : (uint8_t)0;
 }
 

@@ -762,14 +762,14 @@ int ensure_queue(vrhip_renderer *r, uint32_t W, uint32_t H, uint32_t tile_w, uin
     }
     std::stable_sort(items.begin(), items.end(),
                      [](const Item &a, const Item &b) { return a.d2 < b.d2; });
-    // a batch of frames: every patch once per frame (frame index in the upper bits of ty8), the
+    // a batch of frames: every patch once per frame (frame index in the upper bits of ty8 / tx8), the
     // frames' outputs one after the other
     const uint32_t frame_pixels = frame_stride ? frame_stride : (tile_ids ? n_tiles * tile_w * tile_h : W * H);
     std::vector<WaveTile> q(items.size() * n_frames);
     for (size_t i = 0; i < items.size(); ++i)
         for (uint32_t f = 0; f < n_frames; ++f) {
             WaveTile wt = items[i].wt;
-            wt.ty8 = (uint16_t)(wt.ty8 | (f << kFrameShift));
+            wt_set_frame(wt, f);
             wt.out_base += f * frame_pixels;
             q[i * n_frames + f] = wt;
         }
@@ -1625,8 +1625,9 @@ int vrhip_render_batch(vrhip_renderer *r, uint32_t width, uint32_t height, uint3
     if (set_device(r)) return VRHIP_ERR_HIP;
     VR_REQUIRE(r, out_dev && seeds, VRHIP_ERR_INVALID, "vrhip_render_batch: NULL argument");
     VR_REQUIRE(r, n_frames >= 1 && n_frames <= kMaxBatchFrames, VRHIP_ERR_INVALID,
-               "vrhip_render_batch: 1..32 frames per batch");
-    VR_REQUIRE(r, height <= (8u << kFrameShift), VRHIP_ERR_INVALID, "Invalid output image size.");
+               "vrhip_render_batch: 1..256 frames per batch");
+    VR_REQUIRE(r, height <= (8u << kFrameShift) && width <= (8u << kFrameShift), VRHIP_ERR_INVALID,
+               "Invalid output image size.");
     VR_REQUIRE(r, !tile_ids || n_tiles > 0, VRHIP_ERR_INVALID, "vrhip_render_batch: empty tile list");
     // the frames of a batch are independent: nothing that chains frames, nothing that draws from
     // rendering_params.seed outside the ray set-up
@@ -1637,6 +1638,8 @@ int vrhip_render_batch(vrhip_renderer *r, uint32_t width, uint32_t height, uint3
     const uint32_t packed = tile_ids ? n_tiles * tile_w * tile_h : width * height;
     VR_REQUIRE(r, out_frame_stride == 0 || out_frame_stride >= packed, VRHIP_ERR_INVALID,
                "vrhip_render_batch: frame stride smaller than a frame");
+    VR_REQUIRE(r, (unsigned long long)n_frames * (out_frame_stride ? out_frame_stride : packed) <= 0xffffffffull,
+               VRHIP_ERR_INVALID, "vrhip_render_batch: the frames of a batch must hold fewer than 2^32 pixels together");
     int rc = prepare_render(r, width, height, tile_w, tile_h, tile_ids, n_tiles, n_frames,
                             out_frame_stride);
     if (rc) return rc;

@@ -253,7 +253,7 @@ class VolumeRenderCL:
 
     def render_batch(self, width, height, seeds, out_dev_ptr, tile_w=0, tile_h=0, tile_ids=None,
                      frame_stride=0):
-        """len(seeds) <= 32 independent frames (frame f jittered by seeds[f]) in one set of
+        """len(seeds) <= 256 independent frames (frame f jittered by seeds[f]) in one set of
         launches (vrhip_render_batch): whole frames into out[f][height][width][4], or -- with
         tile_ids -- the tile subset into out[f][n_tiles][tile_h][tile_w][4] (device memory);
         frame_stride: pixels between the frames of `out` when they are not packed."""

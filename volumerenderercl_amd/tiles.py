@@ -1,8 +1,8 @@
 """Image-tile decomposition of one frame over the GPUs of a node.
 
 The reference is single-GPU; this layer is new.  Pixels are independent, so the frame is
-cut into tile_w x tile_h tiles dealt to ranks in a diagonal interleave (load balance under
-ESS/ERT: neighbouring tiles -- similar cost -- go to different ranks), every rank holds the
+cut into tile_w x tile_h tiles dealt to the ranks by their distance from the frame's centre
+(deal_tiles: load balance under ESS/ERT -- every rank gets tiles of every distance), every rank holds the
 whole volume, renders its tiles into a compact buffer and rank 0 gathers them over
 RCCL/xGMI (torch.distributed `gather`, backend "nccl" == RCCL; "gloo" in the CPU tests).
 One collective per frame, 16*W*H/N bytes per peer.
@@ -15,6 +15,25 @@ each frame with one small all-reduce ((W/8+1)*(H/8+1) bytes) before the next fra
 import numpy as np
 
 
+def deal_tiles(W, H, tw, th, world):
+    """owner[t] for the tiles of a W x H frame, numbered row-major: the tiles are sorted by the distance
+    of their centre from the frame's centre (integer arithmetic, ties by tile id) and dealt to the ranks
+    like cards, back and forth (0 1 .. n-1 n-1 .. 1 0 0 1 ..): every rank gets tiles of every distance.
+    What a tile costs follows the object in the middle of the view; a diagonal interleave ((tx + ty) mod
+    n) hands whole anti-diagonals to one rank -- at 16 x 16 tiles for 8 ranks the one through the centre:
+    measured shares of 0.012 .. 0.034 ms per frame on the headline, 0.72 of the possible speed-up; dealt
+    by distance 0.96.  The same rule lives in csrc/host/tilegather.cpp."""
+    tiles_x, tiles_y = (W + tw - 1) // tw, (H + th - 1) // th
+    ids = np.arange(tiles_x * tiles_y, dtype=np.int64)
+    dx = (2 * (ids % tiles_x) + 1) * tw - W
+    dy = (2 * (ids // tiles_x) + 1) * th - H
+    order = np.lexsort((ids, dx * dx + dy * dy))          # by distance, then by id
+    j = np.arange(ids.size) % (2 * world)
+    owner = np.empty(ids.size, dtype=np.int64)
+    owner[order] = np.where(j < world, j, 2 * world - 1 - j)
+    return owner
+
+
 class TileSplit:
     def __init__(self, width, height, tile_w, tile_h, world, rank):
         if tile_w % 16 or tile_h % 16:
@@ -25,7 +44,7 @@ class TileSplit:
         self.tiles_y = (self.H + self.th - 1) // self.th
         self.n_tiles = self.tiles_x * self.tiles_y
         ids = np.arange(self.n_tiles, dtype=np.uint32)
-        self.owner = ((ids % self.tiles_x) + (ids // self.tiles_x)) % self.world
+        self.owner = deal_tiles(self.W, self.H, self.tw, self.th, self.world)
         self.tiles_of = [ids[self.owner == r] for r in range(self.world)]
         self.cap = max(len(t) for t in self.tiles_of)     # slots per rank (equal-size gather)
         self.my_tiles = self.tiles_of[self.rank]
