@@ -459,6 +459,141 @@ VR_DEV void eval_batch(const V &vol, const float4 *s_tff, int tffn, float *s_sta
     }
 }
 
+// ---- eval_batch for the default kernels (no instrumentation, no XS extras), cut in three so that the dense
+// pass over the gathered samples is run by ALL 64 lanes of the wave, not only by the lanes whose rays
+// evaluate a batch this round.  A batch runs with ~30 of 64 lanes and gathers ~38 samples with a non-zero
+// opacity on the headline: inside the divergent call that was two passes of the gradient / shading code
+// more often than not; the wave's idle and empty-run-skipping lanes take the second half now.  The same
+// operations per sample, in another lane (as before).
+struct EvalFront {
+    float4 tfc[kBatch];
+    bool lit[kBatch], need[kBatch];
+    uint32_t slot[kBatch];
+};
+
+// divergent part 1: density, transfer function, slots of the samples with an opacity, staged to LDS.
+// Returns the number of slots (the same in every lane that calls).
+template <typename VT, bool FP, typename V>
+VR_DEV uint32_t eval_front(const V &vol, const float4 *s_tff, int tffn, float *s_stage, const RayCtx &c,
+                           const vrhip_rendering_params &rp, const float (&tk)[kBatch], const bool (&vk)[kBatch],
+                           bool ev, EvalFront &ef)
+{
+    // Called by the whole wave: a VALU instruction costs the same with 30 lanes as with 64, and straight
+    // code spares the exec-mask bookkeeping of a divergent region around the batch.  Lanes whose ray does
+    // not evaluate this round (ev false: every vk false) only skip the voxel loads.
+    f3 pk[kBatch];
+    float dens[kBatch];
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+        f3 pos = add3(c.cam, scale3(c.dir, tk[k] - c.offset));
+        pk[k] = mk3(pos.x * 0.5f + 0.5f, pos.y * 0.5f + 0.5f, pos.z * 0.5f + 0.5f);
+        dens[k] = 0.f;
+    }
+    if (ev) {
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) dens[k] = vol.linear(pk[k].x, pk[k].y, pk[k].z);
+    }
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) ef.tfc[k] = tff_linear(s_tff, tffn, dens[k]);
+    const bool shade_mode = rp.illumType == 1;   // :809
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t n_slots = 0;
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+        ef.lit[k] = vk[k] && ef.tfc[k].w > 0.1f;   // :809/:832
+        // opacity 0 gives op = 1 - powr(1, y) = 0 exactly: nothing of the sample survives
+        ef.need[k] = vk[k] && ef.tfc[k].w != 0.f;
+        const unsigned long long m = __ballot(ef.need[k]);
+        ef.slot[k] = n_slots + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        n_slots += (uint32_t)__builtin_popcountll(m);
+    }
+    if (n_slots) {
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+            if (ef.need[k]) {
+                float *q = s_stage + kSlotFloats * ef.slot[k];
+                q[0] = pk[k].x; q[1] = pk[k].y; q[2] = pk[k].z;
+                q[3] = ef.tfc[k].w;
+                q[4] = __uint_as_float(lane | ((ef.lit[k] && shade_mode) ? 64u : 0u));
+            }
+        }
+    }
+    return n_slots;
+}
+
+// wave-uniform part: every lane of the wave takes slots (n_slots > 0, the same in all 64 lanes)
+template <typename VT, bool FP, typename V>
+VR_DEV void eval_dense(const V &vol, float *s_stage, const RayCtx &c, float refInterval, uint32_t n_slots)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t base = 0; base < n_slots; base += 64u) {
+        const uint32_t sidx = base + lane;
+        const bool mine = sidx < n_slots;
+        float *q = s_stage + kSlotFloats * (mine ? sidx : 0u);
+        const float qx = q[0], qy = q[1], qz = q[2], qw = q[3];
+        const uint32_t tag = mine ? __float_as_uint(q[4]) : lane;
+        const int owner = (int)(tag & 63u);
+        const bool shade = mine && (tag & 64u);
+        // the owner's per-ray constants (every lane takes part in the exchange)
+        const f3 lgt = mk3(__shfl(c.lgt.x, owner, 64), __shfl(c.lgt.y, owner, 64), __shfl(c.lgt.z, owner, 64));
+        const f3 hv = mk3(__shfl(c.hv.x, owner, 64), __shfl(c.hv.y, owner, 64), __shfl(c.hv.z, owner, 64));
+        const int hvalid = __shfl(c.hvalid ? 1 : 0, owner, 64);
+        float o_ndl = 0.f, o_sp = 0.f, o_op = 0.f;
+        if (__ballot(shade)) {
+            if (shade) {
+                const f3 g = vol.neg_gradient(qx, qy, qz);
+                // illumination (:294-303) with specularBlinnPhong (:280-291)
+                o_ndl = vmax(0.f, dot3(g, lgt));
+                o_sp = hvalid ? vr_powr(vmax(dot3(g, hv), 0.f), 40.f) : 0.0f;
+                o_sp = o_sp * 0.15f;
+            }
+        }
+        if (mine) {
+            o_op = 1.f - vr_powr(1.f - qw, refInterval);  // opacity correction (:864)
+            q[0] = o_ndl; q[1] = o_sp; q[2] = 0.f; q[3] = o_op;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// divergent part 2: the samples' scalars back from their slots, shading combined, colour x opacity
+VR_DEV void eval_back(const float *s_stage, const RayCtx &c, const vrhip_rendering_params &rp, EvalFront &ef,
+                      uint32_t n_slots, float (&p0)[kBatch], float (&p1)[kBatch], float (&p2)[kBatch],
+                      float (&op)[kBatch])
+{
+    const bool shade_mode = rp.illumType == 1;
+    float ndl[kBatch], spc[kBatch];
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) { ndl[k] = 0.f; spc[k] = 0.f; op[k] = 0.f; }
+    if (n_slots) {
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+            if (ef.need[k]) {
+                const float *q = s_stage + kSlotFloats * ef.slot[k];
+                ndl[k] = q[0]; spc[k] = q[1]; op[k] = q[3];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+        float4 t = ef.tfc[k];
+        if (ef.lit[k] && shade_mode) {
+            t.x = ((t.x * 0.15f) + ((t.x * ndl[k]) * 0.7f)) + spc[k];
+            t.y = ((t.y * 0.15f) + ((t.y * ndl[k]) * 0.7f)) + spc[k];
+            t.z = ((t.z * 0.15f) + ((t.z * ndl[k]) * 0.7f)) + spc[k];
+        }
+        t.x = c.env0 - t.x;
+        t.y = c.env1 - t.y;
+        t.z = c.env2 - t.z;
+        p0[k] = t.x * op[k];
+        p1[k] = t.y * op[k];
+        p2[k] = t.z * op[k];
+    }
+}
+
 #ifndef VR_LOOK1
 #define VR_LOOK1 24
 #endif
@@ -1241,6 +1376,7 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
             VR_MS(6, 1);                                                       // evaluation batches
             VR_MS(7, __builtin_popcountll(__ballot(d.state == S_SAMPLE && !more_empty)));   // lanes in them
         }
+#ifdef VR_EVAL_INLINE   // A/B build: the dense pass inside the divergent call (round 2)
         if (d.state == S_SAMPLE && !more_empty) {
             float tk[kBatch];
             bool vk[kBatch], litk[kBatch];
@@ -1265,6 +1401,39 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
             if (cool) --cool;
             after_segment<true>(c, d);
         }
+#else
+        // the evaluation batch as wave-uniform code in three parts (eval_front / eval_dense / eval_back): every
+        // lane of the wave works in the dense pass, whether its own ray evaluates this round or not
+        const bool ev = d.state == S_SAMPLE && !more_empty;
+        if (__ballot(ev)) {
+            float tk[kBatch];
+            bool vk[kBatch];
+            tk[0] = d.t;
+            vk[0] = ev && d.t < d.t_exit;   // inner loop condition (:790)
+#pragma unroll
+            for (int k = 1; k < kBatch; ++k) {
+                tk[k] = tk[k - 1] + c.stepSize;                                     // :879
+                vk[k] = vk[k - 1] && !(tk[k - 1] >= c.tfar) && (tk[k] < d.t_exit);  // :868, :790
+            }
+#ifdef VR_MARCH_STATS
+            for (int k = 0; k < kBatch; ++k) ms_acc[9] += vk[k] ? 1 : 0;      // valid samples evaluated (per lane: summed below)
+#endif
+            EvalFront ef;
+            const uint32_t ns = eval_front<VT, FP>(vol, s_tff, tffn, s_stage, c, rp, tk, vk, ev, ef);
+            if (ns) eval_dense<VT, FP>(vol, s_stage, c, refInterval, ns);
+            VR_MARK("R_comp");
+            float p0[kBatch], p1[kBatch], p2[kBatch], opk[kBatch];
+            eval_back(s_stage, c, rp, ef, ns, p0, p1, p2, opk);
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k)
+                if (vk[k] && d.state == S_SAMPLE) composite(c, d, p0[k], p1[k], p2[k], opk[k], tk[k]);
+            if (ev) {
+                if (vk[kBatch - 1]) guess_empty = opk[kBatch - 1] == 0.f && cool == 0u;
+                if (cool) --cool;
+                after_segment<true>(c, d);
+            }
+        }
+#endif
     }
 #ifdef VR_MARCH_STATS
     if (lane == 0)
@@ -2197,6 +2366,48 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
                 }
             }
             VR_STAMP(4);
+            const bool ev2 = d.state == S_SAMPLE && !more_empty;   // (the same in the four lanes of a ray)
+            if (INSTR == 0 && !XS) {
+                // default kernels: the batch as wave-uniform code (phase 1's eval_front / eval_dense /
+                // eval_back): the dense pass over the gathered samples is run by all 64 lanes, also those
+                // of rays that step over empty runs or have ended
+                if (__ballot(ev2)) {
+                    float tk[kBatch] = {0.f, 0.f, 0.f, 0.f};
+                    bool vk[kBatch] = {false, false, false, false};
+                    float tc = d.t;
+                    bool v = ev2 && d.t < d.t_exit;
+#pragma unroll
+                    for (int i = 0; i < kSplit * kBatch; ++i) {
+                        if ((int)slot == i / kBatch) { tk[i % kBatch] = tc; vk[i % kBatch] = v; }
+                        const float tn = tc + c.stepSize;
+                        v = v && !(tc >= c.tfar) && (tn < d.t_exit);
+                        tc = tn;
+                    }
+                    EvalFront ef;
+                    const uint32_t ns = eval_front<VT, FP>(vol, s_tff, tffn, s_stage, c, rp, tk, vk, ev2, ef);
+                    if (ns) eval_dense<VT, FP>(vol, s_stage, c, refInterval, ns);
+                    float p0[kBatch], p1[kBatch], p2[kBatch], opk[kBatch];
+                    eval_back(s_stage, c, rp, ef, ns, p0, p1, p2, opk);
+                    VR_STAMP(3);
+                    int fl[kBatch];
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k) fl[k] = (vk[k] ? 1 : 0) | ((ef.lit[k] && rp.illumType == 1) ? 2 : 0);
+                    composite_from<0>(c, d, p0, p1, p2, opk, tk, fl, false, c_taken, c_shaded);
+                    composite_from<1>(c, d, p0, p1, p2, opk, tk, fl, false, c_taken, c_shaded);
+                    composite_from<2>(c, d, p0, p1, p2, opk, tk, fl, false, c_taken, c_shaded);
+                    composite_from<3>(c, d, p0, p1, p2, opk, tk, fl, false, c_taken, c_shaded);
+                    {   // the ray's 16th sample of this round: lane 3 of the quad, slot kBatch - 1
+                        const int f3v = quad_bcast<3>(fl[kBatch - 1]);
+                        const float o3 = quad_bcast<3>(opk[kBatch - 1]);
+                        if (ev2) {
+                            if (f3v & 1) guess_empty = o3 == 0.f && cool == 0u;
+                            if (cool) --cool;
+                            after_segment<ESS>(c, d);
+                        }
+                    }
+                    VR_STAMP(6);
+                }
+            } else
             if (d.state == S_SAMPLE && !more_empty) {
                 // parameters (t += stepSize, :879) and validity (:790, :868) of the ray's next 16
                 // samples; this lane keeps numbers 4*slot .. 4*slot+3
