@@ -251,6 +251,10 @@ double vrhip_last_kernel_seconds(const vrhip_renderer *r);
 /* The ray-cast pass is two back-to-back launches (budgeted march of every ray, then the
  * suspended long rays with 4 lanes per ray): HIP-event seconds of each. */
 int vrhip_last_phase_seconds(const vrhip_renderer *r, double *phase1, double *phase2);
+/* The event between the two phases costs a few microseconds of GPU time per frame (a barrier packet
+ * between two launches): it is recorded only while this is enabled (default off; then
+ * vrhip_last_phase_seconds answers VRHIP_ERR_NODATA). */
+int vrhip_set_phase_timing(vrhip_renderer *r, int enabled);
 
 /* ---- measurement helpers ------------------------------------------- */
 /* When enabled, render calls run the instrumented kernel variant that accumulates

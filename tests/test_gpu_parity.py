@@ -1955,3 +1955,63 @@ def test_bench_multi_gpu_path_rehearsed_over_rccl_on_one_gpu(tmp_path):
         assert d["n_gpus"] == 1 and "RCCL gather per 5 frames" in d["config"]["parallelism"]
         assert d["parity"]["max_abs_diff"] <= TOL and d["parity"]["counters_equal"]
         assert d["value"] > 0 and d["work_per_frame"]["samples_taken"] > 0
+
+
+def test_control_blocks_alternate_cleanly(vr):
+    """The work-queue control words live in two blocks; the first kernel of a set of launches zeroes the
+    block of the next set (no memset launch per frame).  Whatever is interleaved -- instrumented frames,
+    the traffic pass (which uses a block on its own), tiles, batches, the path tracer, phase timing --
+    every frame must equal the one a fresh renderer produces."""
+    import torch
+    vol = common.noise_volume((48, 40, 44), UCHAR, seed=41, smooth=False)
+    tff = common.tffs()["default"]
+    W, H = 96, 72
+    _setup(vr, vol, UCHAR, tff, common.views()["rot30"])
+    vr.setStatsEnabled(False)
+    fresh = VolumeRenderCL()
+    fresh.initialize()
+    try:
+        _setup(fresh, vol, UCHAR, tff, common.views()["rot30"])
+
+        def ref(seed, technique=0):
+            fresh.setTechnique(technique)
+            fresh.setSeed(seed)
+            fresh.setIteration(0)
+            return fresh.runRaycastNoGL(W, H)
+
+        def got(seed, technique=0):
+            vr.setTechnique(technique)
+            vr.setSeed(seed)
+            vr.setIteration(0)
+            return vr.runRaycastNoGL(W, H)
+
+        seeds = [SEED, 581869302, 3890346734, 3586334585, 545404204, 4161255391]
+        want = {s_: ref(s_) for s_ in seeds}
+        want_pt = ref(seeds[0], 1)
+        np.testing.assert_array_equal(got(seeds[0]), want[seeds[0]])
+        np.testing.assert_array_equal(got(seeds[1]), want[seeds[1]])
+        vr.setIteration(0)
+        vr.countTouched(W, H)                                   # a pass of its own on the current block
+        np.testing.assert_array_equal(got(seeds[2]), want[seeds[2]])
+        vr.setStatsEnabled(True)
+        np.testing.assert_array_equal(got(seeds[3]), want[seeds[3]])
+        vr.setStatsEnabled(False)
+        np.testing.assert_array_equal(got(seeds[0], 1), want_pt)   # path tracer: another first kernel
+        vr.setPhaseTiming(True)
+        np.testing.assert_array_equal(got(seeds[4]), want[seeds[4]])
+        p1, p2 = vr.getLastPhaseTimes()
+        assert p1 > 0 and p2 >= 0 and abs((p1 + p2) - vr.getLastExecTime()) < 0.2 * vr.getLastExecTime() + 2e-5
+        vr.setPhaseTiming(False)
+        np.testing.assert_array_equal(got(seeds[5]), want[seeds[5]])
+        assert vr.getLastPhaseTimes() == (0.0, 0.0)
+        out = torch.zeros((3, H, W, 4), dtype=torch.float32, device="cuda")
+        for _ in range(3):                                      # batches: odd number of sets in a row
+            vr.setTechnique(0)
+            vr.render_batch(W, H, seeds[:3], out.data_ptr())
+        torch.cuda.synchronize()
+        for f in range(3):
+            np.testing.assert_array_equal(out[f].cpu().numpy(), want[seeds[f]])
+        np.testing.assert_array_equal(got(seeds[1]), want[seeds[1]])
+    finally:
+        fresh.close()
+        vr.setTechnique(0)

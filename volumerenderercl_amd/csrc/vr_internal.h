@@ -132,6 +132,10 @@ struct FrameView {
     uint32_t n_wave_tiles;
     uint32_t out_stride;   // pixels per row of `out`
     uint32_t *queue_head;  // zeroed before each launch
+    // the control words (kControlWords from queue_head on) of the NEXT set of launches: the renderer
+    // alternates between two blocks, and the first kernel of a set zeroes the other block -- nothing else
+    // touches it until the next set starts -- instead of a memset launch per frame.  nullptr: nothing to zero
+    uint32_t *next_ctrl;
     float4 *fb;            // W*H frame / accumulate buffer (always written)
     float4 *out;           // optional second destination (device), frame or tile layout
     // Two-phase march: rays still alive after `round_budget` sample rounds of phase 1 (0 =
@@ -177,6 +181,12 @@ struct FrameView {
 };
 constexpr uint32_t kSortBins = 256;
 constexpr uint32_t kControlWords = 4 + 2 * kSortBins;   // queue head, cont count, cont head, pad, sort_ws
+// first kernel of a set of launches, first workgroup: the control words of the next set (FrameView::next_ctrl)
+#define VR_ZERO_NEXT_CTRL(fr)                                                                              \
+    do {                                                                                                   \
+        if (blockIdx.x == 0 && (fr).next_ctrl)                                                             \
+            for (uint32_t i_ = threadIdx.x; i_ < kControlWords; i_ += blockDim.x) (fr).next_ctrl[i_] = 0u; \
+    } while (0)
 
 // Cell grid: the volume cut into cells of 2^shift voxels per axis.  For every cell the renderer
 // keeps (min, max) of the voxels a trilinear fetch whose low-corner texel lies in the cell -- or

@@ -93,6 +93,7 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
     VolView vv, TfView tf, CellView grid, FrameView fr, vrhip_camera_params cam,
     vrhip_rendering_params rp, vrhip_pathtrace_params pt, DevStats *stats, uint32_t *touched)
 {
+    VR_ZERO_NEXT_CTRL(fr);
     extern __shared__ float4 s_mem[];
     float4 *s_tff = s_mem;
     for (uint32_t i = threadIdx.x; i < tf.tff_n; i += kBlockDim) s_tff[i] = tf.tff[i];

@@ -1120,6 +1120,7 @@ __global__ __launch_bounds__(kBlockDim) void vr_dda_prepass_kernel(
     // (grid, voxLen: make_grid's and 1 / resolution's values, computed once on the host with the same
     // IEEE operations -- a wave lives for one patch here, and the divisions and the square root were
     // 90 of its ~1250 instructions)
+    VR_ZERO_NEXT_CTRL(fr);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t q = blockIdx.x * (kBlockDim / 64) + (threadIdx.x >> 6);
     if (q >= fr.n_wave_tiles) return;
@@ -1822,6 +1823,7 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_kernel(
     vrhip_camera_params cam, vrhip_rendering_params rp, vrhip_raycast_params rc, DevStats *stats,
     uint32_t *touched)
 {
+    VR_ZERO_NEXT_CTRL(fr);   // (also when the pre-pass has done it: the block stays unused until the next set)
     // LDS: [gradient staging, 4 waves][tff_n float4][skip words + 1]
     extern __shared__ float4 s_mem[];
     VR_STAMP_DECL;
@@ -2008,6 +2010,7 @@ __global__ __launch_bounds__(kBlockDim) void vr_raycast_staged_kernel(
     vrhip_camera_params cam, vrhip_rendering_params rp, vrhip_raycast_params rc)
 {
     typedef uint8_t VT;
+    VR_ZERO_NEXT_CTRL(fr);
     extern __shared__ float4 s_mem[];
     // LDS: [gradient staging, 4 waves][tff_n float4][boxes, 4 waves]
     float *s_stage = reinterpret_cast<float *>(s_mem) + (threadIdx.x >> 6) * kStageFloatsPerWave;

@@ -98,7 +98,11 @@ struct vrhip_renderer {
     // work queue of 8x8 wave tiles (centre first) for the current frame/tile set
     WaveTile *queue_dev = nullptr;
     uint32_t queue_n = 0, queue_cap = 0;
-    uint32_t *queue_head = nullptr;   // kControlWords: queue head, cont count, cont head, pad, sort bins + cursors
+    uint32_t *queue_head = nullptr;   // 2 x kControlWords (queue head, cont count, cont head, pad, sort bins + cursors):
+                                      // the sets of launches alternate between the two blocks (FrameView::next_ctrl)
+    uint32_t ctrl_sel = 0;            // the block the next set of launches uses
+    bool ctrl_clean[2] = {false, false};   // that block is known to hold zeroes
+    bool phase_timing = false;        // vrhip_set_phase_timing: an event between the phases of a frame
     uint16_t *cost = nullptr;         // per pixel: phase-2 rounds of the previous frame (sort key)
     uint32_t *order = nullptr;        // sorted permutation of the suspended rays
     ContRec *live_rays = nullptr;     // pre-pass output: live rays with their DDA state (phase 1's list)
@@ -134,7 +138,7 @@ struct vrhip_renderer {
     uint32_t env_w = 0, env_h = 0;
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr, evb0 = nullptr, evb1 = nullptr;
-    bool timed = false, bricks_timed = false;
+    bool timed = false, bricks_timed = false, phase_timed = false;
 
     vrhip_renderer()
     {
@@ -839,10 +843,12 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
     a->frame.queue = r->queue_dev;
     a->frame.n_wave_tiles = r->queue_n;
     a->frame.out_stride = out_stride;
-    a->frame.queue_head = r->queue_head;
+    uint32_t *const ctrl = r->queue_head + (size_t)r->ctrl_sel * kControlWords;
+    a->frame.queue_head = ctrl;
+    a->frame.next_ctrl = r->queue_head + (size_t)(r->ctrl_sel ^ 1u) * kControlWords;
     a->frame.cont = r->cont;
-    a->frame.cont_count = r->queue_head + 1;
-    a->frame.cont_head = r->queue_head + 2;
+    a->frame.cont_count = ctrl + 1;
+    a->frame.cont_head = ctrl + 2;
     a->frame.round_budget = r->cont ? r->round_budget : 0;
     a->frame.refill_min = r->refill_min;
     a->frame.live = r->prepass ? r->live : nullptr;
@@ -851,10 +857,10 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
     a->frame.lds_stage = r->lds_stage;
     a->frame.march_micro = r->march_micro;
     a->frame.march_fill = r->march_fill;
-    a->frame.live_count = r->queue_head + 3;
+    a->frame.live_count = ctrl + 3;
     a->frame.cost = r->sort_cont ? r->cost : nullptr;
     a->frame.order = r->sort_cont && r->cost ? r->order : nullptr;
-    a->frame.sort_ws = r->queue_head + 4;
+    a->frame.sort_ws = ctrl + 4;
     a->frame.fb = r->fb;
     if (r->render.imgEss && r->render.technique == 0) {
         a->frame.hit_in = r->hit_in;
@@ -887,15 +893,22 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
 int launch_timed(vrhip_renderer *r, const RaycastLaunch &a)
 {
     if (a.instr) VR_HIP(r, hipMemsetAsync(r->stats_dev, 0, sizeof(DevStats), r->stream));
-    VR_HIP(r, hipMemsetAsync(r->queue_head, 0, kControlWords * sizeof(uint32_t), r->stream));
+    // control words: the block of this set was zeroed by the first kernel of the previous set (memset
+    // only for the first set, or after something else has used the block)
+    if (!r->ctrl_clean[r->ctrl_sel])
+        VR_HIP(r, hipMemsetAsync(a.frame.queue_head, 0, kControlWords * sizeof(uint32_t), r->stream));
+    r->ctrl_clean[r->ctrl_sel] = false;
     VR_HIP(r, hipEventRecord(r->ev0, r->stream));
     RaycastLaunch b = a;
-    b.mid_event = r->evm;
+    b.mid_event = r->phase_timing ? r->evm : nullptr;   // (an event between two launches costs ~6 us of GPU time)
+    r->phase_timed = r->phase_timing;
     if (b.frame.hit_in) {
         VR_HIP(r, hipMemsetAsync(r->hit_any, 0, (size_t)r->hit_w * r->hit_h, r->stream));
         b.hit_out = r->hit_out;
     }
     VR_HIP(r, vr_launch_frame(b, r->stream));
+    r->ctrl_sel ^= 1u;                 // the first kernel of this set has zeroed the other block
+    r->ctrl_clean[r->ctrl_sel] = true;
     VR_HIP(r, hipEventRecord(r->ev1, r->stream));
     r->timed = true;
     if (b.frame.hit_in) std::swap(r->hit_in, r->hit_out);   // runRaycast, volumerendercl.cpp:524-530
@@ -967,7 +980,9 @@ int count_touched_impl(vrhip_renderer *r, uint32_t width, uint32_t height, uint3
     // image-order ESS: the pass skips what the next frame will skip, and leaves the hit images alone
     if (a.frame.hit_in && e == hipSuccess)
         e = hipMemsetAsync(r->hit_any, 0, (size_t)r->hit_w * r->hit_h, r->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(r->queue_head, 0, kControlWords * sizeof(uint32_t), r->stream);
+    a.frame.next_ctrl = nullptr;   // (this pass does not take part in the alternation of the control blocks)
+    if (e == hipSuccess) e = hipMemsetAsync(a.frame.queue_head, 0, kControlWords * sizeof(uint32_t), r->stream);
+    r->ctrl_clean[r->ctrl_sel] = false;
     if (e == hipSuccess) e = vr_launch_frame(a, r->stream);
     std::vector<uint32_t> host(words);
     if (e == hipSuccess)
@@ -1024,7 +1039,7 @@ int vrhip_create(int device_id, vrhip_renderer **out)
         (e = hipEventCreate(&r->evb0)) != hipSuccess ||
         (e = hipEventCreate(&r->evb1)) != hipSuccess ||
         (e = hipMalloc((void **)&r->stats_dev, sizeof(DevStats))) != hipSuccess ||
-        (e = hipMalloc((void **)&r->queue_head, kControlWords * sizeof(uint32_t))) != hipSuccess) {
+        (e = hipMalloc((void **)&r->queue_head, 2 * kControlWords * sizeof(uint32_t))) != hipSuccess) {
         std::string msg = std::string("ERROR: vrhip_create (") + hipGetErrorString(e) + ")";
         delete r;
         return fail(nullptr, VRHIP_ERR_HIP, msg);
@@ -1664,13 +1679,20 @@ double vrhip_last_kernel_seconds(const vrhip_renderer *r)
 
 int vrhip_last_phase_seconds(const vrhip_renderer *r, double *phase1, double *phase2)
 {
-    if (!r || !r->timed) return VRHIP_ERR_NODATA;
+    if (!r || !r->timed || !r->phase_timed) return VRHIP_ERR_NODATA;
     float a = 0.f, b = 0.f;
     if (hipEventSynchronize(r->ev1) != hipSuccess) return VRHIP_ERR_HIP;
     if (hipEventElapsedTime(&a, r->ev0, r->evm) != hipSuccess) return VRHIP_ERR_HIP;
     if (hipEventElapsedTime(&b, r->evm, r->ev1) != hipSuccess) return VRHIP_ERR_HIP;
     if (phase1) *phase1 = (double)a * 1e-3;
     if (phase2) *phase2 = (double)b * 1e-3;
+    return VRHIP_OK;
+}
+
+int vrhip_set_phase_timing(vrhip_renderer *r, int enabled)
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    r->phase_timing = enabled != 0;
     return VRHIP_OK;
 }
 

@@ -532,10 +532,17 @@ class VolumeRenderCL:
     def getLastExecTime(self):
         return float(self._lib.vrhip_last_kernel_seconds(self._h))
 
+    def setPhaseTiming(self, v):
+        """Record an event between the two phases of a frame (vrhip_set_phase_timing; off by default:
+        the event costs GPU time)."""
+        self._check(self._lib.vrhip_set_phase_timing(self._h, 1 if v else 0))
+
     def getLastPhaseTimes(self):
-        """(phase-1 seconds, phase-2 seconds) of the last ray-cast pass."""
+        """(phase-1 seconds, phase-2 seconds) of the last ray-cast pass rendered with setPhaseTiming(True);
+        (0.0, 0.0) when the last pass was not phase-timed."""
         a, b = C.c_double(), C.c_double()
-        self._check(self._lib.vrhip_last_phase_seconds(self._h, C.byref(a), C.byref(b)))
+        if self._lib.vrhip_last_phase_seconds(self._h, C.byref(a), C.byref(b)) != _lib.OK:
+            return 0.0, 0.0
         return float(a.value), float(b.value)
 
     # ---- test / bench conveniences (not in the reference)
