@@ -72,6 +72,12 @@ def parse():
     ap.add_argument("--frames-in-flight", type=int, default=2,
                     help="single GPU: renderers (one stream each, sharing the volume) that alternate "
                          "frames, so that the tail of one frame overlaps the head of the next")
+    ap.add_argument("--root-share", default="auto",
+                    help="multi-GPU: the fraction of a peer's tiles rank 0 renders (it also assembles every frame); "
+                         "auto = (1 + a - N a) / (1 + a) with a = 0.055, the assembly's share of a whole frame's "
+                         "time measured on one MI355X (tools/assemble_time.py: 0.0108 of 0.194 ms at 1024^2)")
+    ap.add_argument("--dense-gather", action="store_true",
+                    help="multi-GPU: gather every tile whole (default: tiles of one colour travel as one pixel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="target CPU work for the bounded cpu_baseline sample")
@@ -191,6 +197,15 @@ def host_cpu_share():
 
 def main():
     args = parse()
+    # stdout carries ONE line, the result: native libraries write banners to file descriptor 1 (RCCL prints its
+    # version block there when the process group comes up), so everything but that line goes to stderr
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(text):
+        os.write(result_fd, (text + "\n").encode())
+
     parity_failed = False
     import torch
     import torch.distributed as dist
@@ -253,7 +268,12 @@ def main():
     mt = frontend.Mt19937()
     seeds = [mt() for _ in range(args.warmup + args.steps)]
 
-    split = vtiles.TileSplit(W, H, args.tile, args.tile, world, rank)
+    if args.root_share == "auto":
+        a_asm = 0.055
+        root_share = max(0.25, (1.0 + a_asm - world * a_asm) / (1.0 + a_asm)) if world > 1 else 1.0
+    else:
+        root_share = float(args.root_share)
+    split = vtiles.TileSplit(W, H, args.tile, args.tile, world, rank, root_share)
     frame = torch.empty((H, W, 4), dtype=torch.float32, device=dev) if rank == 0 else None
     # world > 1: `--frames-per-gather` independent frames share one collective (fewer, larger
     # gathers: the host-side cost of a collective is comparable to a rank's rendering time)
@@ -264,7 +284,8 @@ def main():
     throughput = fif > 1 or fpl > 1
     # (in throughput mode this driver only serves the warm-up and the untimed one-frame-at-a-time
     # passes; the timed loop has its own, below)
-    driver = vtiles.TileDriver(vr, split, dev, batch=1 if throughput else fpg, force_gather=force_gather)
+    sparse = not args.dense_gather
+    driver = vtiles.TileDriver(vr, split, dev, batch=1 if throughput else fpg, force_gather=force_gather, sparse=sparse)
     frames = (torch.empty((fpg, H, W, 4), dtype=torch.float32, device=dev)
               if rank == 0 and multi else None)
 
@@ -290,7 +311,7 @@ def main():
         lanes = [(r, s_, torch.empty((fpl, H, W, 4), dtype=torch.float32, device=dev)) for r, s_, _ in lanes]
     if multi and throughput:
         driver_mt = vtiles.TileDriver(vr, split, dev, batch=fpg, lanes=[(r, s_) for r, s_, _ in lanes],
-                                      force_gather=force_gather)
+                                      force_gather=force_gather, sparse=sparse)
 
     # the throughput warm-up renders frames of its OWN seeds (a second generator), not the timed ones:
     # caches and the per-pixel cost map (phase 2's sort key) are primed by similar, not identical, frames
@@ -339,6 +360,7 @@ def main():
         dist.barrier()
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
+    gs0 = dict(drv.gather_stats)
     t0 = time.perf_counter()
     ev0.record(stream)
     for _, s2, _ in lanes[1:]:
@@ -362,6 +384,16 @@ def main():
     if multi:
         dist.barrier()
     wall = time.perf_counter() - t0
+    gather_info = None
+    if multi:
+        gs1 = drv.gather_stats
+        dense_b = 16 * W * H * (world - 1) / world if world > 1 else 16 * W * H
+        gather_info = {"mode": "sparse (tiles of one colour travel as one pixel)" if drv.sparse else "dense",
+                       "dense_bytes_per_frame_to_root": dense_b,
+                       "sent_bytes_per_frame_to_root": ((gs1["sent_bytes"] - gs0["sent_bytes"]) / args.steps
+                                                        if drv.sparse else dense_b),
+                       "tile": args.tile, "root_share": root_share,
+                       "tiles_per_rank": [int(len(t_)) for t_ in split.tiles_of]}
     gpu_region_s = ev0.elapsed_time(ev1) * 1e-3
     last_kernel_s = vr.getLastExecTime()
     last_phases = vr.getLastPhaseTimes()
@@ -383,7 +415,7 @@ def main():
                 "round_budget": args.round_budget if throughput else 10,
                 "launch_sets_in_region": len(blocks) if (not multi and throughput) else args.steps,
                 "note": "timed region only; work counters, roofline and cpu_baseline come from the full run"})
-            print(line, flush=True)
+            emit(line)
             if args.out_json:
                 open(args.out_json, "w").write(line + "\n")
         if multi:
@@ -613,6 +645,7 @@ def main():
                 "frac_hbm_peak": ((b * res ** 3) / bricks_s / 1e9 / HBM_PEAK_GBS
                                   if bricks_s > 0 else None),
             },
+            "gather": gather_info,
             "roofline": roofline,
             "roofline_valu_issue": roofline_valu,
             "cpu_baseline": cpu,
@@ -620,7 +653,7 @@ def main():
             "parity_max_abs_diff": parity["max_abs_diff"] if parity else None,
         }
         line = json.dumps(out)
-        print(line, flush=True)
+        emit(line)
         if args.out_json:
             open(args.out_json, "w").write(line + "\n")
         if parity and not (parity["max_abs_diff"] <= parity["tolerance"] and parity["counters_equal"]):

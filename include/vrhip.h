@@ -232,6 +232,19 @@ int vrhip_assemble_frame(vrhip_renderer *r, const float *staging_dev, const uint
                          uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h,
                          float *frame_dev);
 
+/* Multi-GPU, rank 0: assemble the n_frames frames of a batch straight from the ranks' gather messages
+ * (tiles.py TileDriver, sparse gather: a tile of one colour travels as one pixel).  msgs_dev: HOST array
+ * of `world` (<= 64) device pointers, message r = [maxc floats: slot numbers of rank r's whole tiles |
+ * S = n_frames x cap RGBA pixels, one per tile slot | maxc whole tiles of tile_w x tile_h RGBA pixels]
+ * (16-byte aligned, maxc a multiple of 4); pos_dev[r * S + row] = -1 (one colour: that pixel) or the
+ * position of row = frame x cap + slot among rank r's whole tiles; rank_slot_of_tile_dev[t] = rank << 16 |
+ * slot of tile t (tiles numbered row-major over the frame).  One thread per pixel of frames_dev
+ * [n_frames][height][width][4], enqueued on hip_stream (a hipStream_t; NULL = legacy default stream). */
+int vrhip_assemble_batch(vrhip_renderer *r, void *hip_stream, const float *const *msgs_dev, uint32_t world,
+                         uint32_t n_frames, uint32_t cap, uint32_t maxc, const int32_t *pos_dev,
+                         const uint32_t *rank_slot_of_tile_dev, uint32_t width, uint32_t height, uint32_t tile_w,
+                         uint32_t tile_h, float *frames_dev);
+
 /* A batch of n_frames <= 256 INDEPENDENT frames (n_frames x pixels per frame < 2^32) -- same camera and parameters, frame f with jitter
  * seed seeds[f] (rendering_params.seed is not used) -- in ONE set of launches: the work queue holds
  * every patch once per frame, so a small tile share still fills the GPU and the latency chain of

@@ -46,10 +46,11 @@ void vrhost_free_pixels(float *pixels);
 
 /* Multi-GPU tile dealing of the headless host (csrc/host/tilegather.h; no reference counterpart: the
  * reference is single-GPU, volumerendercl.cpp:140): owner_out[t] = rank of tile t of the width x height
- * frame cut into tile x tile tiles (row-major, n_tiles = ceil(w / tile) * ceil(h / tile)).  Returns 0, or
+ * frame cut into tile x tile tiles (row-major, n_tiles = ceil(w / tile) * ceil(h / tile)); root_share: the
+ * fraction of a peer's tiles rank 0 takes (1 = an equal share; it also assembles the frames).  Returns 0, or
  * 1 on bad arguments. */
-int vrhost_deal_tiles(uint32_t width, uint32_t height, uint32_t tile, uint32_t ranks, uint32_t *owner_out,
-                      uint32_t n_tiles);
+int vrhost_deal_tiles(uint32_t width, uint32_t height, uint32_t tile, uint32_t ranks, double root_share,
+                      uint32_t *owner_out, uint32_t n_tiles);
 
 #ifdef __cplusplus
 }

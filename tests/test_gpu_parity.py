@@ -1923,6 +1923,18 @@ for lo in (0, 1):
     got = frames.cpu().numpy()
     for i in range(4):
         assert np.array_equal(got[i], full[lo + i]), (lo, i)
+# (2b) the same with uniform tiles travelling as one pixel (sparse): all-gather of the counts + payload gather
+drv3 = tiles.TileDriver(vr, split, dev, batch=4, lanes=[(vr, s1), (twin, s2)], force_gather=True, sparse=True)
+drv3.submit_frames(seeds[:4]); drv3.submit_frames(seeds[1:5])
+for lo in (0, 1):
+    drv3.collect_batch(frames); torch.cuda.synchronize()
+    got = frames.cpu().numpy()
+    for i in range(4):
+        assert np.array_equal(got[i], full[lo + i]), ("sparse", lo, i)
+assert 0 < drv3.gather_stats["sent_bytes"] < drv3.gather_stats["dense_bytes"], drv3.gather_stats
+drv4 = tiles.TileDriver(vr, split, dev, force_gather=True, sparse=True)
+vr.setSeed(seeds[3]); vr.setIteration(0)
+assert np.array_equal(drv4.render_frame(frame).cpu().numpy(), full[3])
 # (3) the collectives bench.py issues around the timed region
 t = torch.tensor([1.5], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX)
 c = torch.arange(6, dtype=torch.int64, device=dev); dist.all_reduce(c, op=dist.ReduceOp.SUM)
@@ -1955,6 +1967,7 @@ def test_bench_multi_gpu_path_rehearsed_over_rccl_on_one_gpu(tmp_path):
         assert d["n_gpus"] == 1 and "RCCL gather per 5 frames" in d["config"]["parallelism"]
         assert d["parity"]["max_abs_diff"] <= TOL and d["parity"]["counters_equal"]
         assert d["value"] > 0 and d["work_per_frame"]["samples_taken"] > 0
+        assert d["gather"]["mode"].startswith("sparse") and d["gather"]["sent_bytes_per_frame_to_root"] > 0
 
 
 def test_control_blocks_alternate_cleanly(vr):

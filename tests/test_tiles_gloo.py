@@ -34,7 +34,7 @@ def _scene():
 BATCH_SEEDS = [11, 22222, 3333333, 44, 555]
 
 
-def _worker(rank, world, port, W, H, T, q):
+def _worker(rank, world, port, W, H, T, q, sparse=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -50,7 +50,7 @@ def _worker(rank, world, port, W, H, T, q):
                                         tile=(x0, y0, w, h), threads=1)
             out[k, :h, :w] = torch.from_numpy(img)
 
-    drv = tiles.TileDriver(None, split, torch.device("cpu"), render_tiles_fn=render_tiles, dist=dist)
+    drv = tiles.TileDriver(None, split, torch.device("cpu"), render_tiles_fn=render_tiles, dist=dist, sparse=sparse)
     frame = torch.zeros((H, W, 4)) if rank == 0 else None
     for _ in range(2):   # two frames: buffers are reusable
         out = drv.render_frame(frame)
@@ -66,7 +66,7 @@ def _worker(rank, world, port, W, H, T, q):
             outs.append(o.numpy().copy())
     # batched: up to 3 independent frames (their own jitter seeds) per gather, one gather in flight
     drvb = tiles.TileDriver(None, split, torch.device("cpu"), render_tiles_fn=render_tiles, dist=dist,
-                            batch=3)
+                            batch=3, sparse=sparse)
     frames = torch.zeros((3, H, W, 4)) if rank == 0 else None
     batched = []
 
@@ -83,7 +83,7 @@ def _worker(rank, world, port, W, H, T, q):
             batched += [o[i].numpy().copy() for i in range(n)]
     # the same frames through submit_frames (seeds handed to the renderer, one gather per call)
     drvf = tiles.TileDriver(None, split, torch.device("cpu"), render_tiles_fn=render_tiles, dist=dist,
-                            batch=5)
+                            batch=5, sparse=sparse)
     drvf.submit_frames(BATCH_SEEDS)
     o = drvf.collect_batch(torch.zeros((5, H, W, 4)) if rank == 0 else None)
     if rank == 0:
@@ -92,7 +92,7 @@ def _worker(rank, world, port, W, H, T, q):
     if rank == 0:
         for o in outs:
             np.testing.assert_array_equal(o, first)
-        q.put((first, batched))
+        q.put((first, batched, dict(drvf.gather_stats)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -105,17 +105,26 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,W,H,T", [(2, 96, 64, 32), (3, 80, 56, 16)])
-def test_gloo_tile_gather_matches_single_rank(world, W, H, T):
+@pytest.mark.parametrize("world,W,H,T,sparse", [(2, 96, 64, 32, False), (3, 80, 56, 16, False),
+                                                 (2, 96, 64, 32, True), (3, 160, 112, 16, True)])
+def test_gloo_tile_gather_matches_single_rank(world, W, H, T, sparse):
+    """Tiles over `world` ranks, gathered densely or with uniform tiles travelling as one pixel (sparse):
+    synchronous, pipelined and batched, every assembled frame equal to the single-rank render."""
     vol, tff, cam, rp, rc = _scene()
     ref, _, _ = vro.render_tile(vol, vro.UCHAR, tff, cam, rp, rc, W=W, H=H)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, T, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, T, q, sparse)) for r in range(world)]
     for p in procs:
         p.start()
-    got, batched = q.get(timeout=240)
+    got, batched, stats = q.get(timeout=240)
+    if sparse:   # the corners of the frame lie outside the volume's silhouette: whole tiles of one colour
+        assert stats["batches"] == 1 and stats["sent_bytes"] > 0, stats
+        if T == 16:   # (six 32 x 32 tiles all touch the silhouette; 16 x 16 tiles leave whole ones outside)
+            assert stats["sent_bytes"] < 0.8 * stats["dense_bytes"], stats
+    else:
+        assert stats["batches"] == 0
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -220,16 +229,22 @@ def test_tiles_are_dealt_by_distance_and_the_cpp_host_deals_the_same():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     _lib.load()
     host = C.CDLL(os.path.join(root, "volumerenderercl_amd", "libvrhost.so"))
+    host.vrhost_deal_tiles.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double,
+                                       C.POINTER(C.c_uint32), C.c_uint32]
     for W, H, T, n in ((1024, 1024, 64, 8), (2048, 2048, 64, 8), (1024, 1024, 32, 4), (200, 136, 32, 3),
                        (200, 136, 16, 2), (640, 360, 48, 5), (64, 64, 64, 8), (1024, 1024, 64, 1)):
-        owner = tiles.deal_tiles(W, H, T, T, n)
-        tx, ty = (W + T - 1) // T, (H + T - 1) // T
-        assert owner.shape == (tx * ty,) and owner.min() >= 0 and owner.max() <= n - 1
-        counts = np.bincount(owner, minlength=n)
-        assert counts.max() - counts.min() <= 2
-        out = (C.c_uint32 * (tx * ty))()
-        assert host.vrhost_deal_tiles(W, H, T, n, out, tx * ty) == 0
-        np.testing.assert_array_equal(np.array(out[:], dtype=np.int64), owner)
+        for share in (1.0, 0.58, 0.9, 0.25, 0.0):
+            owner = tiles.deal_tiles(W, H, T, T, n, share)
+            tx, ty = (W + T - 1) // T, (H + T - 1) // T
+            assert owner.shape == (tx * ty,) and owner.min() >= 0 and owner.max() <= n - 1
+            counts = np.bincount(owner, minlength=n)
+            if n > 1:
+                assert counts[1:].max() - counts[1:].min() <= 2
+                # rank 0 holds `share` of a peer's tiles, to within the two cards of a round
+                assert abs(counts[0] - share * counts[1:].mean()) <= 2.0 + 1e-9, (W, H, T, n, share, counts)
+            out = (C.c_uint32 * (tx * ty))()
+            assert host.vrhost_deal_tiles(W, H, T, n, share, out, tx * ty) == 0
+            np.testing.assert_array_equal(np.array(out[:], dtype=np.int64), owner)
     # the headline split: the four central tiles and the four corner tiles go to different ranks each
     owner = tiles.deal_tiles(1024, 1024, 64, 64, 8).reshape(16, 16)
     assert len({owner[7, 7], owner[7, 8], owner[8, 7], owner[8, 8]}) == 4

@@ -16,7 +16,8 @@ class VolumeRenderCL;
 // distance of their centre from the frame's centre (integers, ties by id) and dealt like cards, back and
 // forth (0 1 .. n-1 n-1 .. 1 0 0 1 ..), so that every rank gets tiles of every distance (load balance:
 // a tile's cost follows the object in the middle of the view).  Same rule as tiles.py deal_tiles.
-std::vector<unsigned int> vr_deal_tiles(size_t width, size_t height, size_t tile, size_t n);
+// root_share < 1: rank 0, which also assembles the frames, takes that fraction of a peer's tiles.
+std::vector<unsigned int> vr_deal_tiles(size_t width, size_t height, size_t tile, size_t n, double root_share = 1.0);
 
 class TileGather
 {

@@ -96,14 +96,17 @@ int vrdr_histogram(vrdr *h, uint64_t t, double out[256])
 
 // ---- tile dealing of the multi-GPU driver (tilegather.h), exported for the CPU test against tiles.py
 #include <algorithm>
+#include <cmath>
 #include <utility>
 #include <vector>
 
 #include "tilegather.h"
 
-std::vector<unsigned int> vr_deal_tiles(size_t width, size_t height, size_t tile, size_t n)
+std::vector<unsigned int> vr_deal_tiles(size_t width, size_t height, size_t tile, size_t n, double root_share)
 {
     const size_t tiles_x = (width + tile - 1) / tile, tiles_y = (height + tile - 1) / tile, nt = tiles_x * tiles_y;
+    std::vector<unsigned int> owner(nt, 0u);
+    if (n <= 1) return owner;
     std::vector<std::pair<long long, unsigned int>> order(nt);
     for (size_t t = 0; t < nt; ++t) {
         const long long dx = (2 * static_cast<long long>(t % tiles_x) + 1) * static_cast<long long>(tile) - static_cast<long long>(width);
@@ -111,19 +114,32 @@ std::vector<unsigned int> vr_deal_tiles(size_t width, size_t height, size_t tile
         order[t] = {dx * dx + dy * dy, static_cast<unsigned int>(t)};
     }
     std::sort(order.begin(), order.end());
-    std::vector<unsigned int> owner(nt);
-    for (size_t i = 0; i < nt; ++i) {
-        const size_t j = i % (2 * n);
-        owner[order[i].second] = static_cast<unsigned int>(j < n ? j : 2 * n - 1 - j);
+    // rounds of the deal 0 1 .. n-1 n-1 .. 1 0; of its two cards per round rank 0 takes 2 * root_share on
+    // average (error diffusion, first / last card alternating) -- tiles.py deal_tiles, operation for operation
+    const double share = std::min(1.0, std::max(0.0, root_share));
+    std::vector<unsigned int> seq;
+    seq.reserve(nt + 2 * n);
+    double acc = 0.0;
+    for (size_t cycle = 0; seq.size() < nt; ++cycle) {
+        acc += 2.0 * share;
+        const int take = static_cast<int>(std::floor(acc + 1e-9));
+        acc -= take;
+        const bool first = take == 2 || (take == 1 && cycle % 2 == 0);
+        const bool last = take == 2 || (take == 1 && cycle % 2 == 1);
+        if (first) seq.push_back(0u);
+        for (size_t r = 1; r < n; ++r) seq.push_back(static_cast<unsigned int>(r));
+        for (size_t r = n - 1; r >= 1; --r) seq.push_back(static_cast<unsigned int>(r));
+        if (last) seq.push_back(0u);
     }
+    for (size_t i = 0; i < nt; ++i) owner[order[i].second] = seq[i];
     return owner;
 }
 
-extern "C" int vrhost_deal_tiles(uint32_t width, uint32_t height, uint32_t tile, uint32_t ranks, uint32_t *owner_out,
-                                 uint32_t n_tiles)
+extern "C" int vrhost_deal_tiles(uint32_t width, uint32_t height, uint32_t tile, uint32_t ranks, double root_share,
+                                 uint32_t *owner_out, uint32_t n_tiles)
 {
     if (!owner_out || !tile || !ranks || !width || !height) return 1;
-    const std::vector<unsigned int> owner = vr_deal_tiles(width, height, tile, ranks);
+    const std::vector<unsigned int> owner = vr_deal_tiles(width, height, tile, ranks, root_share);
     if (owner.size() != n_tiles) return 1;
     std::copy(owner.begin(), owner.end(), owner_out);
     return 0;

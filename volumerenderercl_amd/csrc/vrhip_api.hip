@@ -1011,6 +1011,53 @@ __global__ __launch_bounds__(256) void vr_assemble_kernel(const float4 *staging,
     frame[(size_t)y * W + x] = staging[((size_t)slot * th + (y % th)) * tw + (x % tw)];
 }
 
+// Multi-GPU, rank 0: the frames of a batch straight from the ranks' (sparse) gather messages, one thread per
+// pixel -- tiles of one colour from their single pixel, the others from the message's whole tiles
+// (TileDriver, tiles.py: message = [maxc slot numbers | S pixels | maxc whole tiles], S = frames x cap).
+constexpr uint32_t kMaxGatherRanks = 64;
+struct GatherMsgs { const float *p[kMaxGatherRanks]; };
+
+__global__ __launch_bounds__(256) void vr_assemble_batch_kernel(GatherMsgs msgs, const int32_t *pos, const uint32_t *rank_slot,
+                                                                uint32_t S, uint32_t cap, uint32_t maxc, uint32_t W, uint32_t H,
+                                                                uint32_t tw, uint32_t th, uint32_t tiles_x, float4 *frames)
+{
+    // one workgroup per (tile, frame): the tile's rank, slot and position are looked up once, and a thread's
+    // column inside the tile is fixed where the tile's width divides the workgroup (16 .. 256 pixels)
+    const uint32_t t = blockIdx.x, f = blockIdx.y;
+    const uint32_t rs = rank_slot[t];
+    const uint32_t rank = rs >> 16, row = f * cap + (rs & 0xffffu);
+    const float *m = msgs.p[rank];
+    const int32_t p = pos[(size_t)rank * S + row];
+    const uint32_t x0 = (t % tiles_x) * tw, y0 = (t / tiles_x) * th;
+    float4 *dst = frames + ((size_t)f * H + y0) * W + x0;
+    const uint32_t w = min(tw, W - x0), h = min(th, H - y0);   // (ragged right / bottom tiles)
+    if (p < 0) {
+        const float4 v = reinterpret_cast<const float4 *>(m + maxc)[row];
+        if (256u % tw == 0u) {
+            const uint32_t lx = threadIdx.x % tw;
+            if (lx < w)
+                for (uint32_t ly = threadIdx.x / tw; ly < h; ly += 256u / tw) dst[(size_t)ly * W + lx] = v;
+        } else {
+            for (uint32_t i = threadIdx.x; i < tw * th; i += 256u) {
+                const uint32_t ly = i / tw, lx = i - ly * tw;
+                if (lx < w && ly < h) dst[(size_t)ly * W + lx] = v;
+            }
+        }
+        return;
+    }
+    const float4 *src = reinterpret_cast<const float4 *>(m + maxc + 4u * (size_t)S) + (size_t)p * th * tw;
+    if (256u % tw == 0u) {
+        const uint32_t lx = threadIdx.x % tw;
+        if (lx < w)
+            for (uint32_t ly = threadIdx.x / tw; ly < h; ly += 256u / tw) dst[(size_t)ly * W + lx] = src[ly * tw + lx];
+    } else {
+        for (uint32_t i = threadIdx.x; i < tw * th; i += 256u) {
+            const uint32_t ly = i / tw, lx = i - ly * tw;
+            if (lx < w && ly < h) dst[(size_t)ly * W + lx] = src[i];
+        }
+    }
+}
+
 } // namespace
 
 extern "C" {
@@ -1191,6 +1238,30 @@ int vrhip_assemble_frame(vrhip_renderer *r, const float *staging_dev, const uint
     hipLaunchKernelGGL(vr_assemble_kernel, dim3((width + 63) / 64, (height + 3) / 4), dim3(256), 0, r->stream,
                        (const float4 *)staging_dev, slot_of_tile_dev, width, height, tile_w, tile_h, tiles_x,
                        (float4 *)frame_dev);
+    VR_HIP(r, hipGetLastError());
+    return VRHIP_OK;
+}
+
+int vrhip_assemble_batch(vrhip_renderer *r, void *hip_stream, const float *const *msgs_dev, uint32_t world,
+                         uint32_t n_frames, uint32_t cap, uint32_t maxc, const int32_t *pos_dev,
+                         const uint32_t *rank_slot_of_tile_dev, uint32_t width, uint32_t height, uint32_t tile_w,
+                         uint32_t tile_h, float *frames_dev)
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    VR_REQUIRE(r, msgs_dev && pos_dev && rank_slot_of_tile_dev && frames_dev && world >= 1 && world <= kMaxGatherRanks &&
+                      n_frames && cap && cap <= 65536u && width && height && tile_w && tile_h && n_frames <= 65535u,
+               VRHIP_ERR_INVALID, "vrhip_assemble_batch: invalid argument");
+    if (set_device(r)) return VRHIP_ERR_HIP;
+    GatherMsgs g;
+    for (uint32_t i = 0; i < kMaxGatherRanks; ++i) g.p[i] = i < world ? msgs_dev[i] : nullptr;
+    for (uint32_t i = 0; i < world; ++i)
+        VR_REQUIRE(r, g.p[i] && ((uintptr_t)g.p[i] & 15u) == 0 && maxc % 4u == 0, VRHIP_ERR_INVALID,
+                   "vrhip_assemble_batch: messages must be 16-byte aligned, maxc a multiple of 4");
+    const uint32_t tiles_x = (width + tile_w - 1) / tile_w;
+    const uint32_t tiles_y = (height + tile_h - 1) / tile_h;
+    hipLaunchKernelGGL(vr_assemble_batch_kernel, dim3(tiles_x * tiles_y, n_frames), dim3(256), 0,
+                       (hipStream_t)hip_stream, g, pos_dev, rank_slot_of_tile_dev, n_frames * cap, cap, maxc, width,
+                       height, tile_w, tile_h, tiles_x, (float4 *)frames_dev);
     VR_HIP(r, hipGetLastError());
     return VRHIP_OK;
 }

@@ -12,30 +12,50 @@ tile borders: a work-group looks at last frame's hit texels of its 3x3 neighbour
 rank updates the texels of its own tiles; with `image_ess=True` the driver merges them after
 each frame with one small all-reduce ((W/8+1)*(H/8+1) bytes) before the next frame reads them.
 """
+import math
+import os
+
 import numpy as np
 
 
-def deal_tiles(W, H, tw, th, world):
+def deal_tiles(W, H, tw, th, world, root_share=1.0):
     """owner[t] for the tiles of a W x H frame, numbered row-major: the tiles are sorted by the distance
     of their centre from the frame's centre (integer arithmetic, ties by tile id) and dealt to the ranks
     like cards, back and forth (0 1 .. n-1 n-1 .. 1 0 0 1 ..): every rank gets tiles of every distance.
     What a tile costs follows the object in the middle of the view; a diagonal interleave ((tx + ty) mod
     n) hands whole anti-diagonals to one rank -- at 16 x 16 tiles for 8 ranks the one through the centre:
     measured shares of 0.012 .. 0.034 ms per frame on the headline, 0.72 of the possible speed-up; dealt
-    by distance 0.96.  The same rule lives in csrc/host/tilegather.cpp."""
+    by distance 0.96.
+
+    root_share < 1: rank 0 also assembles every frame (time it does not render in), so it takes only that
+    fraction of a peer's tiles: of its two cards per round of the deal it takes 2 * root_share on average
+    (error diffusion over the rounds, first / last card alternating).  The same rule lives in the C++ host
+    (vr_deal_tiles, csrc/host/vrhost_capi.cpp); tests/test_tiles_gloo.py compares the two."""
     tiles_x, tiles_y = (W + tw - 1) // tw, (H + th - 1) // th
-    ids = np.arange(tiles_x * tiles_y, dtype=np.int64)
+    nt = tiles_x * tiles_y
+    ids = np.arange(nt, dtype=np.int64)
     dx = (2 * (ids % tiles_x) + 1) * tw - W
     dy = (2 * (ids // tiles_x) + 1) * th - H
     order = np.lexsort((ids, dx * dx + dy * dy))          # by distance, then by id
-    j = np.arange(ids.size) % (2 * world)
-    owner = np.empty(ids.size, dtype=np.int64)
-    owner[order] = np.where(j < world, j, 2 * world - 1 - j)
+    owner = np.zeros(nt, dtype=np.int64)
+    if world == 1:
+        return owner
+    share = min(1.0, max(0.0, float(root_share)))
+    seq, acc, cycle = [], 0.0, 0
+    while len(seq) < nt:
+        acc += 2.0 * share
+        take = int(math.floor(acc + 1e-9))
+        acc -= take
+        first = take == 2 or (take == 1 and cycle % 2 == 0)
+        last = take == 2 or (take == 1 and cycle % 2 == 1)
+        seq += ([0] if first else []) + list(range(1, world)) + list(range(world - 1, 0, -1)) + ([0] if last else [])
+        cycle += 1
+    owner[order] = np.asarray(seq[:nt], dtype=np.int64)
     return owner
 
 
 class TileSplit:
-    def __init__(self, width, height, tile_w, tile_h, world, rank):
+    def __init__(self, width, height, tile_w, tile_h, world, rank, root_share=1.0):
         if tile_w % 16 or tile_h % 16:
             raise ValueError("Tile size must be a positive multiple of 16.")
         self.W, self.H, self.tw, self.th = int(width), int(height), int(tile_w), int(tile_h)
@@ -44,7 +64,8 @@ class TileSplit:
         self.tiles_y = (self.H + self.th - 1) // self.th
         self.n_tiles = self.tiles_x * self.tiles_y
         ids = np.arange(self.n_tiles, dtype=np.uint32)
-        self.owner = deal_tiles(self.W, self.H, self.tw, self.th, self.world)
+        self.root_share = float(root_share)
+        self.owner = deal_tiles(self.W, self.H, self.tw, self.th, self.world, self.root_share)
         self.tiles_of = [ids[self.owner == r] for r in range(self.world)]
         self.cap = max(len(t) for t in self.tiles_of)     # slots per rank (equal-size gather)
         self.my_tiles = self.tiles_of[self.rank]
@@ -73,6 +94,17 @@ class TileDriver:
         hundred microseconds of GPU work per rank and frame the host-side cost of a collective is
         as long as the rendering, so fewer, larger collectives keep the GPUs busy.
 
+    sparse=True (the frame is mostly background): a tile whose pixels are all bit-identical -- the
+    background outside the volume's silhouette, the cleared inside where nothing was sampled -- travels
+    as ONE pixel; only the other tiles travel whole.  Per batch every rank packs its tile buffer ([slot
+    numbers of its whole tiles | one pixel per slot | the whole tiles]), the ranks agree on the largest
+    count with a tiny all-gather (messages of one size), and rank 0 expands what it receives into the
+    same staging layout the dense gather fills -- so the assembly and the result are the dense path's,
+    bit for bit.  Pure data compression: no assumption about what a background pixel is.  The count has
+    to reach the host (one synchronisation per batch); the payload gather of batch k is therefore issued
+    while batch k + 1 is already queued on the GPU (from the next submit, or from collect).  Headline
+    frame, 64 x 64 tiles: 45 % of the tiles travel whole at 1024^2, 36 % at 2048^2.
+
     Stream ordering: a renderer enqueues on a stream of its own (vrhip_get_stream) and returns
     without synchronising, while torch.distributed orders a collective behind torch's CURRENT
     stream only.  The driver therefore brackets every render: the renderer's stream first waits
@@ -82,7 +114,7 @@ class TileDriver:
     """
 
     def __init__(self, vr, split, device, render_tiles_fn=None, dist=None, image_ess=False,
-                 hit_io=None, batch=1, lanes=None, force_gather=False):
+                 hit_io=None, batch=1, lanes=None, force_gather=False, sparse=False):
         import torch
         self.torch = torch
         self.vr, self.split, self.device = vr, split, device
@@ -92,6 +124,9 @@ class TileDriver:
         # buffers, the collective (a world-size-1 process group: RCCL on a one-GPU box), assembly --
         # instead of the full-frame launch
         self.gathering = s.world > 1 or bool(force_gather)
+        # sparse: uniform tiles travel as one pixel (see _pack / _unpack below)
+        self.sparse = bool(sparse) and self.gathering
+        self.gather_stats = {"batches": 0, "dense_bytes": 0, "sent_bytes": 0}
         # frames in flight on this rank: [(renderer, torch stream), ...]; the frames of a batch are
         # dealt to them in turn (renderers sharing one volume, VolumeRenderCL.shareVolumes)
         self.lanes = list(lanes) if lanes else None
@@ -201,9 +236,7 @@ class TileDriver:
             if self.hit_io is not None:
                 self.merge_hit_image()      # the next frame reads the merged hit image
         self._after_render(streams, cur)    # the gather follows every renderer's frames
-        glist = [self.staging[b][r] for r in range(s.world)] if s.rank == 0 else None
-        work = self.dist.gather(self.local[b], glist, dst=0, async_op=True)
-        self.pending.append((b, n, work))
+        self._start_gather(b, n)
 
     def submit_frames(self, seeds):
         """len(seeds) <= batch independent frames (frame i jittered by seeds[i]) rendered in as few
@@ -235,9 +268,108 @@ class TileDriver:
             r.render_batch(s.W, s.H, seeds[lo:hi], self.local[b][lo].data_ptr(), s.tw, s.th,
                            s.my_tiles, frame_stride=stride)
         self._after_render(streams, cur)
-        glist = [self.staging[b][r] for r in range(s.world)] if s.rank == 0 else None
-        work = self.dist.gather(self.local[b], glist, dst=0, async_op=True)
-        self.pending.append((b, n, work))
+        self._start_gather(b, n)
+
+    # ---- the collective of a batch: dense, or uniform tiles as one pixel (sparse)
+    def _start_gather(self, b, n):
+        s = self.split
+        if not self.sparse:
+            glist = [self.staging[b][r] for r in range(s.world)] if s.rank == 0 else None
+            work = self.dist.gather(self.local[b], glist, dst=0, async_op=True)
+            self.pending.append({"b": b, "n": n, "work": work})
+            return
+        # payloads whose counts are known by now go first: the count of THIS batch reaches the host
+        # only after its frames are rendered, and the next batch should be queued before anyone waits
+        self._issue_payloads()
+        torch = self.torch
+        S, P = n * s.cap, s.th * s.tw
+        x = self.local[b].view(self.batch * s.cap, P, 4)[:S]
+        xi = x.view(torch.int32)
+        whole = (xi != xi[:, :1, :]).view(S, -1).any(dim=1)          # not all pixels bit-identical
+        uni = x[:, 0, :].contiguous()                                 # one pixel per slot
+        count = whole.sum().to(torch.int32).view(1)
+        counts = [torch.zeros(1, dtype=torch.int32, device=self.device) for _ in range(s.world)]
+        cwork = self.dist.all_gather(counts, count, async_op=True)
+        self.pending.append({"b": b, "n": n, "work": None, "whole": whole, "uni": uni, "x": x,
+                             "counts": counts, "cwork": cwork})
+
+    def _issue_payloads(self):
+        """Sparse: start the payload gather of every batch that has none yet (host synchronisation on the
+        ranks' counts of those batches)."""
+        s, torch = self.split, self.torch
+        for e in self.pending:
+            if e["work"] is not None or "cwork" not in e:
+                continue
+            e["cwork"].wait()
+            cs = [int(c.item()) for c in e["counts"]]                # (the synchronisation)
+            maxc = (max(1, max(cs)) + 3) // 4 * 4          # (a multiple of 4: the pixels behind it stay 16-byte aligned)
+            S, P = e["n"] * s.cap, s.th * s.tw
+            slots = torch.nonzero(e["whole"]).view(-1).to(torch.int32)   # cs[rank] entries
+            msg = torch.zeros(maxc + 4 * S + maxc * P * 4, dtype=torch.float32, device=self.device)
+            k = cs[s.rank]
+            if k:
+                msg[:k].view(torch.int32).copy_(slots)
+                msg[maxc + 4 * S: maxc + 4 * S + k * P * 4].view(k, P, 4).copy_(e["x"].index_select(0, slots.to(torch.int64)))
+            msg[maxc: maxc + 4 * S].view(S, 4).copy_(e["uni"])
+            recv = ([torch.empty_like(msg) for _ in range(s.world)] if s.rank == 0 else None)
+            e["work"] = self.dist.gather(msg, recv, dst=0, async_op=True)
+            e.update(cs=cs, maxc=maxc, recv=recv, msg=msg)
+            for key in ("whole", "uni", "x", "counts", "cwork"):
+                e.pop(key, None)
+            self.gather_stats["batches"] += 1
+            peers = max(1, s.world - 1)   # (a world of one, force_gather: its own message counts once)
+            self.gather_stats["dense_bytes"] += 16 * S * P * peers
+            self.gather_stats["sent_bytes"] += 4 * int(msg.numel()) * peers
+
+    def _assemble_fused(self, e, frames):
+        """Rank 0, sparse, on the GPU: the frames straight from the received messages with one kernel
+        (vrhip_assemble_batch) instead of expanding them into the dense staging buffer and assembling that
+        (index_select + strided copy: four passes over the frames' bytes, time rank 0 does not render in).
+        False where it does not apply (CPU tensors, a stand-in renderer, odd layouts): the torch path."""
+        s, torch = self.split, self.torch
+        lib = getattr(self.vr, "lib", None)
+        if os.environ.get("VRHIP_NO_FUSED_ASSEMBLY"):      # A/B: the torch path
+            return False
+        if (lib is None or frames is None or not frames.is_cuda or frames.dtype != torch.float32 or s.world > 64
+                or s.cap > 65536 or not frames[:e["n"]].is_contiguous() or tuple(frames.shape[1:]) != (s.H, s.W, 4)):
+            return False
+        import ctypes as C
+        n, S, maxc = e["n"], e["n"] * s.cap, e["maxc"]
+        pos = torch.full((s.world, S), -1, dtype=torch.int32, device=self.device)
+        for r in range(s.world):
+            k = e["cs"][r]
+            if k:
+                pos[r].index_copy_(0, e["recv"][r][:k].view(torch.int32).to(torch.int64),
+                                   torch.arange(k, dtype=torch.int32, device=self.device))
+        if not hasattr(self, "_rank_slot"):
+            rs = np.zeros(s.n_tiles, dtype=np.uint32)
+            for r in range(s.world):
+                ids = s.tiles_of[r].astype(np.int64)
+                rs[ids] = (np.uint32(r) << np.uint32(16)) | np.arange(len(ids), dtype=np.uint32)
+            self._rank_slot = torch.as_tensor(rs.astype(np.int64), device=self.device).to(torch.int32)
+        ptrs = (C.c_void_p * s.world)(*[m.data_ptr() for m in e["recv"]])
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = lib.vrhip_assemble_batch(self.vr.handle, C.c_void_p(stream), ptrs, s.world, n, s.cap, maxc,
+                                      C.c_void_p(pos.data_ptr()), C.c_void_p(self._rank_slot.data_ptr()), s.W, s.H,
+                                      s.tw, s.th, C.c_void_p(frames.data_ptr()))
+        if rc != 0:
+            raise RuntimeError("vrhip_assemble_batch failed (%d)" % rc)
+        e["keep"] = (pos, ptrs)     # (alive until the kernel has run: the caller synchronises before reuse)
+        self._last_assembled = e
+        return True
+
+    def _unpack(self, e):
+        """Rank 0, sparse: the received messages expanded into the dense staging layout of buffer b."""
+        s, torch = self.split, self.torch
+        S, P, maxc = e["n"] * s.cap, s.th * s.tw, e["maxc"]
+        for r in range(s.world):
+            m = e["recv"][r]
+            dense = self.staging[e["b"]][r].view(self.batch * s.cap, P, 4)[:S]
+            dense.copy_(m[maxc: maxc + 4 * S].view(S, 1, 4).expand(S, P, 4))
+            k = e["cs"][r]
+            if k:
+                slots = m[:k].view(torch.int32).to(torch.int64)
+                dense.index_copy_(0, slots, m[maxc + 4 * S: maxc + 4 * S + k * P * 4].view(k, P, 4))
 
     def collect(self, frame):
         """Finish the oldest frame in flight; returns the assembled frame on rank 0."""
@@ -248,10 +380,17 @@ class TileDriver:
         """Finish the oldest gather in flight; on rank 0 `frames` ([>= n, H, W, 4]) receives its n
         assembled frames (one index_select + one strided copy for the whole batch)."""
         s = self.split
-        b, n, work = self.pending.pop(0)
-        work.wait()
+        if self.sparse:
+            self._issue_payloads()
+        e = self.pending.pop(0)
+        b, n = e["b"], e["n"]
+        e["work"].wait()
         if s.rank != 0:
             return None
+        if self.sparse:
+            if self._assemble_fused(e, frames):
+                return frames
+            self._unpack(e)
         rows = self.staging[b].view(s.world * self.batch * s.cap, s.th, s.tw, 4)
         tiles_sorted = rows.index_select(0, self.perm[:n].reshape(-1))
         tv = tiles_sorted.view(n, s.tiles_y, s.tiles_x, s.th, s.tw, 4).permute(0, 1, 3, 2, 4, 5)
