@@ -201,17 +201,13 @@ def test_empty_skipping_is_exact(vr, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [{"VRHIP_CULL_RADIUS": "0"}, {"VRHIP_CULL_RADIUS": "12"},
-                                 {"VRHIP_MARCH": "1"}, {"VRHIP_MARCH": "1", "VRHIP_MARCH_MICRO": "1"},
-                                 {"VRHIP_EMPTY_SKIP": "1"}, {"VRHIP_EMPTY_SKIP": "1", "VRHIP_CELL_SHIFT": "3"},
-                                 {"VRHIP_LDS_STAGE": "1"}, {"VRHIP_LDS_STAGE": "2"}])
+                                 {"VRHIP_EMPTY_SKIP": "1"}, {"VRHIP_EMPTY_SKIP": "1", "VRHIP_CELL_SHIFT": "3"}])
 def test_schedules_and_culling_do_not_change_pixels(vr, monkeypatch, env):
-    """Scheduling devices of round 2 -- patch culling in the DDA pre-pass (off / wide radius), the
-    decoupled march kernel (vr_march_kernel: per-brick empty words, exact leaps of the t chain with
-    vr_leap, dense evaluation queues), empty-run skipping forced on where the heuristic leaves it off
-    (empty bits on cells of 4 voxels, and of 8: one grid for bounds and bits), the LDS brick
-    staging experiment (vr_raycast_staged_kernel, with and without the staged boxes) -- on a 256^3 field
-    with large empty regions, bricks of 4 voxels, three views, two seeds: bit-identical to the
-    default schedule's frames and equal to the oracle's."""
+    """Scheduling devices of the product library -- patch culling in the DDA pre-pass (off / wide radius),
+    empty-run skipping forced on where the heuristic leaves it off (empty bits on cells of 4 voxels, and
+    of 8: one grid for bounds and bits) -- on a 256^3 field with large empty regions, bricks of 4 voxels,
+    three views, two seeds: bit-identical to the default schedule's frames and equal to the oracle's.
+    (The experiment kernels of round 2 live in A/B builds only: test_experiment_kernels_*.)"""
     res = (256, 256, 256)
     vol = vro.synth_volume("shells", list(res), UCHAR)
     vol[:, :, :96] = 0            # a large empty slab the culling can work with
@@ -2028,3 +2024,66 @@ def test_control_blocks_alternate_cleanly(vr):
     finally:
         fresh.close()
         vr.setTechnique(0)
+
+
+def test_product_library_refuses_the_experiment_kernels(monkeypatch):
+    """vr_march_kernel, vr_raycast_staged_kernel and leap stepping are compiled into A/B builds only
+    (-DVR_EXPERIMENTS); the product library says so instead of rendering with other kernels."""
+    for var in ("VRHIP_MARCH", "VRHIP_LDS_STAGE", "VRHIP_MARCH_MICRO"):
+        monkeypatch.setenv(var, "1")
+        r = VolumeRenderCL()
+        with pytest.raises(RuntimeError, match="VR_EXPERIMENTS"):
+            r.initialize()
+        monkeypatch.delenv(var)
+
+
+def test_experiment_kernels_do_not_change_pixels():
+    """The A/B build with the experiment kernels (tools/mkvariant.sh experiments -DVR_EXPERIMENTS
+    -DVR_LEAP_STEPPING; skipped where it has not been built): the decoupled march kernel, leap stepping in the
+    two-phase kernels and the LDS brick staging kernel (with and without the staged boxes) render frames
+    bit-identical to that library's default schedule, which equals the oracle's."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "volumerenderercl_amd", "_variants", "libvrhip_experiments.so")
+    if not os.path.exists(lib):
+        pytest.skip("A/B build with the experiment kernels not present")
+    code = r"""
+import os, sys
+import numpy as np
+from oracle import vro
+from tests import common
+from volumerenderercl_amd import UCHAR, VolumeRenderCL
+res = (256, 256, 256)
+vol = vro.synth_volume("shells", list(res), UCHAR)
+vol[:, :, :96] = 0
+tff = common.tffs()["default"]
+W, H = 200, 152
+frames = {}
+envs = [("default", {}), ("march", {"VRHIP_MARCH": "1"}), ("march1", {"VRHIP_MARCH": "1", "VRHIP_MARCH_MICRO": "1"}),
+        ("leap", {"VRHIP_MARCH_MICRO": "3"}), ("lds1", {"VRHIP_LDS_STAGE": "1"}), ("lds2", {"VRHIP_LDS_STAGE": "2"})]
+for name, e in envs:
+    os.environ["VRHIP_EMPTY_SKIP"] = "1"
+    for k, v in e.items():
+        os.environ[k] = v
+    r2 = VolumeRenderCL(); r2.initialize()
+    r2.loadVolumeArrays([vol], UCHAR); r2.setTransferFunction(tff)
+    for view in ("rot30", "close", "inside"):
+        r2.updateView(common.views()[view])
+        for seed in (3499211612, 581869302):
+            r2.setSeed(seed); r2.setIteration(0)
+            frames[(name, view, seed)] = r2.runRaycastNoGL(W, H)
+    if name == "default":
+        r2.updateView(common.views()["rot30"]); r2.setSeed(3499211612); r2.setIteration(0)
+        cam, rp, rc, pt = common.to_oracle_params(*r2.params())
+        rp.seed, rp.iteration = 3499211612, 0
+        ref, _, _ = vro.render_tile(vol, UCHAR, tff, cam, rp, rc, pt, W=W, H=H)
+        assert np.array_equal(frames[("default", "rot30", 3499211612)], ref)
+    r2.close()
+    for k in e:
+        del os.environ[k]
+for (name, view, seed), img in frames.items():
+    assert np.array_equal(img, frames[("default", view, seed)]), (name, view, seed)
+print("EXPERIMENTS_OK", len(frames))
+"""
+    p = _run_py(code, env={"VRHIP_LIB_PATH": lib})
+    assert p.returncode == 0 and "EXPERIMENTS_OK 36" in p.stdout, (p.stdout[-500:], p.stderr[-3000:])

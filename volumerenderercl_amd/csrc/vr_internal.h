@@ -245,6 +245,8 @@ struct RaycastLaunch {
 };
 
 hipError_t vr_launch_raycast(const RaycastLaunch &a, hipStream_t stream);
+// 1 when vr_raycast.hip was built with the opt-in experiment kernels (-DVR_EXPERIMENTS: A/B builds only)
+int vr_experiments_built();
 // fills the footprint volume vol.fp of `vol`: (w+1)(h+1)(d+1) entries rounded up to
 // whole micro-bricks, 8 values of the volume's type each; vr_bricks.hip
 hipError_t vr_launch_build_footprint(const VolView &vol, int format, hipStream_t stream);

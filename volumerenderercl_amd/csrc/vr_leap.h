@@ -18,7 +18,7 @@
 #include <stdint.h>
 #include <string.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define VR_LEAP_FN __host__ __device__ inline
 #else
 #define VR_LEAP_FN static inline

@@ -32,8 +32,17 @@
 //  kernel, so the image is bit-identical whatever the schedule (budget, refill, batch, lists).
 #include <algorithm>
 
-#include "vr_leap.h"
 #include "vr_sampling.h"
+
+// A/B builds (tools/mkvariant.sh NAME -DVR_EXPERIMENTS [-DVR_LEAP_STEPPING]) add the kernels that lost their
+// A/B in round 2 -- vr_march_kernel (decoupled march), vr_raycast_staged_kernel (LDS brick staging), leap
+// stepping inside the two-phase kernels -- from vr_experiments_*.inc; the product library has none of them.
+#if defined(VR_EXPERIMENTS) && defined(VR_LEAP_STEPPING)
+#define VR_LEAP 1
+#endif
+#ifdef VR_EXPERIMENTS
+#include "vr_leap.h"
+#endif
 
 namespace {
 
@@ -711,103 +720,9 @@ VR_DEV bool lookahead_pays(bool sampling, bool guess_empty)
     return n_g > 0 && VR_LOOK_NUM * n_g >= n_s;
 }
 
-// ---- stepping over empty space in O(1) per run (CellView::bmask + vr_leap)
-//
-// A ray in a segment looks at its next sample: the sub-block of the ESS brick it falls into is looked
-// up in the per-brick empty words (the words of the last two bricks the ray has touched stay in
-// registers; a miss costs one load that is used by the lane's next step).  In an EMPTY sub-block every
-// sample composites to exactly nothing (:864-879 with opacity 0), so the whole run of samples up to
-// the sub-block's far side is stepped over at once: its length comes from the ray's texel increments
-// (good to a texel: the cells carry a one-texel halo for exactly this), and the ray parameter after
-// that many `t += stepSize` (:879) from vr_leap -- the exact bits of the chain of additions, without
-// the chain.  Only samples that are certainly neither the last of their segment (:790) nor of the
-// ray (:868) are handled in runs (a margin of two steps); the others take the reference's loop one
-// sample at a time.
-constexpr int kRunCap = 4096;              // samples stepped over at once, at most
-#ifndef VR_LEAP_ITERS
-#define VR_LEAP_ITERS 6
+#ifdef VR_EXPERIMENTS   // exact O(1) leaps over empty runs: opt-in experiments only (vr_experiments_leap.inc)
+#include "vr_experiments_leap.inc"
 #endif
-constexpr int kLeapIters = VR_LEAP_ITERS;  // leap steps (+ DDA steps) per round before the evaluation batch
-
-struct LeapCache {
-    uint32_t key0, key1;            // packed brick coordinates of the cached words (0xffffffff: none)
-    unsigned long long m0, m1;
-    float du, dv, ds, inv_step;     // texel increments per sample, 1 / stepSize
-};
-
-VR_DEV void leap_reset(LeapCache &lc, const RayCtx &c, float fw, float fh, float fd)
-{
-    lc.key0 = lc.key1 = 0xffffffffu;
-    lc.m0 = lc.m1 = 0ull;
-    lc.du = (c.dir.x * c.stepSize) * (0.5f * fw);
-    lc.dv = (c.dir.y * c.stepSize) * (0.5f * fh);
-    lc.ds = (c.dir.z * c.stepSize) * (0.5f * fd);
-    lc.inv_step = 1.0f / c.stepSize;
-}
-
-// samples (this one included) whose low-corner texel stays on this side of the sub-block boundary
-// along one axis: ub = texel coordinate of this sample, du = its increment per sample, the
-// sub-block spans [lo, hi)
-VR_DEV int run_axis(float ub, float du, float lo, float hi)
-{
-    const float dist = du > 0.f ? hi - ub : ub - lo;
-    const float q = vmax(dist, 0.f) * __builtin_amdgcn_rcpf(fabsf(du));
-    return du == 0.f ? kRunCap : (int)vmin(q, (float)kRunCap) + 1;
-}
-
-// One step of a lane that is in a segment (S_SAMPLE).  Returns true when the ray now stands at a
-// sample that has to be evaluated (t < t_exit, not known to be empty); otherwise it has moved on:
-// over a run of empty samples, over one sample, out of its segment (after_segment), or it waits for
-// a word it has just asked for.  `taken` counts the samples stepped over (instrumented variants).
-template <bool ESS, typename V>
-VR_DEV bool leap_step(const CellView &cells, const V &vol, const Grid &grid, const RayCtx &c, RayDyn &d,
-                      LeapCache &lc, bool count, unsigned long long &taken)
-{
-    if (!(d.t < d.t_exit)) {
-        after_segment<ESS>(c, d);
-        return false;
-    }
-    const int sx = cells.bex - 2, sy = cells.bey - 2, sz = cells.bez - 2;   // log2 of the sub-block edge
-    // low-corner texel of this sample's fetch (:791-793, Vol::linear), good to a texel
-    const f3 pos = add3(c.cam, scale3(c.dir, d.t - c.offset));
-    const float ub = (pos.x * 0.5f + 0.5f) * vol.fw - 0.5f;
-    const float vb = (pos.y * 0.5f + 0.5f) * vol.fh - 0.5f;
-    const float wb = (pos.z * 0.5f + 0.5f) * vol.fd - 0.5f;
-    const int x0 = iclamp((int)floorf(ub), 0, vol.w1);
-    const int y0 = iclamp((int)floorf(vb), 0, vol.h1);
-    const int z0 = iclamp((int)floorf(wb), 0, vol.d1);
-    const uint32_t bx = (uint32_t)(x0 >> cells.bex), by = (uint32_t)(y0 >> cells.bey), bz = (uint32_t)(z0 >> cells.bez);
-    const uint32_t key = bx | (by << 8) | (bz << 16);
-    if (key != lc.key0 && key != lc.key1) {
-        // the word of a brick this ray has not looked at lately: asked for now, used by the next step
-        lc.key1 = lc.key0; lc.m1 = lc.m0;
-        lc.key0 = key;
-        lc.m0 = cells.bmask[(bz * (uint32_t)grid.bh + by) * (uint32_t)grid.bw + bx];
-        return false;
-    }
-    const unsigned long long m = key == lc.key0 ? lc.m0 : lc.m1;
-    const uint32_t bit = (uint32_t)((x0 >> sx) & 3) | ((uint32_t)((y0 >> sy) & 3) << 2) | ((uint32_t)((z0 >> sz) & 3) << 4);
-    if (!((m >> bit) & 1ull)) return true;
-    // samples 0 .. safe - 1 from here certainly pass :790 and fail :868
-    const int safe = (int)floorf((vmin(d.t_exit, c.tfar) - d.t) * lc.inv_step) - 2;
-    if (safe >= 1) {
-        // all samples whose low-corner texel stays in this sub-block
-        const int run = min(min(run_axis(ub, lc.du, (float)((x0 >> sx) << sx), (float)(((x0 >> sx) + 1) << sx)),
-                                run_axis(vb, lc.dv, (float)((y0 >> sy) << sy), (float)(((y0 >> sy) + 1) << sy))),
-                            min(run_axis(wb, lc.ds, (float)((z0 >> sz) << sz), (float)(((z0 >> sz) + 1) << sz)), safe));
-        d.t = vr_leap(d.t, c.stepSize, (uint32_t)run);
-        if (count) taken += (unsigned long long)run;
-#ifdef VR_RAYLEN
-        d.nsmp += (uint32_t)run;
-#endif
-    } else {
-        if (count) taken++;
-        VR_RAYLEN_INC(d);
-        if (d.t >= c.tfar) d.state = S_DONE;      // :868 after a no-op :865-867
-        else d.t = d.t + c.stepSize;              // :879
-    }
-    return false;
-}
 
 // One front-to-back compositing step (:865-879) with the sample's colour*opacity (q0..q2),
 // opacity qo and ray parameter ti.
@@ -1233,13 +1148,10 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
     const Grid grid = make_grid(bricks, rc, skip.n_words, true);
     const uint32_t *sb = SKIP_LDS ? s_skip : skip.bits;
     const bool skip_empty = cells.empty != nullptr && rp.useLinear != 0;
-    // (opt-in, VRHIP_MARCH_MICRO = leap steps per round: measured no faster than the lookahead below)
-#ifdef VR_LEAP_STEPPING   // diagnostic build; VRHIP_MARCH_MICRO = leap steps per round
+#ifdef VR_LEAP   // A/B build (VR_EXPERIMENTS + VR_LEAP_STEPPING); VRHIP_MARCH_MICRO = leap steps per round
     const bool use_mask = skip_empty && cells.bmask != nullptr && fr.march_micro != 0;
-#else   // (kept out of the default build: its registers cost the two-phase kernels 2.5 % of the frame)
-    const bool use_mask = false;
-#endif
     const uint32_t leap_iters = fr.march_micro;
+#endif
     const uint32_t budget = fr.round_budget ? fr.round_budget : 0xffffffffu;
     const uint32_t kRefillLanes = (fr.refill_min ? fr.refill_min : 16u) * 4u;   // idle lanes before a refill
 
@@ -1248,8 +1160,10 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
     uint32_t gx = 0, gy = 0, out_index = 0, my_rounds = 0, frame_idx = 0;
     bool guess_empty = true;
     uint32_t cool = 0;   // evaluation batches before the ray guesses "empty" again (see the lookahead below)
+#ifdef VR_LEAP
     LeapCache lc;
     lc.key0 = lc.key1 = 0xffffffffu; lc.m0 = lc.m1 = 0ull; lc.du = lc.dv = lc.ds = lc.inv_step = 0.f;
+#endif
 #ifdef VR_MARCH_STATS
     unsigned long long ms_acc[16] = {0};
 #endif
@@ -1295,7 +1209,9 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
                             my_rounds = 0;
                             guess_empty = true;
                             cool = 0;
+#ifdef VR_LEAP
                             leap_reset(lc, c, vol.fw, vol.fh, vol.fd);
+#endif
                         }
                     }
                 }
@@ -1347,6 +1263,7 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
         VR_MARK("R_look");
         if (__ballot(d.state == S_SAMPLE)) my_rounds += d.state == S_SAMPLE ? 1u : 0u;
         bool more_empty = false;
+#ifdef VR_LEAP
         if (use_mask) {
             // steps over runs of empty samples (leap_step) until the ray stands at a sample to evaluate;
             // rays that leave their segment go on with the DDA in the same pass
@@ -1358,7 +1275,9 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
                 if (__ballot(d.state == S_BRICK)) dda_step<0>(sb, grid, c, d, n0, n1);
             }
             more_empty = !ready;
-        } else if (skip_empty && lookahead_pays(d.state == S_SAMPLE, guess_empty)) {
+        } else
+#endif
+        if (skip_empty && lookahead_pays(d.state == S_SAMPLE, guess_empty)) {
             VR_MS(4, 1);                                                       // lookahead executions
             VR_MS(5, __builtin_popcountll(__ballot(d.state == S_SAMPLE)));     // lanes in them
             if (d.state == S_SAMPLE) {
@@ -1377,32 +1296,6 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
             VR_MS(6, 1);                                                       // evaluation batches
             VR_MS(7, __builtin_popcountll(__ballot(d.state == S_SAMPLE && !more_empty)));   // lanes in them
         }
-#ifdef VR_EVAL_INLINE   // A/B build: the dense pass inside the divergent call (round 2)
-        if (d.state == S_SAMPLE && !more_empty) {
-            float tk[kBatch];
-            bool vk[kBatch], litk[kBatch];
-            tk[0] = d.t;
-            vk[0] = d.t < d.t_exit;   // inner loop condition (:790)
-#pragma unroll
-            for (int k = 1; k < kBatch; ++k) {
-                tk[k] = tk[k - 1] + c.stepSize;                                     // :879
-                vk[k] = vk[k - 1] && !(tk[k - 1] >= c.tfar) && (tk[k] < d.t_exit);  // :868, :790
-            }
-            float p0[kBatch], p1[kBatch], p2[kBatch], opk[kBatch];
-#ifdef VR_MARCH_STATS
-            for (int k = 0; k < kBatch; ++k) ms_acc[9] += vk[k] ? 1 : 0;      // valid samples evaluated (per lane: summed below)
-#endif
-            eval_batch<VT, 0, false, FP>(vol, s_tff, tffn, s_stage, c, rp, rc, refInterval, tk, vk, p0, p1, p2,
-                                         opk, litk);
-        VR_MARK("R_comp");
-#pragma unroll
-            for (int k = 0; k < kBatch; ++k)
-                if (vk[k] && d.state == S_SAMPLE) composite(c, d, p0[k], p1[k], p2[k], opk[k], tk[k]);
-            if (vk[kBatch - 1]) guess_empty = opk[kBatch - 1] == 0.f && cool == 0u;
-            if (cool) --cool;
-            after_segment<true>(c, d);
-        }
-#else
         // the evaluation batch as wave-uniform code in three parts (eval_front / eval_dense / eval_back): every
         // lane of the wave works in the dense pass, whether its own ray evaluates this round or not
         const bool ev = d.state == S_SAMPLE && !more_empty;
@@ -1434,7 +1327,6 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
                 after_segment<true>(c, d);
             }
         }
-#endif
     }
 #ifdef VR_MARCH_STATS
     if (lane == 0)
@@ -1442,375 +1334,6 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
     {
         unsigned long long w = wave_sum(ms_acc[9]);
         if (lane == 0) atomicAdd(&g_march_stats[16 + 9], w);
-    }
-#endif
-}
-
-// ------------------------------------------------------------------ decoupled march
-
-// The default march (ESS, no instrumentation, none of the XS extras): stepping, evaluation and
-// compositing are three stages of a round that exchange samples through per-wave LDS queues, so
-// that the expensive part of the frame -- the eight (forty) voxel loads, the transfer-function
-// lookup, opacity correction and shading of a sample -- runs over a DENSE list of the samples
-// that need it, whichever rays they belong to:
-//
-//  A  stepping, one lane per ray, in micro-steps.  A lane in a brick takes one step of the
-//     reference's DDA (dda_step).  A lane in a segment looks at its next sample: the sub-block of
-//     the ESS brick it falls into is looked up in the per-brick empty words (CellView::bmask; the
-//     words of the last two bricks the ray has touched stay in registers, a miss costs one load
-//     that is used in the next micro-step).  In an EMPTY sub-block every sample composites to
-//     exactly nothing, so the whole run of samples up to the sub-block's far side is stepped over
-//     at once: the run's length comes from the ray's texel increments, and the ray parameter after
-//     that many `t += stepSize` (:879) from vr_leap -- the exact bits of the chain of additions,
-//     without the chain.  Otherwise up to kQ samples go to the wave's queue.  Only samples that
-//     are certainly neither the last of their segment (:790) nor of the ray (:868) are handled in
-//     runs (a margin of two steps); the others take the reference's loop one sample at a time.
-//     Nothing in this stage depends on the running alpha: the inner loop can only be left through
-//     its condition with alpha < 0.98, so early ray termination is decided in stage C alone and
-//     at most kQ - 1 samples per ray are evaluated in vain.
-//  B  evaluation, one lane per queued sample: position from the owner ray's (cam, dir, offset)
-//     (ds_bpermute), density, transfer function, gradient + Blinn-Phong where the sample is lit,
-//     opacity correction -- the fp32 sequences of eval_batch, in another lane.
-//  C  compositing, one lane per ray: its results in order (:856, :865-879), ERT, end of ray.
-//
-// Rays come from the pre-pass's list with the DDA state reached there; a lane takes the next ray
-// when 4 * refill_min lanes of its wave are idle.  Exit condition reached by every wave: the list
-// head only grows and every ray ends.
-#ifndef VR_MARCH_Q
-#define VR_MARCH_Q 4
-#endif
-#ifndef VR_MARCH_MICRO
-#define VR_MARCH_MICRO 12
-#endif
-#ifndef VR_MARCH_FILL
-#define VR_MARCH_FILL 48
-#endif
-constexpr int kQ = VR_MARCH_Q;             // samples of a ray in flight per round (queue slots lane * kQ + j)
-constexpr int kMicro = VR_MARCH_MICRO;     // micro-steps of stage A per round, at most
-constexpr int kFill = VR_MARCH_FILL;       // stage A ends early once about this many samples are queued
-static_assert(64 * kQ <= 256, "slot ids travel as bytes");
-constexpr int kMarchWaveBytes = 64 * kQ * 4 + 64 * kQ * 16 + 64 * kQ + 64 * kQ * 2;   // t queue, results, slot map, list of opaque samples
-static_assert(kMarchWaveBytes % 16 == 0, "float4 units");
-
-template <typename VT, bool SKIP_LDS, bool FP>
-__global__ __launch_bounds__(kBlockDim) VR_OCC void vr_march_kernel(
-    VolView vv, BrickView bricks, TfView tf, SkipView skip, CellView cells, FrameView fr,
-    vrhip_camera_params cam, vrhip_rendering_params rp, vrhip_raycast_params rc)
-{
-    const uint32_t n_rays = *fr.live_count;   // written by the pre-pass (previous kernel on the stream)
-    if (n_rays == 0) return;
-    extern __shared__ float4 s_mem[];
-    // LDS: [results, 4 waves][t queue, 4 waves][slot map, 4 waves][opaque list, 4 waves][tff_n float4][skip words + 1]
-    const uint32_t wv = threadIdx.x >> 6;
-    float4 *s_res = s_mem + wv * (64 * kQ);
-    float *s_t = reinterpret_cast<float *>(s_mem + (kBlockDim / 64) * (64 * kQ)) + wv * (64 * kQ);
-    uint8_t *s_map = reinterpret_cast<uint8_t *>(s_mem + (kBlockDim / 64) * (64 * kQ) + (kBlockDim / 64) * (64 * kQ) / 4) +
-                     wv * (64 * kQ);
-    uint16_t *s_map2 = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(s_mem + (kBlockDim / 64) * (64 * kQ) +
-                                                                                (kBlockDim / 64) * (64 * kQ) / 4) +
-                                                    (kBlockDim / 64) * (64 * kQ)) + wv * (64 * kQ);
-    float4 *s_tff = s_mem + (kBlockDim / 64) * kMarchWaveBytes / 16;
-    uint32_t *s_skip = reinterpret_cast<uint32_t *>(s_tff + tf.tff_n);
-    for (uint32_t i = threadIdx.x; i < tf.tff_n; i += kBlockDim) s_tff[i] = tf.tff[i];
-    if (SKIP_LDS)
-        for (uint32_t i = threadIdx.x; i <= skip.n_words; i += kBlockDim) s_skip[i] = skip.bits[i];
-    __syncthreads();
-
-    const uint32_t lane = threadIdx.x & 63u;
-    const int tffn = (int)tf.tff_n;
-    const Vol<VT, 0, FP> vol = make_vol<VT, 0, FP>(vv, nullptr);
-    const f3 resf = mk3(vol.fw, vol.fh, vol.fd);
-    const f3 voxLen = mk3(1.f / vol.fw, 1.f / vol.fh, 1.f / vol.fd);
-    const float refInterval = 1.f / rc.samplingRate;
-    const Grid grid = make_grid(bricks, rc, skip.n_words, true);
-    const uint32_t *sb = SKIP_LDS ? s_skip : skip.bits;
-    const bool use_mask = cells.bmask != nullptr && rp.useLinear != 0;
-    const int sx = cells.bex - 2, sy = cells.bey - 2, sz = cells.bez - 2;   // log2 of the sub-block edge
-    const bool shade_mode = rp.illumType == 1;
-    const uint32_t kRefillLanes = (fr.refill_min ? fr.refill_min : 16u) * 4u;   // idle lanes before a refill
-    const uint32_t march_micro = fr.march_micro ? fr.march_micro : (uint32_t)kMicro;
-    const uint32_t march_fill = fr.march_fill ? fr.march_fill : (uint32_t)kFill;
-
-    unsigned long long n0 = 0, n1 = 0;
-#ifdef VR_MARCH_STATS
-    unsigned long long ms_acc[16] = {0};
-#endif
-    bool have = false, drained = false;
-    uint32_t gx = 0, gy = 0, out_index = 0;
-    // the empty words of the two bricks the ray has touched last (key = packed brick coordinates)
-    uint32_t key0 = 0xffffffffu, key1 = 0xffffffffu;
-    unsigned long long m0 = 0, m1 = 0;
-    float du = 0.f, dv = 0.f, ds = 0.f, inv_step = 0.f;   // texel increments per sample, 1 / stepSize
-    int run_left = 0;   // samples the ray still has in the (not empty) sub-block it was last classified in
-    RayCtx c;
-    RayDyn d;
-    setup_ray<true>(0u, 0u, false, fr, cam, rp, rc, resf, voxLen, grid, c, d, rp.seed);   // S_DONE
-
-    for (;;) {
-        // ---- retire finished rays, take new ones
-        {
-            const bool idle = d.state == S_DONE;
-            const unsigned long long idle_m = __ballot(idle);
-            const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle_m);
-            const bool all_idle = idle_m == ~0ull;
-            if ((!drained && n_idle >= kRefillLanes) || all_idle) {
-                if (idle && have) {
-                    write_pixel<false>(fr, rp, c, d, voxLen, gx, gy, (size_t)out_index);
-                    have = false;
-                }
-                if (!drained) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(fr.queue_head, n_idle);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if (base + n_idle >= n_rays) drained = true;
-                    if (idle) {
-                        const uint32_t ri = base + (uint32_t)__builtin_popcountll(idle_m & ((1ull << lane) - 1ull));
-                        have = ri < n_rays;
-                        if (have) {
-                            const ContRec rec = fr.live_rays[ri];
-                            gx = rec.pix & 0xffffu;
-                            gy = rec.pix >> 16;
-                            out_index = rec.out_index;
-                            const uint32_t frame_idx = (uint32_t)rec.state >> 8;
-                            setup_ray<true>(gx, gy, true, fr, cam, rp, rc, resf, voxLen, grid, c, d,
-                                            fr.seeds ? fr.seeds[frame_idx] : rp.seed);
-                            d.state = rec.state & 0xff;
-                            d.t = rec.t; d.t_exit = rec.t_exit; d.alpha = rec.alpha;
-                            d.r0 = rec.r0; d.r1 = rec.r1; d.r2 = rec.r2;
-                            d.c0 = rec.cx; d.c1 = rec.cy; d.c2 = rec.cz;
-                            d.tv0 = rec.tv0; d.tv1 = rec.tv1; d.tv2 = rec.tv2;
-                            fetch_skip_word(sb, grid, d);
-                            key0 = key1 = 0xffffffffu;
-                            run_left = 0;
-                            du = (c.dir.x * c.stepSize) * (0.5f * vol.fw);
-                            dv = (c.dir.y * c.stepSize) * (0.5f * vol.fh);
-                            ds = (c.dir.z * c.stepSize) * (0.5f * vol.fd);
-                            inv_step = 1.0f / c.stepSize;
-                        }
-                    }
-                }
-                if (!__ballot(d.state != S_DONE)) {
-                    if (drained) break;
-                    continue;
-                }
-            }
-        }
-
-        VR_MARK("A_begin");
-        VR_MS(0, 1);                                                       // rounds
-        VR_MS(1, __builtin_popcountll(__ballot(d.state != S_DONE)));       // live lanes, summed over rounds
-        // ---- stage A: stepping.  n = samples this ray has queued in this round
-        uint32_t n = 0, queued = 0;
-#pragma unroll 1
-        for (uint32_t iter = 0; iter < march_micro && queued < march_fill; ++iter) {
-            const bool in_brick = d.state == S_BRICK;
-            const bool stepping = d.state == S_SAMPLE && n < (uint32_t)kQ;
-            const bool any_brick = __ballot(in_brick) != 0ull, any_step = __ballot(stepping) != 0ull;
-            if (!any_brick && !any_step) break;
-            VR_MS(2, 1);                                                   // stage-A iterations
-            VR_MS(3, any_brick ? 1 : 0);                                   // ... that ran a DDA step
-            VR_MS(4, __builtin_popcountll(__ballot(in_brick)));            // lanes in it
-            VR_MS(5, any_step ? 1 : 0);                                    // ... that ran a sample micro-step
-            VR_MS(6, __builtin_popcountll(__ballot(stepping)));            // lanes in it
-            if (any_brick) dda_step<0>(sb, grid, c, d, n0, n1);   // (lanes that are not in a brick: no effect)
-            VR_MARK("A_dda_end");
-            if (any_step) {
-                const uint32_t n_before = n;
-                if (stepping) {
-                    if (!(d.t < d.t_exit)) {
-                        // the inner loop ends through its condition (:790): alpha < 0.98 here (an ERT break
-                        // would have ended the ray), so :882 is t >= tfar alone
-                        if (d.t >= c.tfar) d.state = S_DONE;                                             // :882
-                        else if (d.c0 == c.exit0 || d.c1 == c.exit1 || d.c2 == c.exit2) d.state = S_DONE;  // :883
-                        else { d.t = d.t_exit; d.state = S_BRICK; }                                     // :884
-                        run_left = 0;
-                    } else {
-                        // samples 0 .. safe - 1 from here certainly pass :790 and fail :868
-                        const int safe = (int)floorf((vmin(d.t_exit, c.tfar) - d.t) * inv_step) - 2;
-                        bool emit = run_left > 0;       // still inside a sub-block that is not empty
-                        if (!emit) {
-                            bool empty = false, miss = false;
-                            int run = kRunCap;
-                            if (use_mask) {
-                                // low-corner texel of this sample's fetch (:791-793, Vol::linear), good to a texel
-                                const f3 pos = add3(c.cam, scale3(c.dir, d.t - c.offset));
-                                const float ub = (pos.x * 0.5f + 0.5f) * vol.fw - 0.5f;
-                                const float vb = (pos.y * 0.5f + 0.5f) * vol.fh - 0.5f;
-                                const float wb = (pos.z * 0.5f + 0.5f) * vol.fd - 0.5f;
-                                const int x0 = iclamp((int)floorf(ub), 0, vol.w1);
-                                const int y0 = iclamp((int)floorf(vb), 0, vol.h1);
-                                const int z0 = iclamp((int)floorf(wb), 0, vol.d1);
-                                const uint32_t bx = (uint32_t)(x0 >> cells.bex), by = (uint32_t)(y0 >> cells.bey);
-                                const uint32_t bz = (uint32_t)(z0 >> cells.bez);
-                                const uint32_t key = bx | (by << 8) | (bz << 16);
-                                if (key == key0 || key == key1) {
-                                    const unsigned long long m = key == key0 ? m0 : m1;
-                                    const uint32_t bit = (uint32_t)((x0 >> sx) & 3) | ((uint32_t)((y0 >> sy) & 3) << 2) |
-                                                         ((uint32_t)((z0 >> sz) & 3) << 4);
-                                    empty = (m >> bit) & 1ull;
-                                    // all samples whose low-corner texel stays in this sub-block
-                                    run = min(min(run_axis(ub, du, (float)((x0 >> sx) << sx), (float)(((x0 >> sx) + 1) << sx)),
-                                                  run_axis(vb, dv, (float)((y0 >> sy) << sy), (float)(((y0 >> sy) + 1) << sy))),
-                                              run_axis(wb, ds, (float)((z0 >> sz) << sz), (float)(((z0 >> sz) + 1) << sz)));
-                                } else {
-                                    // the word of a brick this ray has not looked at lately: loaded now, used by
-                                    // this lane's next micro-step
-                                    miss = true;
-                                    key1 = key0; m1 = m0;
-                                    key0 = key;
-                                    m0 = cells.bmask[(bz * (uint32_t)grid.bh + by) * (uint32_t)grid.bw + bx];
-                                }
-                            }
-                            if (!miss) {
-                                if (!empty) { emit = true; run_left = run; }
-                                else if (safe >= 1) d.t = vr_leap(d.t, c.stepSize, (uint32_t)min(run, safe));
-                                else if (d.t >= c.tfar) d.state = S_DONE;         // :868 after a no-op :865-867
-                                else d.t = d.t + c.stepSize;                      // :879
-                            }
-                        }
-                        if (emit) {
-                            s_t[lane * kQ + n] = d.t;                             // evaluate this one
-                            ++n;
-                            --run_left;
-                            if (d.t >= c.tfar) d.state = S_DONE;                  // :868: the ray's last sample
-                            else {
-                                d.t = d.t + c.stepSize;                           // :879
-#pragma unroll
-                                for (int j = 1; j < kQ; ++j) {
-                                    // certainly in the segment and not the ray's last; beyond the sub-block's
-                                    // run the next micro-step classifies again
-                                    if (n < (uint32_t)kQ && j < safe && run_left > 0) {
-                                        s_t[lane * kQ + n] = d.t;
-                                        ++n;
-                                        --run_left;
-                                        d.t = d.t + c.stepSize;
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
-                queued += (uint32_t)__builtin_popcountll(__ballot(n != n_before));
-            }
-        }
-
-        VR_MARK("A_end");
-        // ---- dense list of this round's samples: j-major (sample j of every ray that has one)
-        uint32_t total = 0;
-#pragma unroll
-        for (int j = 0; j < kQ; ++j) {
-            const bool has = n > (uint32_t)j;
-            const unsigned long long m = __ballot(has);
-            if (has)
-                s_map[total + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
-                    (uint8_t)(lane * kQ + j);
-            total += (uint32_t)__builtin_popcountll(m);
-        }
-        VR_MS(7, total);                                                   // samples queued
-        VR_MS(8, (total + 63u) / 64u);                                     // stage-B passes
-        if (total == 0u) continue;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-
-        VR_MARK("B_begin");
-        // ---- stage B1: density and transfer function over the dense list (:791-808, one sample per
-        // lane); the samples with a non-zero opacity -- the only ones of which anything survives the
-        // compositing (op = 1 - powr(1, y) = 0 exactly otherwise) -- go to a second dense list
-        uint32_t total2 = 0;
-        for (uint32_t base = 0; base < total; base += 64u) {
-            const uint32_t e = base + lane;
-            const bool mine = e < total;
-            const uint32_t slot = mine ? (uint32_t)s_map[e] : lane * kQ;
-            const int owner = (int)(slot / kQ);
-            const float ts = mine ? s_t[slot] : 0.f;
-            // the owner ray's invariants (every lane takes part in the exchange)
-            const f3 ocam = mk3(__shfl(c.cam.x, owner, 64), __shfl(c.cam.y, owner, 64), __shfl(c.cam.z, owner, 64));
-            const f3 odir = mk3(__shfl(c.dir.x, owner, 64), __shfl(c.dir.y, owner, 64), __shfl(c.dir.z, owner, 64));
-            const float ooff = __shfl(c.offset, owner, 64);
-            const f3 pos = add3(ocam, scale3(odir, ts - ooff));                         // :791
-            const f3 pk = mk3(pos.x * 0.5f + 0.5f, pos.y * 0.5f + 0.5f, pos.z * 0.5f + 0.5f);   // :793
-            const float dens = rp.useLinear ? vol.linear(pk.x, pk.y, pk.z) : vol.nearest(pk.x, pk.y, pk.z);
-            const float4 tfc = tff_linear(s_tff, tffn, dens);                           // :808
-            const bool need = mine && tfc.w != 0.f;
-            const bool lit = need && shade_mode && tfc.w > 0.1f;                        // :809
-            if (mine) s_res[slot] = need ? tfc : make_float4(0.f, 0.f, 0.f, 0.f);
-            const unsigned long long m = __ballot(need);
-            if (need)
-                s_map2[total2 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
-                    (uint16_t)(slot | (lit ? 0x8000u : 0u));
-            total2 += (uint32_t)__builtin_popcountll(m);
-        }
-        VR_MS(10, total2);
-        VR_MS(11, (total2 + 63u) / 64u);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        VR_MARK("B2_begin");
-        // ---- stage B2: opacity correction, and gradient + Blinn-Phong where the sample is lit
-        // (:809-830, :864), over the list of opaque samples
-        for (uint32_t base = 0; base < total2; base += 64u) {
-            const uint32_t e = base + lane;
-            const bool mine = e < total2;
-            const uint32_t tag = mine ? (uint32_t)s_map2[e] : lane * kQ;
-            const uint32_t slot = tag & 0x7fffu;
-            const bool lit = mine && (tag & 0x8000u);
-            const int owner = (int)(slot / kQ);
-            float4 tfc = s_res[slot];
-            if (__ballot(lit)) {
-                const float ts = s_t[slot];
-                const f3 ocam = mk3(__shfl(c.cam.x, owner, 64), __shfl(c.cam.y, owner, 64), __shfl(c.cam.z, owner, 64));
-                const f3 odir = mk3(__shfl(c.dir.x, owner, 64), __shfl(c.dir.y, owner, 64), __shfl(c.dir.z, owner, 64));
-                const float ooff = __shfl(c.offset, owner, 64);
-                const f3 lgt = mk3(__shfl(c.lgt.x, owner, 64), __shfl(c.lgt.y, owner, 64), __shfl(c.lgt.z, owner, 64));
-                const f3 hv = mk3(__shfl(c.hv.x, owner, 64), __shfl(c.hv.y, owner, 64), __shfl(c.hv.z, owner, 64));
-                const int hvalid = __shfl(c.hvalid ? 1 : 0, owner, 64);
-                if (lit) {
-                    const f3 pos = add3(ocam, scale3(odir, ts - ooff));
-                    const f3 pk = mk3(pos.x * 0.5f + 0.5f, pos.y * 0.5f + 0.5f, pos.z * 0.5f + 0.5f);
-                    const f3 g = vol.neg_gradient(pk.x, pk.y, pk.z);                    // :814
-                    const float ndl = vmax(0.f, dot3(g, lgt));                          // :294-303, :280-291
-                    float sp = hvalid ? vr_powr(vmax(dot3(g, hv), 0.f), 40.f) : 0.0f;
-                    sp = sp * 0.15f;
-                    tfc.x = ((tfc.x * 0.15f) + ((tfc.x * ndl) * 0.7f)) + sp;
-                    tfc.y = ((tfc.y * 0.15f) + ((tfc.y * ndl) * 0.7f)) + sp;
-                    tfc.z = ((tfc.z * 0.15f) + ((tfc.z * ndl) * 0.7f)) + sp;
-                }
-            }
-            if (mine) {
-                tfc.w = 1.f - vr_powr(1.f - tfc.w, refInterval);                        // :864
-                s_res[slot] = tfc;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-
-        VR_MARK("C_begin");
-        // ---- stage C: compositing, in ray order (:856, :865-879)
-        {
-            bool alive = true;
-#pragma unroll
-            for (int j = 0; j < kQ; ++j) {
-                if (alive && n > (uint32_t)j) {
-                    const float4 r = s_res[lane * kQ + j];
-                    const float q0 = (c.env0 - r.x) * r.w, q1 = (c.env1 - r.y) * r.w, q2 = (c.env2 - r.z) * r.w;
-                    const float oma = 1.f - d.alpha;
-                    d.r0 = d.r0 - q0 * oma;
-                    d.r1 = d.r1 - q1 * oma;
-                    d.r2 = d.r2 - q2 * oma;
-                    d.alpha = d.alpha + r.w * oma;
-                    // (double)alpha > 0.98 <=> alpha >= 0.98f (ERT_THRESHOLD, :28): the ray ends here,
-                    // whatever stage A has queued behind this sample
-                    if (d.alpha >= 0.98f) { d.state = S_DONE; alive = false; VR_MS(9, n - 1u - (uint32_t)j); }   // evaluated in vain
-                }
-            }
-        }
-    }
-#ifdef VR_MARCH_STATS
-    if (lane == 0)
-        for (int i = 0; i < 12; ++i)
-            if (i != 9) atomicAdd(&g_march_stats[i], ms_acc[i]);
-    {
-        unsigned long long w = wave_sum(ms_acc[9]);
-        if (lane == 0) atomicAdd(&g_march_stats[9], w);
     }
 #endif
 }
@@ -1994,166 +1517,6 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_kernel(
     }
 }
 
-// ------------------------------------------------------------------ LDS brick staging (experiment)
-
-// north_star names "the 3-D scalar field staged as LDS bricks for coalesced HBM reads".  This is
-// that mechanism, built to be measured against the production path ("LDS staging"):
-// the patch kernel (one wave = one 8x8 patch, whose rays stay together), single phase, UCHAR,
-// default modes.  Before every evaluation batch the wave takes the box of voxels the batch's
-// fetches can touch; when it is not inside the staged box any more, the wave re-stages
-// kStageEdge^3 voxels ((kStageEdge / 4)^3 micro-bricks = whole 64-byte lines, loaded with 16-byte
-// accesses) positioned so that the rays have the most room ahead, and the batch reads its voxels
-// from LDS.  LS = false: the same kernel without the staging (the A/B's other arm).
-template <bool LS>
-__global__ __launch_bounds__(kBlockDim) void vr_raycast_staged_kernel(
-    VolView vv, BrickView bricks, TfView tf, SkipView skip, CellView cells, FrameView fr,
-    vrhip_camera_params cam, vrhip_rendering_params rp, vrhip_raycast_params rc)
-{
-    typedef uint8_t VT;
-    VR_ZERO_NEXT_CTRL(fr);
-    extern __shared__ float4 s_mem[];
-    // LDS: [gradient staging, 4 waves][tff_n float4][boxes, 4 waves]
-    float *s_stage = reinterpret_cast<float *>(s_mem) + (threadIdx.x >> 6) * kStageFloatsPerWave;
-    float4 *s_tff = s_mem + kStageF4;
-    constexpr int kBoxBytes = (kStageEdge * kStageEdge * kStageEdge + 15) / 16 * 16;
-    uint8_t *s_box = reinterpret_cast<uint8_t *>(s_tff + tf.tff_n) + (threadIdx.x >> 6) * kBoxBytes;
-    for (uint32_t i = threadIdx.x; i < tf.tff_n; i += kBlockDim) s_tff[i] = tf.tff[i];
-    __syncthreads();
-
-    const uint32_t lane = threadIdx.x & 63u;
-    const int tffn = (int)tf.tff_n;
-    Vol<VT, 0, false, LS> vol = make_vol<VT, 0, false, LS>(vv, nullptr);
-    vol.lds = (const __attribute__((address_space(3))) VT *)s_box;
-    const f3 resf = mk3(vol.fw, vol.fh, vol.fd);
-    const f3 voxLen = mk3(1.f / vol.fw, 1.f / vol.fh, 1.f / vol.fd);
-    const float refInterval = 1.f / rc.samplingRate;
-    const Grid grid = make_grid(bricks, rc, skip.n_words, true);
-    const uint32_t *sb = skip.bits;
-    const bool skip_empty = cells.empty != nullptr && rp.useLinear != 0;
-    unsigned long long n0 = 0, n1 = 0;
-
-    uint32_t q_next = 0;
-    if (lane == 0) q_next = atomicAdd(fr.queue_head, 1u);
-    for (;;) {
-        const uint32_t q = __builtin_amdgcn_readfirstlane(q_next);
-        if (q >= fr.n_wave_tiles) break;
-        const WaveTile wt = fr.queue[q];
-        if (lane == 0) q_next = atomicAdd(fr.queue_head, 1u);
-        const uint32_t lx = lane & 7u, ly = lane >> 3;
-        const uint32_t gx = wt_col(wt) * 8u + lx, gy = wt_row(wt) * 8u + ly;
-        const uint32_t seed = fr.seeds ? fr.seeds[wt_frame(wt)] : rp.seed;
-        const bool inside = gx < fr.W && gy < fr.H;
-        RayCtx c;
-        RayDyn d;
-        setup_ray<true>(gx, gy, inside, fr, cam, rp, rc, resf, voxLen, grid, c, d, seed);
-        fetch_skip_word(sb, grid, d);
-        vol.staged = false;
-        bool guess_empty = true;
-        for (;;) {
-            for (int it = 0;; ++it) {
-                if (!__ballot(d.state == S_BRICK)) break;
-                if (it >= kMaxBrickSteps && __ballot(d.state == S_SAMPLE)) break;
-                dda_step<0>(sb, grid, c, d, n0, n1);
-            }
-            if (!__ballot(d.state != S_DONE)) break;
-            bool more_empty = false;
-            if (skip_empty && lookahead_pays(d.state == S_SAMPLE, guess_empty)) {
-                if (d.state == S_SAMPLE) {
-                    const uint32_t em = empty_mask<VT, 0, kLook1>(cells, vol, c, d.t);
-                    more_empty = skip_empty_run(em, c, d, false, n0);
-                    guess_empty = (em & 1u) != 0u;
-                    after_segment<true>(c, d);
-                }
-            }
-            const bool evalr = d.state == S_SAMPLE && !more_empty;
-            if (LS && __ballot(evalr)) {
-                // box of the low-corner texels of the batch's fetches (the ray is straight: its two end
-                // samples bound the others), widened by the gradient's taps (-1 .. +2)
-                int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-(1 << 30), -(1 << 30), -(1 << 30)};
-                if (evalr) {
-                    for (int e = 0; e < 2; ++e) {
-                        const float te = e ? d.t + (float)(kBatch - 1) * c.stepSize : d.t;
-                        const f3 pos = add3(c.cam, scale3(c.dir, te - c.offset));
-                        const int t3[3] = {iclamp((int)floorf((pos.x * 0.5f + 0.5f) * vol.fw - 0.5f), 0, vol.w1),
-                                           iclamp((int)floorf((pos.y * 0.5f + 0.5f) * vol.fh - 0.5f), 0, vol.h1),
-                                           iclamp((int)floorf((pos.z * 0.5f + 0.5f) * vol.fd - 0.5f), 0, vol.d1)};
-                        for (int i = 0; i < 3; ++i) { lo[i] = min(lo[i], t3[i] - 2); hi[i] = max(hi[i], t3[i] + 3); }
-                    }
-                }
-                for (int i = 0; i < 3; ++i)
-                    for (int off = 32; off > 0; off >>= 1) {
-                        lo[i] = min(lo[i], __shfl_xor(lo[i], off, 64));
-                        hi[i] = max(hi[i], __shfl_xor(hi[i], off, 64));
-                    }
-                const int o3[3] = {vol.ox, vol.oy, vol.oz};
-                bool covered = vol.staged, fits = true;
-                for (int i = 0; i < 3; ++i) {
-                    covered = covered && lo[i] >= o3[i] && hi[i] < o3[i] + kStageEdge;
-                    fits = fits && hi[i] - lo[i] < kStageEdge - 3;
-                }
-                if (!covered) {
-                    vol.staged = false;
-                    if (fits) {
-                        // room ahead: the box starts at the batch's near side along the way the rays go
-                        const int m = (int)__builtin_ctzll(__ballot(evalr));
-                        const float dm[3] = {__shfl(c.dir.x, m, 64), __shfl(c.dir.y, m, 64), __shfl(c.dir.z, m, 64)};
-                        int o[3];
-                        for (int i = 0; i < 3; ++i) {
-                            o[i] = dm[i] >= 0.f ? (lo[i] & ~3) : ((hi[i] - kStageEdge + 4) & ~3);
-                            o[i] = max(o[i], -4);
-                        }
-                        constexpr int nb = kStageEdge / 4;
-                        const VT *gp = (const VT *)vv.data;
-                        __builtin_amdgcn_wave_barrier();
-                        for (int b = (int)lane; b < nb * nb * nb; b += 64) {
-                            const int bxi = b % nb, byi = (b / nb) % nb, bzi = b / (nb * nb);
-                            const int mx = (o[0] >> 2) + bxi, my = (o[1] >> 2) + byi, mz = (o[2] >> 2) + bzi;
-                            if (mx < 0 || my < 0 || mz < 0 || mx >= (int)vv.nbx || my >= (int)vv.nby || mz >= (int)vv.nbz)
-                                continue;   // outside the volume: never read (fetch indices are clamped into it)
-                            const uint4 *line = reinterpret_cast<const uint4 *>(
-                                gp + ((unsigned long long)mz * vv.zstride + (unsigned long long)my * vv.ystride +
-                                      (unsigned long long)mx * 64ull));
-#pragma unroll
-                            for (int zz = 0; zz < 4; ++zz) {
-                                const uint4 v = line[zz];   // one z slice of the micro-brick: 4 rows of 4 voxels
-                                uint8_t *row = s_box + ((bzi * 4 + zz) * kStageEdge + byi * 4) * kStageEdge + bxi * 4;
-                                *reinterpret_cast<uint32_t *>(row) = v.x;
-                                *reinterpret_cast<uint32_t *>(row + kStageEdge) = v.y;
-                                *reinterpret_cast<uint32_t *>(row + 2 * kStageEdge) = v.z;
-                                *reinterpret_cast<uint32_t *>(row + 3 * kStageEdge) = v.w;
-                            }
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        vol.ox = o[0]; vol.oy = o[1]; vol.oz = o[2];
-                        vol.staged = true;
-                    }
-                }
-            }
-            if (evalr) {
-                float tk[kBatch];
-                bool vk[kBatch], litk[kBatch];
-                tk[0] = d.t;
-                vk[0] = d.t < d.t_exit;
-#pragma unroll
-                for (int k = 1; k < kBatch; ++k) {
-                    tk[k] = tk[k - 1] + c.stepSize;
-                    vk[k] = vk[k - 1] && !(tk[k - 1] >= c.tfar) && (tk[k] < d.t_exit);
-                }
-                float p0[kBatch], p1[kBatch], p2[kBatch], opk[kBatch];
-                eval_batch<VT, 0, false, false>(vol, s_tff, tffn, s_stage, c, rp, rc, refInterval, tk, vk, p0, p1, p2,
-                                                opk, litk);
-#pragma unroll
-                for (int k = 0; k < kBatch; ++k)
-                    if (vk[k] && d.state == S_SAMPLE) composite(c, d, p0[k], p1[k], p2[k], opk[k], tk[k]);
-                if (vk[kBatch - 1]) guess_empty = opk[kBatch - 1] == 0.f;
-                after_segment<true>(c, d);
-            }
-        }
-        if (inside) write_pixel<false>(fr, rp, c, d, voxLen, gx, gy, (size_t)wt.out_base + (size_t)ly * fr.out_stride + lx);
-    }
-}
-
 // ------------------------------------------------------------------ phase 2
 
 // composite the kBatch samples evaluated by lane O of every quad, in order
@@ -2214,15 +1577,14 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
     const uint32_t *sb = SKIP_LDS ? s_skip : skip.bits;
     const bool skip_empty = INSTR != 2 && cells.empty != nullptr && rp.useLinear != 0 &&
                             !(XS && rp.illumType == 4);
-    // (opt-in, VRHIP_MARCH_MICRO = leap steps per round: measured no faster than the lookahead below)
-#ifdef VR_LEAP_STEPPING   // diagnostic build; VRHIP_MARCH_MICRO = leap steps per round
+#ifdef VR_LEAP   // A/B build (VR_EXPERIMENTS + VR_LEAP_STEPPING); VRHIP_MARCH_MICRO = leap steps per round
     const bool use_mask = skip_empty && cells.bmask != nullptr && fr.march_micro != 0;
-#else   // (kept out of the default build: its registers cost the two-phase kernels 2.5 % of the frame)
-    const bool use_mask = false;
-#endif
     const uint32_t leap_iters = fr.march_micro;
+#endif
+#ifdef VR_LEAP
     LeapCache lc;
     lc.key0 = lc.key1 = 0xffffffffu; lc.m0 = lc.m1 = 0ull; lc.du = lc.dv = lc.ds = lc.inv_step = 0.f;
+#endif
     // Rays are handed out one by one from the sorted list: when `refill_min` ray slots (quads) of
     // the wave are idle they retire their rays and take the next ones (their set-up runs
     // together).  With the default, 16, a wave refills when all its rays are done, but draws as
@@ -2293,7 +1655,9 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
                             my_rounds = 0;
                             guess_empty = true;
                             cool = 0;
+#ifdef VR_LEAP
                             leap_reset(lc, c, vol.fw, vol.fh, vol.fd);
+#endif
                         }
                     }
                 }
@@ -2330,6 +1694,7 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
             if (my_rounds >= VR_CAP_ROUNDS) d.state = S_DONE;
 #endif
             bool more_empty = false;
+#ifdef VR_LEAP
             if (use_mask) {
                 // (the four lanes of a ray hold the same state and cache and take the same steps)
                 bool ready = false;
@@ -2343,7 +1708,9 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
                     }
                 }
                 more_empty = !ready;
-            } else if (skip_empty && lookahead_pays(d.state == S_SAMPLE, guess_empty)) {
+            } else
+#endif
+            if (skip_empty && lookahead_pays(d.state == S_SAMPLE, guess_empty)) {
                 if (d.state == S_SAMPLE) {
                     // the four lanes of a ray hold the same state and take the same decisions;
                     // lane `slot` looks at samples [kLook2 * slot, kLook2 * (slot + 1)) of the run
@@ -2566,6 +1933,11 @@ hipError_t prepare_variant(K kernel, size_t lds, int *nb_out, const char *what, 
     return vr_prepare_kernel(kernel, kBlockDim, lds, nb_out, what, num_cus);
 }
 
+#ifdef VR_EXPERIMENTS   // vr_march_kernel, vr_raycast_staged_kernel and their launchers: A/B builds only
+#include "vr_experiments_kernels.inc"
+#endif
+
+
 template <typename VT, bool ESS, int INSTR, bool SKIP_LDS, bool XS, bool FP = false>
 hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
 {
@@ -2605,21 +1977,11 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
         frame.live = nullptr;
     }
     hipError_t e;
+#ifdef VR_EXPERIMENTS
     if (ESS && INSTR == 0 && !XS && frame.live && frame.live_rays && frame.march && !a.raycast.contours &&
-        !a.raycast.aerial) {
-        // the decoupled march on the pre-pass's ray list: the whole frame in this one launch
-        auto km = vr_march_kernel<VT, SKIP_LDS, FP>;
-        size_t ldsm = (size_t)(kBlockDim / 64) * kMarchWaveBytes + (size_t)a.tf.tff_n * sizeof(float4);
-        if (SKIP_LDS) ldsm += ((size_t)a.skip.n_words + 1) * sizeof(uint32_t);
-        int nbm = 0;
-        e = prepare_variant(km, ldsm, &nbm, "raycast march", a.num_cus);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(km, dim3(cus * (uint32_t)nbm), block, ldsm, stream, a.vol, a.bricks, a.tf, a.skip,
-                           a.cells, frame, a.cam, a.render, a.raycast);
-        e = hipGetLastError();
-        if (e == hipSuccess && a.mid_event) e = hipEventRecord(a.mid_event, stream);
-        return e;
-    }
+        !a.raycast.aerial)
+        return launch_march<VT, SKIP_LDS, FP>(a, frame, block, cus, stream);   // the whole frame in one launch
+#endif
     if (ESS && INSTR == 0 && !XS && frame.live && frame.live_rays) {   // phase 1 on the ray list
         auto kr = vr_raycast_rays_kernel<VT, SKIP_LDS, FP>;
         int nbr = 0;
@@ -2650,31 +2012,6 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
     return hipGetLastError();
 }
 
-// LDS brick staging experiment (FrameView::lds_stage: 1 = staged, 2 = the same kernel without staging)
-hipError_t launch_staged(const RaycastLaunch &a, hipStream_t stream)
-{
-    constexpr size_t box = (size_t)(kStageEdge * kStageEdge * kStageEdge + 15) / 16 * 16;
-    const size_t lds = (size_t)kStageF4 * sizeof(float4) + (size_t)a.tf.tff_n * sizeof(float4) + (kBlockDim / 64) * box;
-    const uint32_t cus = (uint32_t)(a.num_cus > 0 ? a.num_cus : 256);
-    const uint32_t want = (a.frame.n_wave_tiles + 3u) / 4u;
-    int nb = 0;
-    hipError_t e;
-    if (a.frame.lds_stage == 1) {
-        e = prepare_variant(vr_raycast_staged_kernel<true>, lds, &nb, "raycast staged (LDS boxes)", a.num_cus);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(vr_raycast_staged_kernel<true>, dim3(std::min(want, cus * (uint32_t)nb)), dim3(kBlockDim), lds,
-                           stream, a.vol, a.bricks, a.tf, a.skip, a.cells, a.frame, a.cam, a.render, a.raycast);
-    } else {
-        e = prepare_variant(vr_raycast_staged_kernel<false>, lds, &nb, "raycast staged (off)", a.num_cus);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(vr_raycast_staged_kernel<false>, dim3(std::min(want, cus * (uint32_t)nb)), dim3(kBlockDim), lds,
-                           stream, a.vol, a.bricks, a.tf, a.skip, a.cells, a.frame, a.cam, a.render, a.raycast);
-    }
-    e = hipGetLastError();
-    if (e == hipSuccess && a.mid_event) e = hipEventRecord(a.mid_event, stream);
-    return e;
-}
-
 template <typename VT>
 hipError_t launch_typed(const RaycastLaunch &a, hipStream_t stream)
 {
@@ -2684,9 +2021,11 @@ hipError_t launch_typed(const RaycastLaunch &a, hipStream_t stream)
     const bool xs = a.render.illumType >= 2 || a.raycast.useAO != 0 || a.render.showEss != 0 ||
                     a.render.imgEss != 0 || a.vol.channels > 1 || a.raycast.contours != 0 ||
                     a.raycast.aerial != 0 || a.render.useLinear == 0;
+#ifdef VR_EXPERIMENTS
     if (a.frame.lds_stage && !xs && a.instr == 0 && a.use_ess && sizeof(VT) == 1 && !a.raycast.contours &&
         !a.raycast.aerial && a.frame.n_wave_tiles)
         return launch_staged(a, stream);
+#endif
     // the default kernels read the footprint volume when the host has provided one for this frame
     if (!xs && a.instr == 0 && a.vol.fp) {
         if (!a.use_ess) return launch_variant<VT, false, 0, false, false, true>(a, stream);
@@ -2842,4 +2181,14 @@ hipError_t vr_launch_skipmap(const BrickView &bricks, int format, float inv_max,
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
+}
+
+// 1 when this library was built with the opt-in experiment kernels (VRHIP_MARCH, VRHIP_LDS_STAGE, VRHIP_MARCH_MICRO)
+int vr_experiments_built()
+{
+#ifdef VR_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
 }

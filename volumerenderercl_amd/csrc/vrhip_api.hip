@@ -1092,6 +1092,14 @@ int vrhip_create(int device_id, vrhip_renderer **out)
         return fail(nullptr, VRHIP_ERR_HIP, msg);
     }
     r->stream = r->own_stream;
+    // the opt-in experiment kernels exist in A/B builds only (tools/mkvariant.sh NAME -DVR_EXPERIMENTS): asking
+    // the product library for them fails loudly instead of silently rendering with the default kernels
+    if (!vr_experiments_built() && (getenv("VRHIP_MARCH") || getenv("VRHIP_LDS_STAGE") || getenv("VRHIP_MARCH_MICRO"))) {
+        vrhip_destroy(r);
+        return fail(nullptr, VRHIP_ERR_UNSUPPORTED,
+                    "VRHIP_MARCH / VRHIP_LDS_STAGE / VRHIP_MARCH_MICRO need a library built with -DVR_EXPERIMENTS "
+                    "(tools/mkvariant.sh experiments -DVR_EXPERIMENTS; VRHIP_LIB_PATH selects it)");
+    }
     if (const char *b = getenv("VRHIP_ROUND_BUDGET")) r->round_budget = (uint32_t)atoi(b);   // tuning
     if (getenv("VRHIP_NO_PREPASS")) r->prepass = false;        // experiments: phase 1 walks every patch
     if (getenv("VRHIP_NO_RAYLIST")) r->ray_list = false;       // experiments: phase 1 on live patches
