@@ -136,6 +136,12 @@ struct FrameView {
     // alternates between two blocks, and the first kernel of a set zeroes the other block -- nothing else
     // touches it until the next set starts -- instead of a memset launch per frame.  nullptr: nothing to zero
     uint32_t *next_ctrl;
+    // Patch classes (vr_patch_class_kernel, once per camera / transfer function / tile set, not per frame):
+    // class 1 = whatever the jitter, every ray of the patch hits the box and none can meet a brick that is
+    // not skipped, and the background is one colour -- the pre-pass writes 64 times (background, alpha 0)
+    // for it without setting up a single ray.  patch_class[q / set_frames] for work item q; nullptr: off
+    const uint8_t *patch_class;
+    uint32_t set_frames;
     float4 *fb;            // W*H frame / accumulate buffer (always written)
     float4 *out;           // optional second destination (device), frame or tile layout
     // Two-phase march: rays still alive after `round_budget` sample rounds of phase 1 (0 =
@@ -245,6 +251,10 @@ struct RaycastLaunch {
 };
 
 hipError_t vr_launch_raycast(const RaycastLaunch &a, hipStream_t stream);
+// FrameView::patch_class for the n_patches patches of a set of set_frames frames (work item p * set_frames = patch
+// p of frame 0); the launch's camera, parameters, skip bitmaps and queue must be those of the frames to come
+hipError_t vr_launch_patch_classes(const RaycastLaunch &a, uint32_t n_patches, uint32_t set_frames, uint8_t *cls,
+                                   hipStream_t stream);
 // 1 when vr_raycast.hip was built with the opt-in experiment kernels (-DVR_EXPERIMENTS: A/B builds only)
 int vr_experiments_built();
 // fills the footprint volume vol.fp of `vol`: (w+1)(h+1)(d+1) entries rounded up to

@@ -1027,6 +1027,74 @@ VR_DEV bool patch_is_clear(const SkipView &skip, const Grid &g, const RayCtx &c,
 // bitmap is read through the caches).  One wave per 8x8 patch, same set-up and dda_step as the
 // march, hence the same decisions.  Rays that end without a sample write their pixel here;
 // patches with rays that reach a brick to sample go to the `live` list for phase 1.
+// Patch classes: one wave per 8x8 patch, ONCE per camera / parameters / skip bitmap / tile set -- the frames of
+// a set, and the frames after it while nothing changes, differ only in the jitter seed, which moves every
+// ray by less than a pixel (:625-628).  The wave sets up 64 rays WITHOUT jitter on a regular grid over the
+// patch grown by two pixels on every side ([8 tx - 2, 8 tx + 10) x [8 ty - 2, 8 ty + 10)): the jittered rays
+// of the patch's pixels, in any frame, lie inside the hull of these.  Class 1 when
+//  * all 64 hull rays hit the box SHRUNK by a thousandth of its size (rays through a convex box from one
+//    eye point -- or parallel rays -- form a convex set, so every ray inside the hull hits the shrunk box,
+//    and the real box by a margin far above the slab test's rounding): c.valid holds for every ray;
+//  * patch_is_clear holds for the hull rays (its tube bounds |cam - cam_r| + t |dir - dir_r| by the maximum
+//    over the 64 rays: the hull's corners, one pixel outside anything a jittered ray can reach) -- no ray of
+//    the patch can visit a brick that is not skipped;
+//  * the patch lies inside the frame, and the background is one colour (no gradient, no environment map:
+//    checked by the host, with iteration 0, no showEss, no image-order ESS).
+// Then every pixel of the patch ends as (backgroundColor.rgb, alpha 0) -- setup_ray_head's start values through
+// write_pixel -- in every frame: the pre-pass writes that and returns, ~30 instructions instead of ~800.
+__global__ __launch_bounds__(kBlockDim) void vr_patch_class_kernel(SkipView skip, FrameView fr, vrhip_camera_params cam,
+                                                                   vrhip_rendering_params rp, Grid grid,
+                                                                   uint32_t n_patches, uint32_t set_frames, uint8_t *cls)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t pi = blockIdx.x * (kBlockDim / 64) + (threadIdx.x >> 6);
+    if (pi >= n_patches) return;
+    const WaveTile wt = fr.queue[(size_t)pi * set_frames];
+    const float fx = (float)(wt_col(wt) * 8u) - 2.f + (float)(lane & 7u) * (12.f / 7.f);
+    const float fy = (float)(wt_row(wt) * 8u) - 2.f + (float)(lane >> 3) * (12.f / 7.f);
+    // make_ray's geometry (:614-650) at a fractional pixel position, no jitter
+    const float *V = cam.viewMat;
+    const f3 ms = mk3(rp.modelScale[0], rp.modelScale[1], rp.modelScale[2]);
+    const int maxImg = (int)(fr.gsx > fr.gsy ? fr.gsx : fr.gsy);
+    float icx = (fx / (float)maxImg) * 2.f, icy = (fy / (float)maxImg) * 2.f;
+    if (fr.gsx > fr.gsy) { icx -= 1.0f; icy -= fr.ray_aspect; }
+    else { icx -= fr.ray_aspect; icy -= 1.0f; }
+    icy *= -1.f;
+    f3 npp = mk3(icx, icy, -1.0f);
+    f3 rayDir = mk3(dot3(mk3(V[0], V[1], V[2]), npp), dot3(mk3(V[4], V[5], V[6]), npp), dot3(mk3(V[8], V[9], V[10]), npp));
+    f3 camPos = mul3(mk3(V[3], V[7], V[11]), ms);
+    if (cam.ortho) {
+        camPos = mk3(V[3], V[7], V[11]);
+        rayDir = neg3(mk3(V[2], V[6], V[10]));
+        npp = add3(add3(camPos, scale3(mk3(V[0], V[4], V[8]), icx)), scale3(mk3(V[1], V[5], V[9]), icy));
+        npp = scale3(npp, len3(camPos));
+        camPos = mul3(npp, ms);
+    }
+    rayDir = normalize3(mul3(rayDir, ms));
+    const float o[3] = {camPos.x, camPos.y, camPos.z}, dv[3] = {rayDir.x, rayDir.y, rayDir.z};
+    float tn = -3.0e38f, tf = 3.0e38f, tns = -3.0e38f, tfs = 3.0e38f;
+    for (int i = 0; i < 3; ++i) {
+        const float inv = 1.0f / dv[i];
+        const float m = 1.0e-3f * (cam.bbox_tr[i] - cam.bbox_bl[i]);
+        const float tb = inv * (cam.bbox_bl[i] - o[i]), tt = inv * (cam.bbox_tr[i] - o[i]);
+        const float tbs = inv * (cam.bbox_bl[i] + m - o[i]), tts = inv * (cam.bbox_tr[i] - m - o[i]);
+        tn = vmax(tn, vmin(tt, tb)); tf = vmin(tf, vmax(tt, tb));
+        tns = vmax(tns, vmin(tts, tbs)); tfs = vmin(tfs, vmax(tts, tbs));
+    }
+    const bool hit_shrunk = (tfs > tns) && !(tfs < 0.f) && (tfs - tns) > 0.f;
+    RayCtx c;
+    c.cam = camPos;
+    c.dir = rayDir;
+    c.valid = (tf > tn) && !(tf < 0.f);
+    c.tnear = vmax(0.f, tn);
+    c.tfar = tf;
+    const bool inside = wt_col(wt) * 8u + 8u <= fr.W && wt_row(wt) * 8u + 8u <= fr.H;   // (uniform)
+    const bool all_hit = __ballot(hit_shrunk) == ~0ull;
+    bool clear = false;
+    if (inside && all_hit && skip.near_bits) clear = patch_is_clear(skip, grid, c, lane);
+    if (lane == 0) cls[pi] = clear ? 1 : 0;
+}
+
 template <typename VT>
 __global__ __launch_bounds__(kBlockDim) void vr_dda_prepass_kernel(
     VolView vv, BrickView bricks, SkipView skip, FrameView fr, vrhip_camera_params cam,
@@ -1042,6 +1110,15 @@ __global__ __launch_bounds__(kBlockDim) void vr_dda_prepass_kernel(
     const WaveTile wt = fr.queue[q];
     const uint32_t lx = lane & 7u, ly = lane >> 3;
     const uint32_t gx = wt_col(wt) * 8u + lx, gy = wt_row(wt) * 8u + ly;
+    const size_t out_index = (size_t)wt.out_base + (size_t)ly * fr.out_stride + lx;
+    if (fr.patch_class && fr.patch_class[q / fr.set_frames]) {
+        // class 1 (vr_patch_class_kernel): every ray of this patch -- in any frame of the set -- hits the box,
+        // meets no brick to sample, and the background is one colour: what the walk would leave, without a ray
+        const float4 o = make_float4(rp.backgroundColor[0], rp.backgroundColor[1], rp.backgroundColor[2], 0.f);
+        fr.fb[(size_t)gy * fr.W + gx] = o;
+        if (fr.out) fr.out[out_index] = o;
+        return;
+    }
     const uint32_t seed = fr.seeds ? fr.seeds[wt_frame(wt)] : rp.seed;
     const bool inside = gx < fr.W && gy < fr.H;
     const f3 resf = mk3(vv.fw, vv.fh, vv.fd);
@@ -1049,7 +1126,6 @@ __global__ __launch_bounds__(kBlockDim) void vr_dda_prepass_kernel(
     RayDyn d;
     float rnd;
     setup_ray_head<false>(gx, gy, inside, fr, cam, rp, c, d, seed, rnd);   // (nothing is shaded here)
-    const size_t out_index = (size_t)wt.out_base + (size_t)ly * fr.out_stride + lx;
     if (rp.imgEss && image_ess_patch(fr, rp, c, wt, lane, inside, gx, gy, out_index)) return;
     if (skip.near_bits && patch_is_clear(skip, grid, c, lane)) {
         // no ray of this patch can meet a brick that is not skipped: what the walk would leave
@@ -2180,6 +2256,22 @@ hipError_t vr_launch_skipmap(const BrickView &bricks, int format, float inv_max,
         break;
     default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+hipError_t vr_launch_patch_classes(const RaycastLaunch &a, uint32_t n_patches, uint32_t set_frames, uint8_t *cls,
+                                   hipStream_t stream)
+{
+    if (!n_patches) return hipSuccess;
+    Grid hg;   // (as in launch_variant: what make_grid gives on the device)
+    hg.bw = a.bricks.bw; hg.bh = a.bricks.bh; hg.bd = a.bricks.bd;
+    hg.oob_word = a.skip.n_words;
+    hg.bl0 = 1.f / a.raycast.brickRes[0];
+    hg.bl1 = 1.f / a.raycast.brickRes[1];
+    hg.bl2 = 1.f / a.raycast.brickRes[2];
+    hg.brickDia = sqrtf(((hg.bl0 * hg.bl0) + (hg.bl1 * hg.bl1)) + (hg.bl2 * hg.bl2)) * 2.f;
+    hipLaunchKernelGGL(vr_patch_class_kernel, dim3((n_patches + 3u) / 4u), dim3(kBlockDim), 0, stream, a.skip, a.frame,
+                       a.cam, a.render, hg, n_patches, set_frames, cls);
     return hipGetLastError();
 }
 

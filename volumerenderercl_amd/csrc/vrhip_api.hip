@@ -100,6 +100,13 @@ struct vrhip_renderer {
     uint32_t queue_n = 0, queue_cap = 0;
     uint32_t *queue_head = nullptr;   // 2 x kControlWords (queue head, cont count, cont head, pad, sort bins + cursors):
                                       // the sets of launches alternate between the two blocks (FrameView::next_ctrl)
+    uint8_t *patch_class = nullptr;   // FrameView::patch_class of the current queue, camera, parameters and skip bitmaps
+    size_t patch_class_cap = 0;
+    std::vector<uint8_t> patch_class_key;   // what the classes were computed for (empty: nothing valid)
+    uint32_t skip_version = 0;        // bumped whenever the skip bitmaps are rebuilt
+    uint32_t queue_version = 0;       // bumped whenever the work queue is rebuilt
+    uint32_t queue_frames = 1;        // frames per set of the current queue
+    bool use_patch_classes = true;    // VRHIP_NO_PATCH_CLASS=1 disables
     uint32_t ctrl_sel = 0;            // the block the next set of launches uses
     bool ctrl_clean[2] = {false, false};   // that block is known to hold zeroes
     bool phase_timing = false;        // vrhip_set_phase_timing: an event between the phases of a frame
@@ -580,6 +587,7 @@ int ensure_skipmap(vrhip_renderer *r)
         VR_HIP(r, vr_launch_skip_near(make_brick_view(r, r->vols[r->timestep].bricks), r->skip_bits, words,
                                       r->cull_radius, r->near_scratch, r->near_bits, r->stream));
     r->skip_dirty = false;
+    ++r->skip_version;
     return VRHIP_OK;
 }
 
@@ -793,6 +801,8 @@ int ensure_queue(vrhip_renderer *r, uint32_t W, uint32_t H, uint32_t tile_w, uin
                             hipMemcpyHostToDevice));
     r->queue_n = (uint32_t)q.size();
     r->queue_key.swap(key);
+    r->queue_frames = n_frames;
+    ++r->queue_version;
     // continuation buffer of the two-phase march: worst case every ray is suspended
     const size_t need = q.size() * 64;
     if (need > r->cont_cap) {
@@ -846,6 +856,8 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
     uint32_t *const ctrl = r->queue_head + (size_t)r->ctrl_sel * kControlWords;
     a->frame.queue_head = ctrl;
     a->frame.next_ctrl = r->queue_head + (size_t)(r->ctrl_sel ^ 1u) * kControlWords;
+    a->frame.patch_class = nullptr;   // (launch_timed: ensure_patch_classes)
+    a->frame.set_frames = 1;
     a->frame.cont = r->cont;
     a->frame.cont_count = ctrl + 1;
     a->frame.cont_head = ctrl + 2;
@@ -890,6 +902,53 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
     a->num_cus = r->num_cus;
 }
 
+// FrameView::patch_class for this launch (vr_patch_class_kernel), recomputed only when something it depends on
+// has changed: camera, rendering / ray-cast parameters (the jitter seed does not count), frame geometry and
+// work queue, skip bitmaps.  A static camera pays it once.
+int ensure_patch_classes(vrhip_renderer *r, RaycastLaunch *a)
+{
+    a->frame.patch_class = nullptr;
+    a->frame.set_frames = r->queue_frames;
+    const vrhip_rendering_params &rp = a->render;
+    if (!r->use_patch_classes || rp.technique != 0 || !a->use_ess || a->instr != 0 || !a->frame.live || !a->skip.near_bits ||
+        rp.useGradient || a->frame.env || rp.showEss || rp.imgEss || rp.iteration != 0 || a->frame.lds_stage)
+        return VRHIP_OK;
+    const uint32_t n_patches = r->queue_n / r->queue_frames;
+    std::vector<uint8_t> key;
+    auto put = [&key](const void *p, size_t n) { key.insert(key.end(), (const uint8_t *)p, (const uint8_t *)p + n); };
+    vrhip_rendering_params rk = rp;
+    rk.seed = 0;   // (frames of one camera differ in the seed only; iteration is 0 here)
+    put(&a->cam, sizeof a->cam);
+    put(&rk, sizeof rk);
+    put(&a->raycast, sizeof a->raycast);
+    const uint32_t misc[10] = {a->frame.W, a->frame.H, a->frame.gsx, a->frame.gsy, r->queue_version, r->skip_version,
+                               a->skip.near_r, n_patches, r->queue_frames, (uint32_t)a->bricks.bw};
+    put(misc, sizeof misc);
+    if (key != r->patch_class_key) {
+        if (n_patches > r->patch_class_cap) {
+            VR_HIP(r, hipStreamSynchronize(r->stream));
+            if (r->patch_class) VR_HIP(r, hipFree(r->patch_class));
+            r->patch_class = nullptr;
+            r->patch_class_cap = 0;
+            VR_HIP(r, hipMalloc((void **)&r->patch_class, n_patches));
+            r->patch_class_cap = n_patches;
+        }
+        r->patch_class_key.clear();
+        VR_HIP(r, vr_launch_patch_classes(*a, n_patches, r->queue_frames, r->patch_class, r->stream));
+        r->patch_class_key.swap(key);
+        if (getenv("VRHIP_DEBUG")) {   // how many patches skip their ray set-up
+            std::vector<uint8_t> h(n_patches);
+            VR_HIP(r, hipMemcpyAsync(h.data(), r->patch_class, n_patches, hipMemcpyDeviceToHost, r->stream));
+            VR_HIP(r, hipStreamSynchronize(r->stream));
+            size_t n1 = 0;
+            for (uint8_t v : h) n1 += v;
+            fprintf(stderr, "[vrhip] patch classes: %zu of %u patches are background for every jitter\n", n1, n_patches);
+        }
+    }
+    a->frame.patch_class = r->patch_class;
+    return VRHIP_OK;
+}
+
 int launch_timed(vrhip_renderer *r, const RaycastLaunch &a)
 {
     if (a.instr) VR_HIP(r, hipMemsetAsync(r->stats_dev, 0, sizeof(DevStats), r->stream));
@@ -898,8 +957,12 @@ int launch_timed(vrhip_renderer *r, const RaycastLaunch &a)
     if (!r->ctrl_clean[r->ctrl_sel])
         VR_HIP(r, hipMemsetAsync(a.frame.queue_head, 0, kControlWords * sizeof(uint32_t), r->stream));
     r->ctrl_clean[r->ctrl_sel] = false;
-    VR_HIP(r, hipEventRecord(r->ev0, r->stream));
     RaycastLaunch b = a;
+    {
+        const int rc = ensure_patch_classes(r, &b);   // (before the frame's timing starts: once per camera)
+        if (rc) return rc;
+    }
+    VR_HIP(r, hipEventRecord(r->ev0, r->stream));
     b.mid_event = r->phase_timing ? r->evm : nullptr;   // (an event between two launches costs ~6 us of GPU time)
     r->phase_timed = r->phase_timing;
     if (b.frame.hit_in) {
@@ -1112,6 +1175,7 @@ int vrhip_create(int device_id, vrhip_renderer **out)
     if (const char *e = getenv("VRHIP_MARCH_MICRO")) r->march_micro = (uint32_t)atoi(e);
     if (const char *e = getenv("VRHIP_MARCH_FILL")) r->march_fill = (uint32_t)atoi(e);
     if (getenv("VRHIP_NO_SORT")) r->sort_cont = false;         // experiments: phase 2 in append order
+    if (getenv("VRHIP_NO_PATCH_CLASS")) r->use_patch_classes = false;   // A/B: every patch sets up its rays
     if (getenv("VRHIP_PT_NO_CULL")) r->pt_cull = false;        // experiments: no opacity-bound culling
     if (getenv("VRHIP_NO_EMPTY_SKIP")) r->skip_empty = false;  // experiments: no empty-run skipping
     if (getenv("VRHIP_EMPTY_SKIP")) r->skip_empty_force = true;   // ... or everywhere
@@ -1155,6 +1219,7 @@ void vrhip_destroy(vrhip_renderer *r)
     if (r->skip_bits) (void)hipFree(r->skip_bits);
     if (r->near_bits) (void)hipFree(r->near_bits);
     if (r->near_scratch) (void)hipFree(r->near_scratch);
+    if (r->patch_class) (void)hipFree(r->patch_class);
     if (r->cell_bound) (void)hipFree(r->cell_bound);
     if (r->cell_empty) (void)hipFree(r->cell_empty);
     if (r->cell_sparse) (void)hipFree(r->cell_sparse);
