@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""tools/cells_time.py -- time the build of both cell grids (cells of 4 and of 8 voxels, bounds, empty bits, per-brick
+"""tools/cells_time.py -- time the one-time builders at 2048^3 (under rocprofv3 --kernel-trace --stats: ESS bricks,
+footprint volume, cell grids): the build of both cell grids (cells of 4 and of 8 voxels, bounds, empty bits, per-brick
 words) at 2048^3: separable streaming build vs the one-wave-per-cell kernel."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,4 +21,11 @@ for mode in ("stream", "wave"):
     assert rc == 0, vr.lib.vrhip_last_error(vr.handle)
     torch.cuda.synchronize()
     print(mode, "cell grid build incl. bounds + words: %.2f ms (host clock)" % ((time.perf_counter() - t0) * 1e3))
+    if mode == "stream":   # one frame: the fine cell grid and the footprint volume are built on first use
+        vr.updateView(frontend.view_matrix(frontend.quat_from_axis_angle((1, 1, 0), 30.0)))
+        vr.setSeed(1)
+        t0 = time.perf_counter()
+        vr.runRaycast(256, 256)
+        torch.cuda.synchronize()
+        print("first frame incl. footprint volume + fine cell grid: %.2f ms (host clock)" % ((time.perf_counter() - t0) * 1e3))
     vr.close()
