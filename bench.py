@@ -230,6 +230,8 @@ def main():
     multi = world > 1 or force_gather
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    _pool = torch.cuda.Stream(dev)   # torch creates its stream pool on first use (one 17 ms hipStreamCreateWithPriority
+    del _pool                        # on this image): here, not between the warm-up and the first timed frame
     if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if force_gather:

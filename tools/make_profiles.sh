@@ -24,7 +24,7 @@ region() {   # TAG WORKLOAD ARGS...
 }
 region shells2048_tput shells2048 --warmup 0 --steps 64
 region shells2048_driver_args shells2048 --warmup 5 --steps 20
-region shells2048_single shells2048 --warmup 1 --steps 32 --frames-in-flight 1 --frames-per-launch 1
+region shells2048_single shells2048 --warmup 3 --steps 32 --frames-in-flight 1 --frames-per-launch 1
 region haze2048_tput haze2048 --warmup 0 --steps 64
 region pt1024f_sphere pt1024f_sphere --warmup 1 --steps 16
 region pt1024f pt1024f --warmup 1 --steps 16
@@ -36,7 +36,7 @@ mkdir -p "$ROOT/profiles/$R"
 cp "$OUT"/pmc_issue_*.json "$OUT"/pmc_traffic_*.json "$ROOT/profiles/$R/"   # (the bench lines below look them up)
 b shells2048
 b shells2048_driver_args --steps 20 --warmup 5
-b shells2048_single --frames-in-flight 1 --frames-per-launch 1 --steps 32 --warmup 1
+b shells2048_single --frames-in-flight 1 --frames-per-launch 1 --steps 32 --warmup 3
 b sphere256_plain_512 --workload sphere256_plain --viewport 512
 b sphere256 --workload sphere256
 b shells1024u16 --workload shells1024u16
