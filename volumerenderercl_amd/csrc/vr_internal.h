@@ -243,6 +243,7 @@ struct RaycastLaunch {
     int format;            // vrhip_format
     int use_ess;
     int instr;             // 0 none, 1 stats, 2 stats + touched bitmap
+    int occ3;              // default kernels at three waves per SIMD (vr_raycast.hip VR_OCC_T): a schedule, not a result
     DevStats *stats;
     uint32_t *touched;
     int num_cus;

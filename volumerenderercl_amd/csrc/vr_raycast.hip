@@ -1199,8 +1199,14 @@ __global__ __launch_bounds__(kBlockDim) void vr_dda_prepass_kernel(
 // 4 * refill_min lanes of the wave are idle (default 64: the whole wave, measured best).  Same per-ray operation sequence as the patch kernel above; no dead
 // lanes carried through a patch, no second DDA walk.  Exit condition reached by every wave: the
 // list head only grows, and every ray ends or is suspended.
-template <typename VT, bool SKIP_LDS, bool FP>
-__global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_rays_kernel(
+// OCC: 0 = the compiler's choice (two waves per SIMD with these kernels' 176 VGPRs), 3 = three waves per SIMD
+// (<= 168 VGPRs, three to five of them spilled): pays where the march waits for its fetches -- volumes whose
+// ESS bricks are too small for the empty-run lookahead (256^3: -9 % per frame) -- and not where the lookahead
+// keeps the lanes busy with arithmetic (2048^3 "shells": +-0, one frame at a time +11 %).  See launch_variant.
+#define VR_OCC_T(n) __attribute__((amdgpu_waves_per_eu((n) ? (n) : 1, (n) ? (n) : 8)))
+
+template <typename VT, bool SKIP_LDS, bool FP, int OCC = 0>
+__global__ __launch_bounds__(kBlockDim) VR_OCC_T(OCC) void vr_raycast_rays_kernel(
     VolView vv, BrickView bricks, TfView tf, SkipView skip, CellView cells, FrameView fr,
     vrhip_camera_params cam, vrhip_rendering_params rp, vrhip_raycast_params rc)
 {
@@ -1621,8 +1627,8 @@ VR_DEV void composite_from(const RayCtx &c, RayDyn &d, const float (&p0)[kBatch]
 // lane replays the compositing of all 16 in ray order, fetching the other lanes' results with
 // in-quad DPP broadcasts -- the fp32 operation sequence per ray is exactly phase 1's (and the
 // reference's), the serial chain of a long ray is 4x shorter.
-template <typename VT, bool ESS, int INSTR, bool SKIP_LDS, bool XS, bool FP>
-__global__ __launch_bounds__(kBlockDim) VR_OCC void vr_raycast_split_kernel(
+template <typename VT, bool ESS, int INSTR, bool SKIP_LDS, bool XS, bool FP, int OCC = 0>
+__global__ __launch_bounds__(kBlockDim) VR_OCC_T(OCC) void vr_raycast_split_kernel(
     VolView vv, BrickView bricks, TfView tf, SkipView skip, CellView cells, FrameView fr,
     vrhip_camera_params cam, vrhip_rendering_params rp, vrhip_raycast_params rc, DevStats *stats,
     uint32_t *touched)
@@ -2019,6 +2025,10 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
 {
     auto k1 = vr_raycast_kernel<VT, ESS, INSTR, SKIP_LDS, XS, FP>;
     auto k2 = vr_raycast_split_kernel<VT, ESS, INSTR, SKIP_LDS, XS, FP>;
+    // three waves per SIMD (RaycastLaunch::occ3): default kernels on the footprint volume, skip bitmap from L2 (a
+    // third workgroup's LDS has no room for it: launch_typed sends these launches to SKIP_LDS = false)
+    constexpr bool kOcc3 = ESS && INSTR == 0 && !XS && FP && !SKIP_LDS;
+    if (kOcc3 && a.occ3) k2 = vr_raycast_split_kernel<VT, ESS, INSTR, SKIP_LDS, XS, FP, kOcc3 ? 3 : 0>;
     size_t lds = (size_t)kStageF4 * sizeof(float4) + (size_t)a.tf.tff_n * sizeof(float4);
     if (ESS && SKIP_LDS) lds += ((size_t)a.skip.n_words + 1) * sizeof(uint32_t);
     int nb1 = 0, nb2 = 0;
@@ -2060,6 +2070,7 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
 #endif
     if (ESS && INSTR == 0 && !XS && frame.live && frame.live_rays) {   // phase 1 on the ray list
         auto kr = vr_raycast_rays_kernel<VT, SKIP_LDS, FP>;
+        if (kOcc3 && a.occ3) kr = vr_raycast_rays_kernel<VT, SKIP_LDS, FP, kOcc3 ? 3 : 0>;
         int nbr = 0;
         e = prepare_variant(kr, lds, &nbr, "raycast phase 1 (ray list)", a.num_cus);
         if (e != hipSuccess) return e;
@@ -2091,7 +2102,7 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
 template <typename VT>
 hipError_t launch_typed(const RaycastLaunch &a, hipStream_t stream)
 {
-    const bool lds = a.skip.in_lds != 0;
+    const bool lds = a.skip.in_lds != 0 && !a.occ3;
     // the rarely used shading modes 2-5, contours, the depth cue and nearest filtering live in kernel
     // variants of their own (XS), so that their code and registers do not tax the default ones
     const bool xs = a.render.illumType >= 2 || a.raycast.useAO != 0 || a.render.showEss != 0 ||
