@@ -494,7 +494,10 @@ def main():
         # budgeted march of every ray; phase 2: the suspended long rays, 4 lanes per ray).  Its
         # duration = HIP events over the timed region on the launch stream / K (world == 1; with
         # the gather in the region at world > 1 the vrhip events of the last pass are used).
-        kernel_s = gpu_region_s / args.steps if not multi else last_kernel_s
+        # (multi: the renderer's own events around its last set of launches, which held its share of
+        # ceil(len(last chunk) / renderers) frames in throughput mode)
+        last_set_frames = (-(-len(chunks[-1]) // fif)) if (multi and throughput) else 1
+        kernel_s = gpu_region_s / args.steps if not multi else last_kernel_s / last_set_frames
         achieved = alg_bytes / kernel_s / 1e9
         src = source_hash()
         key = schedule_key(args.workload, W, args.view, fif, max(len(b_) for b_ in blocks) if throughput else 1,
