@@ -1633,7 +1633,7 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC_T(OCC) void vr_raycast_split_kern
     vrhip_camera_params cam, vrhip_rendering_params rp, vrhip_raycast_params rc, DevStats *stats,
     uint32_t *touched)
 {
-    static_assert(kSplit == 4 && kBatch == 4, "phase 2 is written for 4 lanes x 4 samples");
+    static_assert(kSplit == 4 && (kBatch == 4 || kBatch == 8), "phase 2 is written for 4 lanes x 4 (8: A/B build) samples");
     const uint32_t n_rays = *fr.cont_count;   // written by phase 1 (previous kernel on the stream)
     if (n_rays == 0) return;
     extern __shared__ float4 s_mem[];
