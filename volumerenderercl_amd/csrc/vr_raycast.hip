@@ -1280,15 +1280,6 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC_T(OCC) void vr_raycast_rays_kerne
                             gy = rec.pix >> 16;
                             out_index = rec.out_index;
                             frame_idx = (uint32_t)rec.state >> 8;
-#ifdef VR_TWICE_SETUP   // diagnostic build: sensitivity of the frame time to the ray set-up at a refill
-                            {
-                                RayCtx c2; RayDyn d2;
-                                setup_ray<true>(gx ^ 1u, gy, true, fr, cam, rp, rc, resf, voxLen, grid, c2, d2,
-                                                fr.seeds ? fr.seeds[frame_idx] : rp.seed);
-                                asm volatile("" ::"v"(c2.cam.x), "v"(c2.dir.x), "v"(c2.stepSize), "v"(c2.offset), "v"(c2.tfar),
-                                             "v"(c2.dT0), "v"(c2.lgt.x), "v"(c2.hv.x), "v"(d2.t_exit), "v"(c2.env0));
-                            }
-#endif
                             setup_ray<true>(gx, gy, true, fr, cam, rp, rc, resf, voxLen, grid, c, d,
                                             fr.seeds ? fr.seeds[frame_idx] : rp.seed);
                             d.state = rec.state & 0xff;
@@ -1732,15 +1723,6 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC_T(OCC) void vr_raycast_split_kern
                             gy = rec.pix >> 16;
                             out_index = rec.out_index;
                             const uint32_t f = (uint32_t)rec.state >> 8;
-#ifdef VR_TWICE_SETUP
-                            {
-                                RayCtx c2; RayDyn d2;
-                                setup_ray<ESS>(gx ^ 1u, gy, true, fr, cam, rp, rc, resf, voxLen, grid, c2, d2,
-                                               fr.seeds ? fr.seeds[f] : rp.seed);
-                                asm volatile("" ::"v"(c2.cam.x), "v"(c2.dir.x), "v"(c2.stepSize), "v"(c2.offset), "v"(c2.tfar),
-                                             "v"(c2.dT0), "v"(c2.lgt.x), "v"(c2.hv.x), "v"(d2.t_exit), "v"(c2.env0));
-                            }
-#endif
                             setup_ray<ESS>(gx, gy, true, fr, cam, rp, rc, resf, voxLen, grid, c, d,
                                            fr.seeds ? fr.seeds[f] : rp.seed);
                             d.state = rec.state & 0xff;
