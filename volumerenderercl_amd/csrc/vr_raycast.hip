@@ -2028,9 +2028,10 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
     // three waves per SIMD (RaycastLaunch::occ3): default kernels on the footprint volume, skip bitmap from L2 (a
     // third workgroup's LDS has no room for it: launch_typed sends these launches to SKIP_LDS = false)
     constexpr bool kOcc3 = ESS && INSTR == 0 && !XS && FP && !SKIP_LDS;
-    if (kOcc3 && a.occ3) k2 = vr_raycast_split_kernel<VT, ESS, INSTR, SKIP_LDS, XS, FP, kOcc3 ? 3 : 0>;
-    size_t lds = (size_t)kStageF4 * sizeof(float4) + (size_t)a.tf.tff_n * sizeof(float4);
-    if (ESS && SKIP_LDS) lds += ((size_t)a.skip.n_words + 1) * sizeof(uint32_t);
+    if (kOcc3 && a.occ3_split) k2 = vr_raycast_split_kernel<VT, ESS, INSTR, SKIP_LDS, XS, FP, kOcc3 ? 3 : 0>;
+    const size_t lds_base = (size_t)kStageF4 * sizeof(float4) + (size_t)a.tf.tff_n * sizeof(float4);
+    const size_t lds_skip = ((size_t)a.skip.n_words + 1) * sizeof(uint32_t);
+    const size_t lds = lds_base + (ESS && SKIP_LDS ? lds_skip : 0);
     int nb1 = 0, nb2 = 0;
     {
         hipError_t e = prepare_variant(k1, lds, &nb1, "raycast phase 1", a.num_cus);
@@ -2069,12 +2070,18 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
         return launch_march<VT, SKIP_LDS, FP>(a, frame, block, cus, stream);   // the whole frame in one launch
 #endif
     if (ESS && INSTR == 0 && !XS && frame.live && frame.live_rays) {   // phase 1 on the ray list
-        auto kr = vr_raycast_rays_kernel<VT, SKIP_LDS, FP>;
-        if (kOcc3 && a.occ3) kr = vr_raycast_rays_kernel<VT, SKIP_LDS, FP, kOcc3 ? 3 : 0>;
+        // phase 1 picks its own schedule: skip bitmap in LDS at two waves per SIMD, from L2 at two or three
+        constexpr bool kOcc3R = FP;   // (three waves: footprint volume only)
+        const bool r3 = kOcc3R && a.occ3;
+        const bool rlds = a.skip.in_lds != 0 && !r3;
+        auto kr = vr_raycast_rays_kernel<VT, false, FP>;
+        if (r3) kr = vr_raycast_rays_kernel<VT, false, FP, kOcc3R ? 3 : 0>;
+        else if (rlds) kr = vr_raycast_rays_kernel<VT, true, FP>;
+        const size_t lds_r = lds_base + (rlds ? lds_skip : 0);
         int nbr = 0;
-        e = prepare_variant(kr, lds, &nbr, "raycast phase 1 (ray list)", a.num_cus);
+        e = prepare_variant(kr, lds_r, &nbr, "raycast phase 1 (ray list)", a.num_cus);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kr, dim3(cus * (uint32_t)nbr), block, lds, stream, a.vol, a.bricks, a.tf, a.skip,
+        hipLaunchKernelGGL(kr, dim3(cus * (uint32_t)nbr), block, lds_r, stream, a.vol, a.bricks, a.tf, a.skip,
                            a.cells, frame, a.cam, a.render, a.raycast);
     } else {
         hipLaunchKernelGGL(k1, grid, block, lds, stream, a.vol, a.bricks, a.tf, a.skip, a.cells, frame, a.cam,
@@ -2102,7 +2109,7 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
 template <typename VT>
 hipError_t launch_typed(const RaycastLaunch &a, hipStream_t stream)
 {
-    const bool lds = a.skip.in_lds != 0 && !a.occ3;
+    const bool lds = a.skip.in_lds != 0 && !a.occ3_split;   // (phase 2 and the patch kernels; phase 1 on the ray list: launch_variant)
     // the rarely used shading modes 2-5, contours, the depth cue and nearest filtering live in kernel
     // variants of their own (XS), so that their code and registers do not tax the default ones
     const bool xs = a.render.illumType >= 2 || a.raycast.useAO != 0 || a.render.showEss != 0 ||

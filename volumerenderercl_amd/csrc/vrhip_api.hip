@@ -108,6 +108,7 @@ struct vrhip_renderer {
     uint32_t queue_frames = 1;        // frames per set of the current queue
     bool use_patch_classes = true;    // VRHIP_NO_PATCH_CLASS=1 disables
     int occ_force = 0;                // VRHIP_OCC=2|3: waves per SIMD of the default marching kernels (0 = by volume)
+    int occ_force_split = 0;          // ... of phase 2 (VRHIP_OCC sets both, VRHIP_OCC_P1 / VRHIP_OCC_P2 one)
     uint32_t ctrl_sel = 0;            // the block the next set of launches uses
     bool ctrl_clean[2] = {false, false};   // that block is known to hold zeroes
     bool phase_timing = false;        // vrhip_set_phase_timing: an event between the phases of a frame
@@ -899,11 +900,18 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
     a->format = r->format;
     a->use_ess = r->use_ess ? 1 : 0;
     a->instr = r->stats_enabled ? 1 : 0;
-    // Three waves per SIMD where the march waits for its fetches instead of stepping over empty cells: volumes whose
-    // ESS bricks are too small for the empty-run lookahead (ray_skip_empty; 256^3: -9 % per frame, -6 % one frame at a
-    // time).  With the lookahead the lanes are busy with arithmetic and the third wave buys nothing (2048^3 "shells":
-    // +-0 in throughput mode, +11 % one frame at a time).  VRHIP_OCC=2|3 forces either (tools/ab_env.sh).
-    a->occ3 = r->occ_force ? (r->occ_force == 3) : (r->use_ess && !ray_skip_empty(r));
+    // Three waves per SIMD (skip bitmap from L2 instead of LDS) where waves wait more than they issue:
+    //  * volumes whose ESS bricks are too small for the empty-run lookahead (ray_skip_empty): the march waits for its
+    //    fetches instead of stepping over empty cells (256^3: -9 % per frame, -6 % one frame at a time);
+    //  * launch sets of several frames (the throughput schedule, a rank's tile share): enough rays for a third
+    //    workgroup per CU, and no chain of one frame's longest rays that a third wave would stretch (2048^3, 16 frames
+    //    per set and two renderers: "shells" -2.5 ... -4 %, "haze" -5 %, an 8-rank tile share -3 ... -5 %; both phases
+    //    at three waves -- one of them alone gains half of it or nothing).
+    // One frame at a time with the lookahead: two waves ("shells" +10 % with three, the longest rays' chain).
+    // VRHIP_OCC=2|3 forces both phases, VRHIP_OCC_P1 / VRHIP_OCC_P2 one of them (tools/ab_env.sh).
+    const bool three = r->use_ess && (!ray_skip_empty(r) || r->queue_frames >= 4u);
+    a->occ3 = r->occ_force ? (r->occ_force == 3) : three;
+    a->occ3_split = r->occ_force_split ? (r->occ_force_split == 3) : three;
     a->stats = r->stats_dev;
     a->num_cus = r->num_cus;
 }
@@ -1182,7 +1190,13 @@ int vrhip_create(int device_id, vrhip_renderer **out)
     if (const char *e = getenv("VRHIP_MARCH_FILL")) r->march_fill = (uint32_t)atoi(e);
     if (getenv("VRHIP_NO_SORT")) r->sort_cont = false;         // experiments: phase 2 in append order
     if (getenv("VRHIP_NO_PATCH_CLASS")) r->use_patch_classes = false;   // A/B: every patch sets up its rays
-    if (const char *e = getenv("VRHIP_OCC")) r->occ_force = atoi(e) == 3 ? 3 : atoi(e) == 2 ? 2 : 0;
+    auto occ_env = [](const char *name, int dflt) {
+        const char *e = getenv(name);
+        return e ? (atoi(e) == 3 ? 3 : atoi(e) == 2 ? 2 : 0) : dflt;
+    };
+    r->occ_force = r->occ_force_split = occ_env("VRHIP_OCC", 0);
+    r->occ_force = occ_env("VRHIP_OCC_P1", r->occ_force);
+    r->occ_force_split = occ_env("VRHIP_OCC_P2", r->occ_force_split);
     if (getenv("VRHIP_PT_NO_CULL")) r->pt_cull = false;        // experiments: no opacity-bound culling
     if (getenv("VRHIP_NO_EMPTY_SKIP")) r->skip_empty = false;  // experiments: no empty-run skipping
     if (getenv("VRHIP_EMPTY_SKIP")) r->skip_empty_force = true;   // ... or everywhere
