@@ -131,17 +131,21 @@ def cpu_baseline(vr, vol_host, bricks_host, tff, fmt, W, H, target_s, seeds, use
 def source_hash():
     """sha256 (16 hex digits) over the kernel sources the measured code is built from
     (volumerenderercl_amd/csrc/*.hip, *.h and the C ABI header): a committed PMC profile is only used
-    for a roofline figure when it was taken from the same sources."""
-    import glob
-    import hashlib
-    h = hashlib.sha256()
-    base = os.path.join(ROOT, "volumerenderercl_amd", "csrc")
-    files = sorted(glob.glob(os.path.join(base, "*.hip")) + glob.glob(os.path.join(base, "*.h")))
-    files.append(os.path.join(ROOT, "include", "vrhip.h"))
-    for f in files:
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
-    return h.hexdigest()[:16]
+    for a roofline figure when it was taken from the same sources, and a library built from other
+    sources than the tree holds is not measured at all (check_library_sources)."""
+    from volumerenderercl_amd import _srchash
+    return _srchash.source_hash()
+
+
+def check_library_sources(lib):
+    """The loaded libvrhip.so carries the hash of the sources it was built from: a stale build (sources edited or
+    reverted without a rebuild) would be measured under the tree's name otherwise."""
+    import ctypes
+    lib.vrhip_build_source_hash.restype = ctypes.c_char_p
+    built, tree = lib.vrhip_build_source_hash().decode(), source_hash()
+    if built != tree:
+        raise SystemExit("bench.py: libvrhip.so was built from kernel sources %s, the tree holds %s -- rebuild "
+                         "(python -c 'import __graft_entry__ as g; g.build()') before measuring" % (built, tree))
 
 
 def schedule_key(workload, viewport, view, fif, fpl, round_budget):
@@ -254,6 +258,7 @@ def main():
 
     vr = VolumeRenderCL()
     vr.initialize(device_id=local_rank)
+    check_library_sources(vr.lib)
     stream = torch.cuda.current_stream(dev)
     vr.set_stream(stream.cuda_stream)            # kernels + HIP events on torch's stream
     vr.synthVolume(kind, (res, res, res), fmt)   # input generated in HBM

@@ -290,6 +290,11 @@ int vrhip_count_touched_tiles(vrhip_renderer *r, uint32_t width, uint32_t height
                               uint32_t tile_w, uint32_t tile_h, const uint32_t *tile_ids,
                               uint32_t n_tiles, uint64_t *microbricks_touched);
 
+/* Hash (16 hex digits) of the kernel sources this library was built from (the .hip and .h files of csrc/ and this header,
+ * volumerenderercl_amd/_srchash.py): bench.py compares it with the tree's before it measures, so that a stale build
+ * is never measured under the tree's name.  No reference counterpart. */
+const char *vrhip_build_source_hash(void);
+
 #ifdef __cplusplus
 }
 #endif

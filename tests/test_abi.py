@@ -76,3 +76,12 @@ def test_host_library_exports_every_declared_symbol():
     host = C.CDLL(os.path.join(ROOT, "volumerenderercl_amd", "libvrhost.so"))
     for name in names:
         assert hasattr(host, name), name
+
+
+def test_library_carries_the_hash_of_its_sources():
+    """vrhip_build_source_hash(): what bench.py checks before it measures (a stale build is refused)."""
+    from volumerenderercl_amd import _lib, _srchash
+    lib = _lib.load()
+    built = lib.vrhip_build_source_hash().decode()
+    assert len(built) == 16 and int(built, 16) >= 0
+    assert built == _srchash.source_hash(), "libvrhip.so is older than its sources: run __graft_entry__.build()"
