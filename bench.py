@@ -69,6 +69,9 @@ def parse():
                          "(vrhip_render_batch); 1 = one frame per launch set")
     ap.add_argument("--round-budget", type=int, default=48,
                     help="phase-1 sample rounds per ray when several frames are in flight")
+    ap.add_argument("--frame-timing", type=int, default=0,
+                    help="throughput mode on one GPU: 1 = keep the renderers' own events around every launch set "
+                         "(vrhip_set_frame_timing; the region is timed as a whole either way)")
     ap.add_argument("--frames-in-flight", type=int, default=2,
                     help="single GPU: renderers (one stream each, sharing the volume) that alternate "
                          "frames, so that the tail of one frame overlaps the head of the next")
@@ -316,6 +319,11 @@ def main():
         lanes.append((twin, s2, None))
     if not multi and throughput:   # one output block of fpl frames per renderer
         lanes = [(r, s_, torch.empty((fpl, H, W, 4), dtype=torch.float32, device=dev)) for r, s_, _ in lanes]
+        # nobody reads a launch set's own kernel time here (the region is timed as a whole): without the two
+        # events around every set the next set's pre-pass can overlap the tail of the one before
+        # (vrhip_set_frame_timing; on again for the one-frame-at-a-time pass below)
+        for r, _, _ in lanes:
+            r.setFrameTiming(bool(args.frame_timing))
     if multi and throughput:
         driver_mt = vtiles.TileDriver(vr, split, dev, batch=fpg, lanes=[(r, s_) for r, s_, _ in lanes],
                                       force_gather=force_gather, sparse=sparse)
@@ -433,6 +441,8 @@ def main():
 
     # ---- untimed: the same frames one at a time (what one launch takes when it has the GPU to itself)
     serial_s = None
+    for r, _, _ in lanes:
+        r.setFrameTiming(True)
     if throughput:
         vr.setRoundBudget(10)      # the single-frame schedule for everything that follows
     if not multi and throughput:

@@ -268,6 +268,11 @@ int vrhip_last_phase_seconds(const vrhip_renderer *r, double *phase1, double *ph
  * between two launches): it is recorded only while this is enabled (default off; then
  * vrhip_last_phase_seconds answers VRHIP_ERR_NODATA). */
 int vrhip_set_phase_timing(vrhip_renderer *r, int enabled);
+/* The two events around a frame's launches (what vrhip_last_kernel_seconds reads; the reference times every frame
+ * with CL profiling events, volumerendercl.cpp:545-551) cost GPU time of their own when frames follow each other
+ * without a wait in between.  Default on; off: vrhip_last_kernel_seconds answers 0 and vrhip_last_phase_seconds
+ * VRHIP_ERR_NODATA. */
+int vrhip_set_frame_timing(vrhip_renderer *r, int enabled);
 
 /* ---- measurement helpers ------------------------------------------- */
 /* When enabled, render calls run the instrumented kernel variant that accumulates

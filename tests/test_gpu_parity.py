@@ -2013,6 +2013,16 @@ def test_control_blocks_alternate_cleanly(vr):
         vr.setPhaseTiming(False)
         np.testing.assert_array_equal(got(seeds[5]), want[seeds[5]])
         assert vr.getLastPhaseTimes() == (0.0, 0.0)
+        # the events around a frame are a switch too (vrhip_set_frame_timing): same pixels, no kernel time
+        assert vr.getLastExecTime() > 0
+        vr.setFrameTiming(False)
+        vr.setPhaseTiming(True)                                 # (has nothing to measure against: no data either)
+        np.testing.assert_array_equal(got(seeds[4]), want[seeds[4]])
+        assert vr.getLastExecTime() == 0.0 and vr.getLastPhaseTimes() == (0.0, 0.0)
+        vr.setPhaseTiming(False)
+        vr.setFrameTiming(True)
+        np.testing.assert_array_equal(got(seeds[5]), want[seeds[5]])
+        assert vr.getLastExecTime() > 0
         out = torch.zeros((3, H, W, 4), dtype=torch.float32, device="cuda")
         for _ in range(3):                                      # batches: odd number of sets in a row
             vr.setTechnique(0)
@@ -2047,6 +2057,16 @@ def test_experiment_kernels_do_not_change_pixels():
     lib = os.path.join(root, "volumerenderercl_amd", "_variants", "libvrhip_experiments.so")
     if not os.path.exists(lib):
         pytest.skip("A/B build with the experiment kernels not present")
+    import ctypes
+    from volumerenderercl_amd import _srchash
+    try:
+        vlib = ctypes.CDLL(lib)
+        vlib.vrhip_build_source_hash.restype = ctypes.c_char_p
+        built = vlib.vrhip_build_source_hash().decode()
+    except (OSError, AttributeError):
+        built = None
+    if built != _srchash.source_hash():
+        pytest.skip("A/B build with the experiment kernels is older than the sources (tools/mkvariant.sh rebuilds it)")
     code = r"""
 import os, sys
 import numpy as np

@@ -107,6 +107,7 @@ SYMBOLS = {
     "vrhip_last_kernel_seconds": (C.c_double, [_H]),
     "vrhip_last_phase_seconds": (C.c_int, [_H, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vrhip_set_phase_timing": (C.c_int, [_H, C.c_int]),
+    "vrhip_set_frame_timing": (C.c_int, [_H, C.c_int]),
     "vrhip_build_source_hash": (C.c_char_p, []),
     "vrhip_set_stats_enabled": (C.c_int, [_H, C.c_int]),
     "vrhip_get_stats": (C.c_int, [_H, C.POINTER(Stats)]),

@@ -112,6 +112,7 @@ struct vrhip_renderer {
     uint32_t ctrl_sel = 0;            // the block the next set of launches uses
     bool ctrl_clean[2] = {false, false};   // that block is known to hold zeroes
     bool phase_timing = false;        // vrhip_set_phase_timing: an event between the phases of a frame
+    bool frame_timing = true;         // vrhip_set_frame_timing: events around a frame's launches (vrhip_last_kernel_seconds)
     uint16_t *cost = nullptr;         // per pixel: phase-2 rounds of the previous frame (sort key)
     uint32_t *order = nullptr;        // sorted permutation of the suspended rays
     ContRec *live_rays = nullptr;     // pre-pass output: live rays with their DDA state (phase 1's list)
@@ -976,9 +977,9 @@ int launch_timed(vrhip_renderer *r, const RaycastLaunch &a)
         const int rc = ensure_patch_classes(r, &b);   // (before the frame's timing starts: once per camera)
         if (rc) return rc;
     }
-    VR_HIP(r, hipEventRecord(r->ev0, r->stream));
-    b.mid_event = r->phase_timing ? r->evm : nullptr;   // (an event between two launches costs ~6 us of GPU time)
-    r->phase_timed = r->phase_timing;
+    if (r->frame_timing) VR_HIP(r, hipEventRecord(r->ev0, r->stream));
+    b.mid_event = r->phase_timing && r->frame_timing ? r->evm : nullptr;   // (an event between two launches costs ~6 us of GPU time)
+    r->phase_timed = r->phase_timing && r->frame_timing;
     if (b.frame.hit_in) {
         VR_HIP(r, hipMemsetAsync(r->hit_any, 0, (size_t)r->hit_w * r->hit_h, r->stream));
         b.hit_out = r->hit_out;
@@ -986,8 +987,8 @@ int launch_timed(vrhip_renderer *r, const RaycastLaunch &a)
     VR_HIP(r, vr_launch_frame(b, r->stream));
     r->ctrl_sel ^= 1u;                 // the first kernel of this set has zeroed the other block
     r->ctrl_clean[r->ctrl_sel] = true;
-    VR_HIP(r, hipEventRecord(r->ev1, r->stream));
-    r->timed = true;
+    if (r->frame_timing) VR_HIP(r, hipEventRecord(r->ev1, r->stream));
+    r->timed = r->frame_timing;
     if (b.frame.hit_in) std::swap(r->hit_in, r->hit_out);   // runRaycast, volumerendercl.cpp:524-530
     return VRHIP_OK;
 }
@@ -1194,6 +1195,7 @@ int vrhip_create(int device_id, vrhip_renderer **out)
         const char *e = getenv(name);
         return e ? (atoi(e) == 3 ? 3 : atoi(e) == 2 ? 2 : 0) : dflt;
     };
+    if (const char *e = getenv("VRHIP_FRAME_TIMING")) r->frame_timing = atoi(e) != 0;   // A/B (tools/ab_env.sh)
     r->occ_force = r->occ_force_split = occ_env("VRHIP_OCC", 0);
     r->occ_force = occ_env("VRHIP_OCC_P1", r->occ_force);
     r->occ_force_split = occ_env("VRHIP_OCC_P2", r->occ_force_split);
@@ -1858,6 +1860,14 @@ int vrhip_set_phase_timing(vrhip_renderer *r, int enabled)
 {
     if (!r) return VRHIP_ERR_INVALID;
     r->phase_timing = enabled != 0;
+    return VRHIP_OK;
+}
+
+int vrhip_set_frame_timing(vrhip_renderer *r, int enabled)
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    r->frame_timing = enabled != 0;
+    if (!r->frame_timing) r->timed = r->phase_timed = false;
     return VRHIP_OK;
 }
 

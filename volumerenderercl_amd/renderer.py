@@ -537,6 +537,12 @@ class VolumeRenderCL:
         the event costs GPU time)."""
         self._check(self._lib.vrhip_set_phase_timing(self._h, 1 if v else 0))
 
+    def setFrameTiming(self, v):
+        """Record the two events around a frame's launches (vrhip_set_frame_timing; on by default, as the
+        reference times every frame, volumerendercl.cpp:545-551).  Off: getLastExecTime() answers 0 and frames
+        that follow each other without a wait lose the events' GPU time."""
+        self._check(self._lib.vrhip_set_frame_timing(self._h, 1 if v else 0))
+
     def getLastPhaseTimes(self):
         """(phase-1 seconds, phase-2 seconds) of the last ray-cast pass rendered with setPhaseTiming(True);
         (0.0, 0.0) when the last pass was not phase-timed."""
