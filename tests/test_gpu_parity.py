@@ -1,9 +1,10 @@
 """GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same
-seeded inputs.  Bar: <= 1e-4 per channel (north_star); the kernels execute the oracle's
-fp32 operation sequences, so the observed difference is expected to be exactly 0 and the
-integer work counters must match bit for bit.
+seeded inputs.  The north_star's bar is 1e-4 per channel; the kernels execute the oracle's
+fp32 operation sequences, so the tests ask for a difference of exactly 0 (VRHIP_TEST_TOL=1e-4
+relaxes them to the bar) and the integer work counters must match bit for bit.
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -16,7 +17,7 @@ from volumerenderercl_amd import FLOAT, UCHAR, USHORT, VolumeRenderCL, frontend
 
 pytestmark = pytest.mark.gpu
 
-TOL = 1e-4   # per channel, float RGBA (BASELINE.json north_star)
+TOL = float(os.environ.get("VRHIP_TEST_TOL", "0"))   # per channel, float RGBA: bit-exact (north_star allows 1e-4)
 SEED = 3499211612
 
 
@@ -2107,3 +2108,89 @@ print("EXPERIMENTS_OK", len(frames))
 """
     p = _run_py(code, env={"VRHIP_LIB_PATH": lib})
     assert p.returncode == 0 and "EXPERIMENTS_OK 36" in p.stdout, (p.stdout[-500:], p.stderr[-3000:])
+
+
+def _random_scene(rng):
+    """A scene drawn from the parameter space the reference's GUI can reach: voxel type, odd non-cubic resolution,
+    anisotropic slice thickness, empty halves, transfer-function stops, camera inside / outside / orthographic,
+    clip box, sampling rate, shading, ESS, filtering, jitter seed, odd viewports."""
+    fmt = [UCHAR, USHORT, FLOAT][int(rng.integers(3))]
+    res = tuple(int(v) for v in rng.integers(17, 70, size=3))
+    vol = common.noise_volume(res, fmt, seed=int(rng.integers(1 << 30)), smooth=bool(rng.integers(2)))
+    if rng.random() < 0.5:   # a slab of nothing: bricks to skip, cells to step over
+        ax, cut = int(rng.integers(3)), float(rng.uniform(0.2, 0.6))
+        sl = [slice(None)] * 3
+        n = vol.shape[ax]
+        sl[ax] = slice(0, int(n * cut)) if rng.random() < 0.5 else slice(int(n * (1 - cut)), n)
+        vol[tuple(sl)] = 0
+    pos = np.sort(rng.uniform(0.02, 0.98, size=int(rng.integers(1, 4))))
+    stops = [(0.0, (0, 0, 0, 0))]
+    for p in pos:
+        stops.append((float(p), tuple(int(v) for v in rng.integers(0, 256, size=3)) +
+                      (int(rng.integers(0, 256)) if rng.random() < 0.7 else 0,)))
+    stops.append((1.0, tuple(int(v) for v in rng.integers(0, 256, size=3)) + (int(rng.integers(0, 256)),)))
+    tff = frontend.tff_from_stops(stops)
+    q = frontend.quat_from_axis_angle(tuple(rng.normal(size=3)), float(rng.uniform(0, 360)))
+    z = float(rng.choice([rng.uniform(0.2, 0.9), rng.uniform(1.2, 4.0)]))
+    view = frontend.view_matrix(q, (float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.3, 0.3)), z))
+    kw = {"illum": int(rng.integers(2)), "ess": bool(rng.random() < 0.75), "linear": bool(rng.random() < 0.85),
+          "ortho": bool(rng.random() < 0.2), "rate": float(rng.choice([0.5, 1.0, 1.5, 2.0, 3.1])),
+          "gradient_bg": bool(rng.random() < 0.3), "seed": int(rng.integers(1, 1 << 32))}
+    if rng.random() < 0.3:
+        lo = rng.uniform(-1.0, -0.2, size=3)
+        hi = rng.uniform(0.2, 1.0, size=3)
+        kw["bbox"] = tuple(float(v) for v in lo) + tuple(float(v) for v in hi)
+    if rng.random() < 0.3:
+        kw["thickness"] = tuple(float(v) for v in rng.choice([0.5, 1.0, 1.0, 2.0, 3.3], size=3))
+    if rng.random() < 0.25:
+        kw["background"] = tuple(float(v) for v in rng.uniform(0, 1, size=3)) + (1.0,)
+    W, H = int(rng.integers(33, 150)), int(rng.integers(33, 120))
+    return vol, fmt, tff, view, kw, W, H
+
+
+@pytest.mark.parametrize("case", range(48))
+def test_randomised_scenes_match_oracle(vr, case):
+    """Scenes nobody wrote by hand (seeded: the same 48 every run): instrumented and production kernels against the
+    oracle, image and work counters (_compare)."""
+    rng = np.random.default_rng(20261004 + case)
+    vol, fmt, tff, view, kw, W, H = _random_scene(rng)
+    _setup(vr, vol, fmt, tff, view, **kw)
+    try:
+        vr.updateOutputImg(W, H)
+        _compare(vr, vol, fmt, tff, W, H, ess=kw["ess"])
+    finally:
+        vr.setBBox(-1, -1, -1, 1, 1, 1)
+        vr.setUseGradient(False)
+        vr.setCamOrtho(False)
+        vr.setLinearInterpolation(True)
+
+
+@pytest.mark.parametrize("case", range(32))
+def test_randomised_scenes_with_the_rarer_modes_match_oracle(vr, case):
+    """The same with the modes that live in kernel variants of their own: illumination 2-5, contours, the depth
+    cue, ambient occlusion, showEss, nearest filtering, progressive accumulation over two iterations."""
+    rng = np.random.default_rng(77261004 + case)
+    vol, fmt, tff, view, kw, W, H = _random_scene(rng)
+    kw.update(illum=int(rng.integers(0, 6)), contours=bool(rng.random() < 0.3), aerial=bool(rng.random() < 0.3),
+              ao=bool(rng.random() < 0.25), show_ess=bool(rng.random() < 0.25), linear=bool(rng.random() < 0.6))
+    _setup(vr, vol, fmt, tff, view, **kw)
+    try:
+        vr.updateOutputImg(W, H)
+        _compare(vr, vol, fmt, tff, W, H, ess=kw["ess"])
+    finally:
+        _setup(vr, vol, fmt, tff, view)   # every switch back to its default
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_randomised_scenes_path_traced_match_oracle(vr, case):
+    """The same through the path tracer (technique 1), with a random extinction."""
+    rng = np.random.default_rng(55261004 + case)
+    vol, fmt, tff, view, kw, W, H = _random_scene(rng)
+    kw = {k: v for k, v in kw.items() if k in ("seed", "bbox", "thickness", "background", "ortho", "gradient_bg")}
+    kw["ext"] = float(rng.choice([10.0, 40.0, 100.0, 250.0]))
+    _setup(vr, vol, fmt, tff, view, technique=1, **kw)
+    try:
+        vr.updateOutputImg(W, H)
+        _compare(vr, vol, fmt, tff, W, H, pathtrace=True)
+    finally:
+        _setup(vr, vol, fmt, tff, view)
