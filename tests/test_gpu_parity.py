@@ -2194,3 +2194,41 @@ def test_randomised_scenes_path_traced_match_oracle(vr, case):
         _compare(vr, vol, fmt, tff, W, H, pathtrace=True)
     finally:
         _setup(vr, vol, fmt, tff, view)
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_randomised_batches_of_tile_subsets_equal_their_frames(vr, case):
+    """vrhip_render_batch on random scenes: a random number of frames (own seeds), a random tile size and a random
+    subset of the tiles in one set of launches (two or three waves per SIMD by the set's size) -- every tile of
+    every frame equals the same region of the frame rendered alone, which _compare checks against the oracle."""
+    import torch
+    rng = np.random.default_rng(99261004 + case)
+    vol, fmt, tff, view, kw, W, H = _random_scene(rng)
+    kw["linear"] = True if rng.random() < 0.8 else kw["linear"]
+    _setup(vr, vol, fmt, tff, view, **kw)
+    try:
+        vr.updateOutputImg(W, H)
+        _compare(vr, vol, fmt, tff, W, H, ess=kw["ess"])
+        n_frames = int(rng.integers(1, 10))
+        seeds = [int(v) for v in rng.integers(1, 1 << 32, size=n_frames)]
+        vr.setStatsEnabled(False)
+        singles = []
+        for s in seeds:
+            vr.setSeed(s)
+            vr.setIteration(0)
+            singles.append(vr.runRaycastNoGL(W, H))
+        T = int(rng.choice([16, 32, 64]))
+        tx, ty = (W + T - 1) // T, (H + T - 1) // T
+        n_tiles = tx * ty
+        ids = np.sort(rng.choice(n_tiles, size=int(rng.integers(1, n_tiles + 1)), replace=False)).astype(np.uint32)
+        out = torch.zeros((n_frames, len(ids), T, T, 4), dtype=torch.float32, device="cuda")
+        vr.render_batch(W, H, seeds, out.data_ptr(), tile_w=T, tile_h=T, tile_ids=ids)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        for f in range(n_frames):
+            for k, t in enumerate(ids):
+                x0, y0 = (int(t) % tx) * T, (int(t) // tx) * T
+                w, h = min(T, W - x0), min(T, H - y0)
+                assert np.array_equal(got[f, k, :h, :w], singles[f][y0:y0 + h, x0:x0 + w]), (f, int(t))
+    finally:
+        _setup(vr, vol, fmt, tff, view)
