@@ -549,7 +549,8 @@ def main():
             "serial_launch_ms": serial_s * 1e3 if serial_s else None,
             "launch_note": ("%d renderer(s) on as many streams over one shared volume, each rendering up to %d independent "
                             "frames (own jitter seeds) per set of launches (vrhip_render_batch): avg_launch_ms = "
-                            "HIP-event time of the timed region / frames, phase-1 round budget %d (throughput "
+                            "HIP-event time of the timed region / frames (the renderers' own events around each "
+                            "set off unless --frame-timing 1), phase-1 round budget %d (throughput "
                             "schedule); serial_launch_ms = the same frames one at a time with the single-frame "
                             "schedule (budget 10), which is what a rocprofv3 kernel trace of `--frames-in-flight 1 "
                             "--frames-per-launch 1` sums to" % (fif, fpl, args.round_budget))
