@@ -67,8 +67,9 @@ def parse():
     ap.add_argument("--frames-per-launch", type=int, default=16,
                     help="independent frames (own jitter seeds) rendered by one set of launches "
                          "(vrhip_render_batch); 1 = one frame per launch set")
-    ap.add_argument("--round-budget", type=int, default=48,
-                    help="phase-1 sample rounds per ray when several frames are in flight")
+    ap.add_argument("--round-budget", type=int, default=0,
+                    help="phase-1 sample rounds per ray when several frames are in flight (0 = 48 on one GPU; "
+                         "on several, by the size of a rank's launch set: DESIGN.md 'Multi-GPU')")
     ap.add_argument("--frame-timing", type=int, default=0,
                     help="throughput mode on one GPU: 1 = keep the renderers' own events around every launch set "
                          "(vrhip_set_frame_timing; the region is timed as a whole either way)")
@@ -292,6 +293,17 @@ def main():
     fif = max(1, args.frames_in_flight) if technique == 0 else 1
     fpl = max(1, min(args.frames_per_launch, 32)) if technique == 0 else 1
     throughput = fif > 1 or fpl > 1
+    if args.round_budget <= 0:
+        # One GPU: 48 rounds (rays stay in the leaner one-lane phase while other frames hide its latency).  A rank's
+        # tile share of a short run cannot fill its GPU, and the set's time is the chain of its longest rays: fewer
+        # rounds before the 4-lane phase, by the pixel-frames of a launch set (tools/share_time.py, BUDGET=...:
+        # 8-rank shares of 2 x 10 frames 0.043 -> 0.036 ms per frame with 16-24 rounds, 4 ranks 0.061 -> 0.056 with
+        # 24-32, 2 ranks 0.104 -> 0.095 with 32).  The dense "haze" regime keeps 48 at every size (measured).
+        args.round_budget = 48
+        if multi and throughput and tff_name != "haze":
+            set_frames = -(-min(fpg, args.steps) // fif)
+            p_set = set_frames * len(split.my_tiles) * args.tile * args.tile
+            args.round_budget = 48 if p_set >= (8 << 20) else 32 if p_set >= (4 << 20) else 24 if p_set >= (2 << 20) else 16
     # (in throughput mode this driver only serves the warm-up and the untimed one-frame-at-a-time
     # passes; the timed loop has its own, below)
     sparse = not args.dense_gather

@@ -18,9 +18,9 @@ only = os.environ.get("ONLY")   # e.g. "2x128": one schedule only
 dev = torch.device("cuda", 0)
 vr = VolumeRenderCL(); vr.initialize()
 vr.synthVolume("shells", (2048,) * 3, 0)
-vr.setTransferFunction(frontend.tff_from_stops())
+vr.setTransferFunction(frontend.haze_tff() if os.environ.get("TFF") == "haze" else frontend.tff_from_stops())
 vr.updateView(frontend.view_matrix(frontend.quat_from_axis_angle((1, 1, 0), 30.0)))
-vr.setRoundBudget(48)
+vr.setRoundBudget(int(os.environ.get("BUDGET", "48")))
 mt = frontend.Mt19937()
 seeds = [mt() for _ in range(16384)]
 twins = [vr] + [vr.shareVolumes() for _ in range(3)]
