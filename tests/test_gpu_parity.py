@@ -2232,3 +2232,46 @@ def test_randomised_batches_of_tile_subsets_equal_their_frames(vr, case):
                 assert np.array_equal(got[f, k, :h, :w], singles[f][y0:y0 + h, x0:x0 + w]), (f, int(t))
     finally:
         _setup(vr, vol, fmt, tff, view)
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_randomised_frame_sequences_match_oracle(vr, case):
+    """Random scenes through the modes that chain frames: image-order ESS (the hit-image ping-pong over three
+    frames, with whatever shading / filtering the scene drew) or progressive accumulation (the running mean over
+    three iterations with their own jitter seeds), ray caster or path tracer."""
+    rng = np.random.default_rng(33261004 + case)
+    vol, fmt, tff, view, kw, W, H = _random_scene(rng)
+    img_ess = case % 2 == 0
+    technique = 1 if (not img_ess and rng.random() < 0.4) else 0
+    if technique:
+        kw = {k: v for k, v in kw.items() if k in ("seed", "bbox", "thickness", "background", "ortho", "gradient_bg")}
+    else:
+        kw["illum"] = int(rng.integers(0, 6))
+    _setup(vr, vol, fmt, tff, view, technique=technique, img_ess=img_ess, **kw)
+    try:
+        vr.updateOutputImg(W, H)
+        vr.setStatsEnabled(False)
+        if img_ess:
+            hin, hout = vro.hit_image_init(W, H)
+            for frame in range(3):
+                got = vr.runRaycastNoGL(W, H)
+                vr.setIteration(0)
+                cam, rp, rc, pt = common.to_oracle_params(*vr.params())   # (the frame's jitter seed: set when it renders)
+                ref, _, _ = vro.render_tile(vol, fmt, tff, cam, rp, rc, pt, use_ess=kw.get("ess", True), W=W, H=H,
+                                            hit_in=hin, hit_out=hout)
+                assert np.abs(got - ref).max() <= TOL, frame
+                hin, hout = hout, hin
+                g_in, g_out = vr.getImageEss(W, H)
+                assert np.array_equal(g_in, hin) and np.array_equal(g_out, hout), frame
+        else:
+            acc = None
+            for it in range(3):
+                vr.setSeed(int(rng.integers(1, 1 << 32)))
+                vr.setIteration(it)
+                got = vr.runRaycastNoGL(W, H)
+                vr.setIteration(it)
+                ref, _, _ = common.oracle_frame(vr, vol, fmt, tff, W, H, use_ess=kw.get("ess", True), in_accum=acc)
+                assert np.abs(got - ref).max() <= TOL, it
+                acc = ref
+    finally:
+        _setup(vr, vol, fmt, tff, view)

@@ -553,8 +553,11 @@ class VolumeRenderCL:
 
     # ---- test / bench conveniences (not in the reference)
     def setSeed(self, seed):
-        """Pin the per-frame jitter seed (None restores the mt19937 sequence)."""
+        """Pin the per-frame jitter seed (None restores the mt19937 sequence).  params() shows a pinned seed at
+        once, not only after the next frame."""
         self._fixed_seed = None if seed is None else int(seed) & 0xFFFFFFFF
+        if self._fixed_seed is not None:
+            self._rendering.seed = self._fixed_seed
 
     def setIteration(self, it):
         self._rendering.iteration = int(it)
