@@ -174,7 +174,8 @@ def find_profile(kind, key, src_hash):
     paths = glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_%s*.json" % kind))
     for path in sorted(paths, key=lambda q: (-round_no(q), q)):
         try:
-            d = json.load(open(path))
+            with open(path) as f:
+                d = json.load(f)
         except Exception:
             continue
         for entry in d.values():

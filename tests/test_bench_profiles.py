@@ -13,8 +13,9 @@ def _committed(kind):
     import glob
     out = []
     for path in glob.glob(os.path.join(ROOT, "profiles", "r3", "pmc_%s*.json" % kind)):
-        for entry in json.load(open(path)).values():
-            out.append((path, entry))
+        with open(path) as f:
+            for entry in json.load(f).values():
+                out.append((path, entry))
     return out
 
 

@@ -17,7 +17,8 @@ def source_hash():
     files.append(os.path.join(ROOT, "include", "vrhip.h"))
     for f in files:
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
     return h.hexdigest()[:16]
 
 
