@@ -243,8 +243,8 @@ struct RaycastLaunch {
     int format;            // vrhip_format
     int use_ess;
     int instr;             // 0 none, 1 stats, 2 stats + touched bitmap
-    int occ3;              // phase 1 on the ray list at three waves per SIMD (vr_raycast.hip VR_OCC_T): a schedule, not a result
-    int occ3_split;        // the same for phase 2 (which then reads the skip bitmap from L2, like phase 1 at three waves)
+    int occ3;              // phase 1 on the ray list at three waves per SIMD (vr_raycast.hip kWavesWide): a schedule, not a result
+    int occ3_split;        // the same for phase 2
     DevStats *stats;
     uint32_t *touched;
     int num_cus;

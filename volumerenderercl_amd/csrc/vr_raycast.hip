@@ -1199,14 +1199,16 @@ __global__ __launch_bounds__(kBlockDim) void vr_dda_prepass_kernel(
 // 4 * refill_min lanes of the wave are idle (default 64: the whole wave, measured best).  Same per-ray operation sequence as the patch kernel above; no dead
 // lanes carried through a patch, no second DDA walk.  Exit condition reached by every wave: the
 // list head only grows, and every ray ends or is suspended.
-// OCC: 0 = the compiler's choice (two waves per SIMD with these kernels' 176 VGPRs), 3 = three waves per SIMD
-// (<= 168 VGPRs, three to five of them spilled): pays where the march waits for its fetches -- volumes whose
-// ESS bricks are too small for the empty-run lookahead (256^3: -9 % per frame) -- and not where the lookahead
-// keeps the lanes busy with arithmetic (2048^3 "shells": +-0, one frame at a time +11 %).  See launch_variant.
-#define VR_OCC_T(n) __attribute__((amdgpu_waves_per_eu((n) ? (n) : 1, (n) ? (n) : 8)))
+// WAVES: waves per workgroup.  4 (256 threads): the compiler's register choice (184 VGPRs), two workgroups per CU by
+// their 72 KiB of LDS = two waves per SIMD.  12 (768 threads): launch bounds that leave 170 VGPRs (168 used, three to
+// six spilled), ONE workgroup per CU = three waves per SIMD that share one transfer function and one skip bitmap in
+// LDS (60 + 16 + 32 KiB): pays where waves wait more than they issue -- launch sets of several frames, volumes whose
+// ESS bricks are too small for the empty-run lookahead -- and not one frame at a time with the lookahead, where a
+// third wave only stretches the chain of the longest rays.  See launch_variant.
+constexpr int kWavesWide = 12;
 
-template <typename VT, bool SKIP_LDS, bool FP, int OCC = 0>
-__global__ __launch_bounds__(kBlockDim) VR_OCC_T(OCC) void vr_raycast_rays_kernel(
+template <typename VT, bool SKIP_LDS, bool FP, int WAVES = 4>
+__global__ __launch_bounds__(WAVES * 64) void vr_raycast_rays_kernel(
     VolView vv, BrickView bricks, TfView tf, SkipView skip, CellView cells, FrameView fr,
     vrhip_camera_params cam, vrhip_rendering_params rp, vrhip_raycast_params rc)
 {
@@ -1214,11 +1216,11 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC_T(OCC) void vr_raycast_rays_kerne
     if (n_rays == 0) return;
     extern __shared__ float4 s_mem[];
     float *s_stage = reinterpret_cast<float *>(s_mem) + (threadIdx.x >> 6) * kStageFloatsPerWave;
-    float4 *s_tff = s_mem + kStageF4;
+    float4 *s_tff = s_mem + WAVES * kStageFloatsPerWave / 4;
     uint32_t *s_skip = reinterpret_cast<uint32_t *>(s_tff + tf.tff_n);
-    for (uint32_t i = threadIdx.x; i < tf.tff_n; i += kBlockDim) s_tff[i] = tf.tff[i];
+    for (uint32_t i = threadIdx.x; i < tf.tff_n; i += WAVES * 64) s_tff[i] = tf.tff[i];
     if (SKIP_LDS)
-        for (uint32_t i = threadIdx.x; i <= skip.n_words; i += kBlockDim) s_skip[i] = skip.bits[i];
+        for (uint32_t i = threadIdx.x; i <= skip.n_words; i += WAVES * 64) s_skip[i] = skip.bits[i];
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -1627,8 +1629,8 @@ VR_DEV void composite_from(const RayCtx &c, RayDyn &d, const float (&p0)[kBatch]
 // lane replays the compositing of all 16 in ray order, fetching the other lanes' results with
 // in-quad DPP broadcasts -- the fp32 operation sequence per ray is exactly phase 1's (and the
 // reference's), the serial chain of a long ray is 4x shorter.
-template <typename VT, bool ESS, int INSTR, bool SKIP_LDS, bool XS, bool FP, int OCC = 0>
-__global__ __launch_bounds__(kBlockDim) VR_OCC_T(OCC) void vr_raycast_split_kernel(
+template <typename VT, bool ESS, int INSTR, bool SKIP_LDS, bool XS, bool FP, int WAVES = 4>
+__global__ __launch_bounds__(WAVES * 64) void vr_raycast_split_kernel(
     VolView vv, BrickView bricks, TfView tf, SkipView skip, CellView cells, FrameView fr,
     vrhip_camera_params cam, vrhip_rendering_params rp, vrhip_raycast_params rc, DevStats *stats,
     uint32_t *touched)
@@ -1639,11 +1641,11 @@ __global__ __launch_bounds__(kBlockDim) VR_OCC_T(OCC) void vr_raycast_split_kern
     extern __shared__ float4 s_mem[];
     VR_STAMP_DECL;
     float *s_stage = reinterpret_cast<float *>(s_mem) + (threadIdx.x >> 6) * kStageFloatsPerWave;
-    float4 *s_tff = s_mem + kStageF4;
+    float4 *s_tff = s_mem + WAVES * kStageFloatsPerWave / 4;
     uint32_t *s_skip = reinterpret_cast<uint32_t *>(s_tff + tf.tff_n);
-    for (uint32_t i = threadIdx.x; i < tf.tff_n; i += kBlockDim) s_tff[i] = tf.tff[i];
+    for (uint32_t i = threadIdx.x; i < tf.tff_n; i += WAVES * 64) s_tff[i] = tf.tff[i];
     if (ESS && SKIP_LDS)
-        for (uint32_t i = threadIdx.x; i <= skip.n_words; i += kBlockDim) s_skip[i] = skip.bits[i];
+        for (uint32_t i = threadIdx.x; i <= skip.n_words; i += WAVES * 64) s_skip[i] = skip.bits[i];
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -2010,10 +2012,19 @@ __global__ __launch_bounds__(kBlockDim) void vr_hit_resolve_kernel(FrameView fr,
 }
 
 template <typename K>
-hipError_t prepare_variant(K kernel, size_t lds, int *nb_out, const char *what, int num_cus)
+hipError_t prepare_variant(K kernel, size_t lds, int *nb_out, const char *what, int num_cus, int block_dim = kBlockDim)
 {
-    return vr_prepare_kernel(kernel, kBlockDim, lds, nb_out, what, num_cus);
+    return vr_prepare_kernel(kernel, block_dim, lds, nb_out, what, num_cus);
 }
+
+// dynamic LDS of the marching kernels: a stage per wave, the transfer function, the skip bitmap if it is kept there
+inline size_t march_lds(int waves, const RaycastLaunch &a, bool skip_lds)
+{
+    return (size_t)waves * kStageFloatsPerWave * sizeof(float) + (size_t)a.tf.tff_n * sizeof(float4) +
+           (skip_lds ? ((size_t)a.skip.n_words + 1) * sizeof(uint32_t) : 0);
+}
+// does a workgroup of kWavesWide waves with the skip bitmap fit a CU's LDS?
+inline bool wide_fits_lds(const RaycastLaunch &a) { return march_lds(kWavesWide, a, true) <= (size_t)160 * 1024; }
 
 #ifdef VR_EXPERIMENTS   // vr_march_kernel, vr_raycast_staged_kernel and their launchers: A/B builds only
 #include "vr_experiments_kernels.inc"
@@ -2025,17 +2036,18 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
 {
     auto k1 = vr_raycast_kernel<VT, ESS, INSTR, SKIP_LDS, XS, FP>;
     auto k2 = vr_raycast_split_kernel<VT, ESS, INSTR, SKIP_LDS, XS, FP>;
-    // three waves per SIMD (RaycastLaunch::occ3): default kernels on the footprint volume, skip bitmap from L2 (a
-    // third workgroup's LDS has no room for it: launch_typed sends these launches to SKIP_LDS = false)
-    constexpr bool kOcc3 = ESS && INSTR == 0 && !XS && FP && !SKIP_LDS;
-    if (kOcc3 && a.occ3_split) k2 = vr_raycast_split_kernel<VT, ESS, INSTR, SKIP_LDS, XS, FP, kOcc3 ? 3 : 0>;
-    const size_t lds_base = (size_t)kStageF4 * sizeof(float4) + (size_t)a.tf.tff_n * sizeof(float4);
-    const size_t lds_skip = ((size_t)a.skip.n_words + 1) * sizeof(uint32_t);
-    const size_t lds = lds_base + (ESS && SKIP_LDS ? lds_skip : 0);
+    // three waves per SIMD (RaycastLaunch::occ3 / occ3_split): the default kernels on the footprint volume as ONE
+    // workgroup of kWavesWide waves per CU (launch_typed keeps SKIP_LDS for them when the bitmap fits beside 12 stages)
+    constexpr bool kWide = ESS && INSTR == 0 && !XS && FP;
+    const bool wide2 = kWide && a.occ3_split;
+    if (wide2) k2 = vr_raycast_split_kernel<VT, ESS, INSTR, SKIP_LDS, XS, FP, kWide ? kWavesWide : 4>;
+    const int waves2 = wide2 ? kWavesWide : 4;
+    const size_t lds = march_lds(4, a, ESS && SKIP_LDS);
+    const size_t lds2 = march_lds(waves2, a, ESS && SKIP_LDS);
     int nb1 = 0, nb2 = 0;
     {
         hipError_t e = prepare_variant(k1, lds, &nb1, "raycast phase 1", a.num_cus);
-        if (e == hipSuccess) e = prepare_variant(k2, lds, &nb2, "raycast phase 2", a.num_cus);
+        if (e == hipSuccess) e = prepare_variant(k2, lds2, &nb2, "raycast phase 2", a.num_cus, waves2 * 64);
         if (e != hipSuccess) return e;
     }
     const uint32_t cus = (uint32_t)(a.num_cus > 0 ? a.num_cus : 256);
@@ -2070,19 +2082,25 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
         return launch_march<VT, SKIP_LDS, FP>(a, frame, block, cus, stream);   // the whole frame in one launch
 #endif
     if (ESS && INSTR == 0 && !XS && frame.live && frame.live_rays) {   // phase 1 on the ray list
-        // phase 1 picks its own schedule: skip bitmap in LDS at two waves per SIMD, from L2 at two or three
-        constexpr bool kOcc3R = FP;   // (three waves: footprint volume only)
-        const bool r3 = kOcc3R && a.occ3;
-        const bool rlds = a.skip.in_lds != 0 && !r3;
+        // phase 1 picks its own schedule: two or three waves per SIMD (three: footprint volume only), the skip
+        // bitmap in LDS whenever it fits
+        constexpr bool kWideR = FP;
+        const bool r3 = kWideR && a.occ3;
+        const bool rlds = a.skip.in_lds != 0 && (!r3 || wide_fits_lds(a));
+        const int waves_r = r3 ? kWavesWide : 4;
         auto kr = vr_raycast_rays_kernel<VT, false, FP>;
-        if (r3) kr = vr_raycast_rays_kernel<VT, false, FP, kOcc3R ? 3 : 0>;
-        else if (rlds) kr = vr_raycast_rays_kernel<VT, true, FP>;
-        const size_t lds_r = lds_base + (rlds ? lds_skip : 0);
+        if (r3) {
+            kr = vr_raycast_rays_kernel<VT, false, FP, kWideR ? kWavesWide : 4>;
+            if (rlds) kr = vr_raycast_rays_kernel<VT, true, FP, kWideR ? kWavesWide : 4>;
+        } else if (rlds) {
+            kr = vr_raycast_rays_kernel<VT, true, FP>;
+        }
+        const size_t lds_r = march_lds(waves_r, a, rlds);
         int nbr = 0;
-        e = prepare_variant(kr, lds_r, &nbr, "raycast phase 1 (ray list)", a.num_cus);
+        e = prepare_variant(kr, lds_r, &nbr, "raycast phase 1 (ray list)", a.num_cus, waves_r * 64);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kr, dim3(cus * (uint32_t)nbr), block, lds_r, stream, a.vol, a.bricks, a.tf, a.skip,
-                           a.cells, frame, a.cam, a.render, a.raycast);
+        hipLaunchKernelGGL(kr, dim3(cus * (uint32_t)nbr), dim3(waves_r * 64), lds_r, stream, a.vol, a.bricks, a.tf,
+                           a.skip, a.cells, frame, a.cam, a.render, a.raycast);
     } else {
         hipLaunchKernelGGL(k1, grid, block, lds, stream, a.vol, a.bricks, a.tf, a.skip, a.cells, frame, a.cam,
                            a.render, a.raycast, a.stats, a.touched);
@@ -2101,7 +2119,7 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
     }
     // phase 2: persistent grid; exits at once when nothing was suspended
     dim3 grid2(cus * (uint32_t)nb2);
-    hipLaunchKernelGGL(k2, grid2, block, lds, stream, a.vol, a.bricks, a.tf, a.skip, a.cells, frame, a.cam,
+    hipLaunchKernelGGL(k2, grid2, dim3(waves2 * 64), lds2, stream, a.vol, a.bricks, a.tf, a.skip, a.cells, frame, a.cam,
                        a.render, a.raycast, a.stats, a.touched);
     return hipGetLastError();
 }
@@ -2109,7 +2127,8 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
 template <typename VT>
 hipError_t launch_typed(const RaycastLaunch &a, hipStream_t stream)
 {
-    const bool lds = a.skip.in_lds != 0 && !a.occ3_split;   // (phase 2 and the patch kernels; phase 1 on the ray list: launch_variant)
+    // (phase 2 and the patch kernels; phase 1 on the ray list: launch_variant)
+    const bool lds = a.skip.in_lds != 0 && (!a.occ3_split || wide_fits_lds(a));
     // the rarely used shading modes 2-5, contours, the depth cue and nearest filtering live in kernel
     // variants of their own (XS), so that their code and registers do not tax the default ones
     const bool xs = a.render.illumType >= 2 || a.raycast.useAO != 0 || a.render.showEss != 0 ||

@@ -901,13 +901,14 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
     a->format = r->format;
     a->use_ess = r->use_ess ? 1 : 0;
     a->instr = r->stats_enabled ? 1 : 0;
-    // Three waves per SIMD (skip bitmap from L2 instead of LDS) where waves wait more than they issue:
+    // Three waves per SIMD -- one workgroup of 12 waves per CU that share one transfer function and one skip bitmap
+    // in LDS, 168 VGPRs per lane (vr_raycast.hip kWavesWide) -- where waves wait more than they issue:
     //  * volumes whose ESS bricks are too small for the empty-run lookahead (ray_skip_empty): the march waits for its
-    //    fetches instead of stepping over empty cells (256^3: -9 % per frame, -6 % one frame at a time);
-    //  * launch sets of several frames (the throughput schedule, a rank's tile share): enough rays for a third
-    //    workgroup per CU, and no chain of one frame's longest rays that a third wave would stretch (2048^3, 16 frames
-    //    per set and two renderers: "shells" -2.5 ... -4 %, "haze" -5 %, an 8-rank tile share -3 ... -5 %; both phases
-    //    at three waves -- one of them alone gains half of it or nothing).
+    //    fetches instead of stepping over empty cells (256^3: -12 % per frame, -6 % one frame at a time);
+    //  * launch sets of several frames (the throughput schedule, a rank's tile share): enough rays for a third wave
+    //    per SIMD, and no chain of one frame's longest rays that a third wave would stretch (2048^3, 16 frames per
+    //    set and two renderers: "shells" -6 %, "haze" -8 %, 1024^3 USHORT -8 %; both phases -- one of them alone
+    //    gains half of it or nothing).
     // One frame at a time with the lookahead: two waves ("shells" +10 % with three, the longest rays' chain).
     // VRHIP_OCC=2|3 forces both phases, VRHIP_OCC_P1 / VRHIP_OCC_P2 one of them (tools/ab_env.sh).
     const bool three = r->use_ess && (!ray_skip_empty(r) || r->queue_frames >= 4u);
