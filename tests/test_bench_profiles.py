@@ -34,7 +34,7 @@ def test_profiles_describe_themselves():
 
 def test_a_profile_is_used_only_for_its_own_schedule_and_sources():
     path, e = next((p, e) for p, e in _committed("issue") if e["meta"]["workload"] == "shells2048"
-                   and e["meta"]["frames_per_launch"] == 16)
+                   and e["meta"]["frames_per_launch"] >= 16)   # (the default throughput schedule's profile)
     m = e["meta"]
     key = bench.schedule_key(m["workload"], m["viewport"], m["view"], m["frames_in_flight"], m["frames_per_launch"],
                              m["round_budget"])
