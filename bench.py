@@ -96,10 +96,9 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(vr, vol_host, bricks_host, tff, fmt, W, H, target_s, seeds, use_ess=True):
-    """Oracle (CPU restatement: scalar fp32 C, OpenMP over 8-pixel row chunks) timed on whole
-    frames of the same workload -- the timed frames' own jitter seeds, one after the other --
-    until ~target_s seconds of CPU work have been spent (bounded: at most len(seeds) frames)."""
+def oracle_renderer(vr, vol_host, bricks_host, tff, fmt, W, H, use_ess=True):
+    """render(seed) -> (image, work counters): the oracle (CPU restatement: scalar fp32 C, OpenMP over 8-pixel row
+    chunks) on the renderer's own kernel-argument structs, iteration 0.  The checker, and the cpu_baseline leg."""
     from oracle import vro
     cam, rp, rc, pt = vr.params()
     ocam = vro.CameraParams.from_buffer_copy(bytes(cam))
@@ -108,22 +107,33 @@ def cpu_baseline(vr, vol_host, bricks_host, tff, fmt, W, H, target_s, seeds, use
     opt = vro.PathtraceParams.from_buffer_copy(bytes(pt))
     prefix = vro.prefix_sum(tff)
     cores = host_cpu_share()
-    frames, samples, secs = 0, 0, 0.0
-    first = None
-    for seed in seeds:
+
+    def render(seed):
         orp.seed = seed
         orp.iteration = 0
-        t0 = time.perf_counter()
         img, st, _ = vro.render_tile(vol_host, fmt, tff, ocam, orp, orc, opt, use_ess=use_ess,
                                      W=W, H=H, bricks=bricks_host, prefix=prefix, threads=cores)
+        return img, st
+    return render, cores
+
+
+def cpu_baseline(render, cores, target_s, seeds, keep=()):
+    """The oracle timed on whole frames of the same workload -- the timed frames' own jitter seeds, one after the
+    other -- until ~target_s seconds of CPU work have been spent (bounded: at most len(seeds) frames).  Returns the
+    frames of the seeds in `keep` (and of the first seed) for the parity check, and the cpu_baseline object."""
+    frames, samples, secs = 0, 0, 0.0
+    kept = {}
+    for seed in seeds:
+        t0 = time.perf_counter()
+        img, st = render(seed)
         secs += time.perf_counter() - t0
-        if first is None:
-            first = (seed, img, st)     # the checker's frame for the first timed seed
+        if frames == 0 or seed in keep:
+            kept[seed] = (img, st)
         samples += st["samples_taken"]
         frames += 1
         if secs >= target_s:
             break
-    return first, {
+    return kept, {
         "value": samples / secs / 1e6 if secs > 0 else 0.0,
         "unit": "Msamples/s",
         "cores": int(cores),
@@ -134,24 +144,31 @@ def cpu_baseline(vr, vol_host, bricks_host, tff, fmt, W, H, target_s, seeds, use
     }
 
 
+_BUILT_HASH = None
+
+
 def source_hash():
     """sha256 (16 hex digits) over the kernel sources the measured code is built from
-    (volumerenderercl_amd/csrc/*.hip, *.h and the C ABI header): a committed PMC profile is only used
-    for a roofline figure when it was taken from the same sources, and a library built from other
-    sources than the tree holds is not measured at all (check_library_sources)."""
+    (volumerenderercl_amd/csrc/*.hip, *.h, *.inc and the C ABI header), as the loaded library reports it -- an A/B
+    build with extra compile flags carries "+<flags hash>" behind it (volumerenderercl_amd/_srchash.py).  A committed
+    PMC profile is only used for a roofline figure when it was taken from the same build, and a library built from
+    other sources than the tree holds is not measured at all (check_library_sources)."""
     from volumerenderercl_amd import _srchash
-    return _srchash.source_hash()
+    return _BUILT_HASH or _srchash.source_hash()
 
 
 def check_library_sources(lib):
     """The loaded libvrhip.so carries the hash of the sources it was built from: a stale build (sources edited or
     reverted without a rebuild) would be measured under the tree's name otherwise."""
+    global _BUILT_HASH
     import ctypes
+    from volumerenderercl_amd import _srchash
     lib.vrhip_build_source_hash.restype = ctypes.c_char_p
-    built, tree = lib.vrhip_build_source_hash().decode(), source_hash()
-    if built != tree:
+    built, tree = lib.vrhip_build_source_hash().decode(), _srchash.source_hash()
+    if built.split("+")[0] != tree:
         raise SystemExit("bench.py: libvrhip.so was built from kernel sources %s, the tree holds %s -- rebuild "
                          "(python -c 'import __graft_entry__ as g; g.build()') before measuring" % (built, tree))
+    _BUILT_HASH = built
 
 
 def schedule_key(workload, viewport, view, fif, fpl, round_budget):
@@ -432,6 +449,33 @@ def main():
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
     wall = float(wall_t.item())
 
+    # ---- the timed region's own output, copied to the host before anything else renders: the frames the
+    # oracle is asked about below (parity.timed_frames) and what the last timed launch set launched
+    timed_frames, timed_info = [], None      # [(label, jitter seed, host image)]
+    set_frames_used = max(len(b_) for b_ in blocks) if throughput else 1
+    if rank == 0 and technique == 0 and not args.profile_region:
+        def pick(label, k, tensor):
+            if all(k != k_ for _, k_, _ in timed_frames):
+                timed_frames.append((label, k, tensor.detach().cpu().numpy().copy()))
+        if not multi and throughput:
+            # every renderer's output block still holds the last launch set it rendered
+            last_of_lane = {j % fif: j for j in range(len(blocks))}
+            j_first, j_last = min(last_of_lane.values()), len(blocks) - 1
+            for j, i in ((j_first, 0), (j_last, len(blocks[j_last]) - 1)):
+                pick("timed frame %d: frame %d of %d in launch set %d of %d (renderer %d)"
+                     % (blocks[j][i], i, len(blocks[j]), j, len(blocks), j % fif), blocks[j][i], lanes[j % fif][2][i])
+            timed_info = lanes[j_last % fif][0].lastLaunchInfo()
+        elif not multi:
+            pick("timed frame %d (the last of the region)" % (args.steps - 1), args.steps - 1, frame)
+            timed_info = vr.lastLaunchInfo()
+        else:
+            n_last = len(chunks[-1])
+            for i in (0, n_last - 1):
+                pick("timed frame %d: frame %d of %d of the last gathered batch, assembled on rank 0"
+                     % (chunks[-1][i], i, n_last), chunks[-1][i], frames[i])
+            timed_info = vr.lastLaunchInfo()
+        timed_frames = [(label, seeds[args.warmup + k], img) for label, k, img in timed_frames]
+
     if args.profile_region:
         # nothing but warm-up + timed launches has run: for rocprofv3 --kernel-trace --stats / --pmc
         if rank == 0:
@@ -441,10 +485,13 @@ def main():
                 "avg_launch_ms": gpu_region_s / args.steps * 1e3,
                 "viewport": W, "view": args.view, "source_hash": source_hash(),
                 "head": os.environ.get("VRHIP_HEAD"),
-                "frames_in_flight": fif, "frames_per_launch": max(len(b_) for b_ in blocks) if throughput else 1,
+                "frames_in_flight": fif, "frames_per_launch": set_frames_used,
                 "round_budget": args.round_budget if throughput else 10,
                 "launch_sets_in_region": len(blocks) if (not multi and throughput) else args.steps,
-                "note": "timed region only; work counters, roofline and cpu_baseline come from the full run"})
+                "warmup_launch_sets": (args.warmup + (fif if throughput else 0)) if not multi else None,
+                "note": "warm-up + timed region and nothing else: the process's kernel dispatches are the warm-up's "
+                        "(`warmup` single frames, then one launch set per renderer in throughput mode) followed by "
+                        "the timed launch sets; work counters, roofline and cpu_baseline come from the full run"})
             emit(line)
             if args.out_json:
                 open(args.out_json, "w").write(line + "\n")
@@ -530,8 +577,7 @@ def main():
         kernel_s = gpu_region_s / args.steps if not multi else last_kernel_s / last_set_frames
         achieved = alg_bytes / kernel_s / 1e9
         src = source_hash()
-        key = schedule_key(args.workload, W, args.view, fif, max(len(b_) for b_ in blocks) if throughput else 1,
-                           args.round_budget if throughput else 10)
+        key = schedule_key(args.workload, W, args.view, fif, set_frames_used, args.round_budget if throughput else 10)
         traffic, traffic_stale = find_profile("traffic", key, src) if not multi else (None, None)
         hbm_traffic = traffic["hbm_bytes_per_pass"] if traffic else None
         # a fraction of the HBM peak is only printed when the counters agree that the kernel moves at
@@ -558,17 +604,17 @@ def main():
             "algorithmic_bytes_note": alg_note,
             "avg_launch_ms": kernel_s * 1e3,
             "frames_in_flight": fif,
-            "frames_per_launch": max(len(b_) for b_ in blocks) if throughput else 1,
+            "frames_per_launch": set_frames_used,
             "round_budget": args.round_budget if throughput else 10,
             "viewport": W, "view": args.view, "source_hash": src,
             "serial_launch_ms": serial_s * 1e3 if serial_s else None,
             "launch_note": ("%d renderer(s) on as many streams over one shared volume, each rendering up to %d independent "
-                            "frames (own jitter seeds) per set of launches (vrhip_render_batch): avg_launch_ms = "
+                            "frames (own jitter seeds) per set of launches (vrhip_render_batch; this run: sets of %d): avg_launch_ms = "
                             "HIP-event time of the timed region / frames (the renderers' own events around each "
                             "set off unless --frame-timing 1), phase-1 round budget %d (throughput "
                             "schedule); serial_launch_ms = the same frames one at a time with the single-frame "
                             "schedule (budget 10), which is what a rocprofv3 kernel trace of `--frames-in-flight 1 "
-                            "--frames-per-launch 1` sums to" % (fif, fpl, args.round_budget))
+                            "--frames-per-launch 1` sums to" % (fif, fpl, set_frames_used, args.round_budget))
                            if throughput else "one frame at a time",
             "last_pass_ms_hip_events": {"phase1": last_phases[0] * 1e3, "phase2": last_phases[1] * 1e3,
                                         "total": last_kernel_s * 1e3},
@@ -599,29 +645,46 @@ def main():
                 "valu_lane_utilisation": issue.get("valu_lane_utilisation"),
                 "source": issue.get("file"),
                 "profile_meta": issue.get("meta"),
-                "note": "SQ_INSTS_VALU of the timed launches (rocprofv3 --pmc of `bench.py --profile-region` with this "
-                        "run's workload, viewport, schedule and kernel sources, committed under profiles/) / frames, "
-                        "over this run's avg_launch_ms",
+                "note": "SQ_INSTS_VALU of the warm-up + timed launches of `bench.py --profile-region` (rocprofv3 --pmc, with "
+                        "this run's workload, viewport, schedule and kernel sources, committed under profiles/; the warm-up's "
+                        "launch sets render frames of the same schedule, its `warmup` single frames ride along) / all the "
+                        "frames those launches rendered, over this run's avg_launch_ms",
             }
         elif issue_stale:
             roofline_valu = {"bound": "valu_issue", "achieved": None, "frac": None, "stale_profile": issue_stale,
                              "note": "no committed PMC profile matches this run's schedule and kernel sources "
                                      "(tools/profile_region.sh regenerates it)"}
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
+            # ---- the oracle: the cpu_baseline leg (N = 1 only) and the checker
             vol_host = vr.downloadVolume()
             bricks_host = vr.downloadBricks()
-            cpu_seeds = seeds[args.warmup:] + [mt() for _ in range(2000)]   # bounded by cpu_seconds
-            first, cpu = cpu_baseline(vr, vol_host, bricks_host, tff, fmt, W, H, args.cpu_seconds,
-                                      cpu_seeds, use_ess=ess)
+            orender, cores = oracle_renderer(vr, vol_host, bricks_host, tff, fmt, W, H, use_ess=ess)
+            seed0 = seeds[args.warmup]
+            kept = {}
+            if world == 1:
+                cpu_seeds = seeds[args.warmup:] + [mt() for _ in range(2000)]   # bounded by cpu_seconds
+                kept, cpu = cpu_baseline(orender, cores, args.cpu_seconds, cpu_seeds,
+                                         keep=[sd for _, sd, _ in timed_frames])
+            for sd in [seed0] + [sd for _, sd, _ in timed_frames]:
+                if sd not in kept:
+                    kept[sd] = orender(sd)     # (untimed: a frame the baseline leg did not reach)
             del vol_host
-            # ---- the checker's frame for the first timed seed against the GPU's: the production
-            # kernels' image and the instrumented kernels' image + six work counters (technique 1
-            # chains its frames through the running mean: iteration 0 = a frame on its own)
-            seed0, ref_img, ref_st = first
+            # ---- (1) the frames the timed region itself produced -- the launch sets of the benchmark, with their
+            # schedule (frames per set, round budget, waves per workgroup, lookahead: `timed_launch`) -- against the
+            # oracle's frames of the same jitter seeds
+            checked = []
+            for label, sd, img in timed_frames:
+                checked.append({"frame": label, "seed": int(sd),
+                                "max_abs_diff": float(np.abs(img.astype(np.float64) - kept[sd][0]).max())})
+            # ---- (2) one frame on its own for the first timed seed: the production (un-instrumented) kernels'
+            # image and the instrumented kernels' image + six work counters (technique 1 chains its frames
+            # through the running mean: iteration 0 = a frame on its own)
+            ref_img, ref_st = kept[seed0]
             vr.setSeed(seed0)
             vr.setIteration(0)
             vr.setStatsEnabled(False)
             gpu_img = vr.runRaycastNoGL(W, H)
+            single_info = vr.lastLaunchInfo()
             vr.setIteration(0)
             vr.setStatsEnabled(True)
             gpu_img_i = vr.runRaycastNoGL(W, H)
@@ -629,13 +692,23 @@ def main():
             vr.setStatsEnabled(False)
             if technique == 1:   # the path tracer's brick counters count its culling, not bricks
                 gpu_st = dict(gpu_st, bricks_visited=0, bricks_skipped=0)
+            single = float(max(np.abs(gpu_img.astype(np.float64) - ref_img).max(),
+                               np.abs(gpu_img_i.astype(np.float64) - ref_img).max()))
             parity = {
-                "max_abs_diff": float(max(np.abs(gpu_img.astype(np.float64) - ref_img).max(),
-                                          np.abs(gpu_img_i.astype(np.float64) - ref_img).max())),
+                "max_abs_diff": max([single] + [c["max_abs_diff"] for c in checked]),
                 "tolerance": 1e-4,
                 "counters_equal": gpu_st == ref_st,
-                "frame": "first timed seed %d, %dx%d, production (un-instrumented) and instrumented "
-                         "kernels vs the oracle frame of the cpu_baseline leg" % (seed0, W, H),
+                "timed_frames": checked,
+                "timed_launch": timed_info,
+                "single_frame": {"seed": int(seed0), "max_abs_diff": single, "launch": single_info},
+                "frame": ("%d frame(s) of the timed region itself (copied from the renderers' output blocks when the "
+                          "region ended) and, rendered on its own, the first timed seed %d through the production "
+                          "(un-instrumented) and the instrumented kernels (+ six work counters), %dx%d, each against "
+                          "the oracle's frame of the same seed" % (len(checked), seed0, W, H))
+                         if checked else
+                         ("first timed seed %d at iteration 0, %dx%d, production (un-instrumented) and instrumented "
+                          "kernels vs the oracle frame (the timed launches are this kernel at iterations 0..%d of the "
+                          "running mean)" % (seed0, W, H, args.steps - 1)),
             }
 
     if rank == 0:
@@ -668,7 +741,8 @@ def main():
                                "gather per %d frames (one gather in flight)" % (
                                    args.tile, args.tile, world, fif, fpg)
                                if multi else "single GPU, full frames, %d renderer(s) x %d frames per "
-                                                 "launch set" % (fif, fpl),
+                                                 "launch set (%d launch sets in the timed region)" % (
+                                                     fif, set_frames_used, len(blocks) if throughput else args.steps),
             },
             "value_note": "samples TAKEN = inner-loop bodies the reference executes after ESS/ERT; those that lie in "
                           "provably empty cells (opacity exactly 0) are stepped over without a voxel fetch and still "

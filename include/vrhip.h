@@ -274,6 +274,32 @@ int vrhip_set_phase_timing(vrhip_renderer *r, int enabled);
  * VRHIP_ERR_NODATA. */
 int vrhip_set_frame_timing(vrhip_renderer *r, int enabled);
 
+/* What the last render call launched (no reference counterpart; filled by the launchers themselves, not
+ * re-derived): the tests and bench.py assert that the kernel instantiation and schedule they mean to check
+ * are the ones that ran -- e.g. that the timed frames of the benchmark and the frames compared with the
+ * oracle came out of the same kernels. */
+typedef struct vrhip_launch_info {
+    uint32_t technique;      /* 0 ray caster, 1 path tracer                                             */
+    uint32_t frames;         /* frames of the launch set (vrhip_render_batch), else 1                   */
+    uint32_t work_items;     /* 8x8 patches in the work queue, all frames                               */
+    uint32_t prepass;        /* 1: vr_dda_prepass_kernel ran                                            */
+    uint32_t ray_list;       /* 1: phase 1 = vr_raycast_rays_kernel on the pre-pass's ray list          */
+    uint32_t phase1_waves;   /* waves per workgroup of the phase-1 kernel: 4, or 12 (three per SIMD)    */
+    uint32_t phase2_waves;   /* the same for vr_raycast_split_kernel; 0: single phase                   */
+    uint32_t round_budget;   /* phase-1 sample rounds per ray, 0 = single phase                         */
+    uint32_t footprint;      /* 1: the kernels read the footprint volume                                */
+    uint32_t empty_skip;     /* 1: the empty-run lookahead is on (cell grid handed to the kernels)      */
+    uint32_t skip_in_lds;    /* 1: the ESS skip bitmap is staged in LDS (phase 1)                       */
+    uint32_t instrumented;   /* 0 production kernels, 1 work counters, 2 / 3 + touched bitmap           */
+    uint32_t extras;         /* 1: the variants with the rarer modes (illumType 2-5, AO, contours, ...) */
+    uint32_t patch_classes;  /* 1: the pre-pass used per-patch classes                                  */
+    uint32_t sorted_phase2;  /* 1: suspended rays were counting-sorted, longest first                   */
+    uint32_t direct_long;    /* 1: rays predicted long went straight to the 4-lane kernel               */
+    uint32_t reserved[16];
+} vrhip_launch_info;
+/* VRHIP_ERR_NODATA before the first render call. */
+int vrhip_last_launch_info(const vrhip_renderer *r, vrhip_launch_info *out);
+
 /* ---- measurement helpers ------------------------------------------- */
 /* When enabled, render calls run the instrumented kernel variant that accumulates
  * vrhip_stats (one atomic per wave). */

@@ -1115,11 +1115,13 @@ def test_time_series_steps_match_oracle(vr):
         assert np.array_equal(again, frames[2])
 
 
-@pytest.mark.parametrize("kind,fmt", [("shells", UCHAR), ("sphere", USHORT)])
-def test_midsize_synthetic_volume_matches_oracle(vr, kind, fmt):
+@pytest.mark.parametrize("kind,fmt,ess,illum", [("shells", UCHAR, True, 1), ("sphere", USHORT, True, 1),
+                                                ("sphere", UCHAR, False, 0)])
+def test_midsize_synthetic_volume_matches_oracle(vr, kind, fmt, ess, illum):
     """256^3 synthetic fields (SURVEY 8d formulas, generated on the GPU and by the oracle): brick
     edge 4, many micro-brick rows, the cell grid at 32^3 cells, the footprint volume with 65^3
-    micro-bricks of entries -- instrumented and default kernels against the oracle."""
+    micro-bricks of entries -- instrumented and default kernels against the oracle.  The third case is
+    BASELINE config 1's exact conjunction: 256^3 UCHAR sphere, no shading, no ESS."""
     res = (256, 256, 256)
     vol = vro.synth_volume(kind, list(res), fmt)
     tff = common.tffs()["default"]
@@ -1128,9 +1130,9 @@ def test_midsize_synthetic_volume_matches_oracle(vr, kind, fmt):
     np.testing.assert_array_equal(vr.downloadVolume(0), vol)
     vr.setTransferFunction(tff)
     vr.setSeed(SEED)
-    for name, val in (("setIllumination", 1), ("setLinearInterpolation", True), ("setCamOrtho", False),
+    for name, val in (("setIllumination", illum), ("setLinearInterpolation", True), ("setCamOrtho", False),
                       ("setUseGradient", False), ("setContours", False), ("setAerial", False),
-                      ("setObjEss", True), ("setAmbientOcclusion", False), ("setTechnique", 0),
+                      ("setObjEss", ess), ("setAmbientOcclusion", False), ("setTechnique", 0),
                       ("setShowESS", False), ("setImgEss", False)):
         getattr(vr, name)(val)
     vr.updateSamplingRate(1.5)
@@ -1138,12 +1140,70 @@ def test_midsize_synthetic_volume_matches_oracle(vr, kind, fmt):
     vr.params()[1].backgroundColor[:] = [1.0, 1.0, 1.0, 1.0]
     vr.updateView(common.views()["rot30"])
     vr.setIteration(0)
-    got, ref, stats = _compare(vr, vol, fmt, tff, W, H)
-    assert stats["bricks_skipped"] > 0 and stats["samples_shaded"] > 0
+    got, ref, stats = _compare(vr, vol, fmt, tff, W, H, ess=ess)
+    if ess:
+        assert stats["bricks_skipped"] > 0 and stats["samples_shaded"] > 0
+    else:
+        assert stats["bricks_visited"] == 0 and stats["samples_shaded"] == 0 and stats["samples_taken"] > 0
     vr.setStatsEnabled(False)
     plain = vr.runRaycastNoGL(W, H)
+    li = vr.lastLaunchInfo()
+    assert li["instrumented"] == 0 and li["extras"] == 0 and li["footprint"] == 1 and li["ray_list"] == (1 if ess else 0)
     vr.setIteration(0)
     assert np.array_equal(plain, got)
+    vr.setObjEss(True)
+    vr.setIllumination(1)
+
+
+def _timed_schedule_batches_match_oracle(r, vol, fmt, tff, ref_bricks, W, H, n_seeds=6):
+    """The benchmark's throughput schedule -- two renderers over one shared volume, each rendering its frames as
+    ONE launch set (vrhip_render_batch) with a phase-1 round budget of 48 -- at a volume size where that means the
+    12-wave marching kernels (three waves per SIMD) WITH the empty-run lookahead: the instantiation bench.py's
+    timed region runs, and the one no single-frame test reaches (a set of >= 4 frames, ESS bricks >= 16 voxels).
+    Every frame of both sets against the oracle's frame of its jitter seed."""
+    import torch
+
+    dev = torch.device("cuda")
+    mt = frontend.Mt19937(77)
+    seeds = [mt() for _ in range(2 * n_seeds)]
+    cam, rp, rc, pt = common.to_oracle_params(*r.params())
+    refs = []
+    for sd in seeds:
+        rp.seed, rp.iteration = sd, 0
+        refs.append(vro.render_tile(vol, fmt, tff, cam, rp, rc, pt, W=W, H=H, bricks=ref_bricks)[0])
+    r.setStatsEnabled(False)
+    r.setRoundBudget(48)
+    twin = r.shareVolumes()
+    try:
+        outs = []
+        for k, x in enumerate((r, twin)):
+            out = torch.zeros((n_seeds, H, W, 4), dtype=torch.float32, device=dev)
+            x.setFrameTiming(False)
+            x.render_batch(W, H, seeds[k * n_seeds:(k + 1) * n_seeds], out.data_ptr())   # both sets in flight
+            outs.append(out)
+        torch.cuda.synchronize()
+        for k, x in enumerate((r, twin)):
+            li = x.lastLaunchInfo()
+            assert li["frames"] == n_seeds and li["round_budget"] == 48 and li["prepass"] == 1 and li["ray_list"] == 1, li
+            assert li["phase1_waves"] == 12 and li["phase2_waves"] == 12 and li["empty_skip"] == 1, li
+            assert li["footprint"] == 1 and li["instrumented"] == 0 and li["extras"] == 0 and li["skip_in_lds"] == 1, li
+            got = outs[k].cpu().numpy()
+            for i in range(n_seeds):
+                d = np.abs(got[i].astype(np.float64) - refs[k * n_seeds + i])
+                assert d.max() <= TOL, "renderer %d, frame %d of its launch set: %g at %s" % (
+                    k, i, d.max(), np.unravel_index(d.argmax(), d.shape))
+        # the same kernels, second sets on both renderers (control blocks alternate, cost map primed)
+        for k, x in enumerate((twin, r)):
+            x.render_batch(W, H, seeds[k * n_seeds:(k + 1) * n_seeds], outs[k].data_ptr())
+        torch.cuda.synchronize()
+        for k in range(2):
+            got = outs[k].cpu().numpy()
+            for i in range(n_seeds):
+                assert np.abs(got[i].astype(np.float64) - refs[k * n_seeds + i]).max() <= TOL, (k, i)
+    finally:
+        twin.close()
+        r.setFrameTiming(True)
+        r.setRoundBudget(10)
 
 
 def test_headline_size_volume_matches_oracle():
@@ -1195,6 +1255,9 @@ def test_headline_size_volume_matches_oracle():
         n, bm = r.countTouched(W, H, want_bitmap=True)
         np.testing.assert_array_equal(bm, ref_bm)
         assert n == int(np.unpackbits(ref_bm).sum()) and n > 0
+        r.setSeed(SEED)
+        r.setIteration(0)
+        _timed_schedule_batches_match_oracle(r, vol, UCHAR, tff, ref_bricks, 256, 192)
         _config4_tile_split_at_size(r, vol, tff, ref_bricks)
     finally:
         r.close()
@@ -1308,6 +1371,92 @@ def test_config3_size_volume_matches_oracle():
                 assert np.abs(got.astype(np.float64) - ref).max() <= TOL, "seed=%d stats=%s" % (seed, stats)
                 if stats:
                     assert r.getStats() == rstats
+        r.setIteration(0)
+        _timed_schedule_batches_match_oracle(r, vol, USHORT, tff, ref_bricks, 224, 160)
+    finally:
+        r.close()
+
+
+def test_midsize_volume_with_the_forced_lookahead_at_three_waves(monkeypatch):
+    """256^3 (ESS bricks of 4 voxels: the lookahead is off by default there) with VRHIP_EMPTY_SKIP=1 and
+    VRHIP_OCC=3: the 12-wave kernels with the empty-run lookahead on a SINGLE frame and on a launch set --
+    a conjunction the defaults never pick at this size -- against the oracle."""
+    import torch
+
+    monkeypatch.setenv("VRHIP_EMPTY_SKIP", "1")
+    monkeypatch.setenv("VRHIP_OCC", "3")
+    res = (256, 256, 256)
+    vol = vro.synth_volume("shells", list(res), UCHAR)
+    tff = common.tffs()["default"]
+    W, H = 200, 152
+    r = VolumeRenderCL()
+    r.initialize()
+    try:
+        r.synthVolume("shells", res, UCHAR)
+        r.setTransferFunction(tff)
+        r.updateView(common.views()["rot30"])
+        r.setSeed(SEED)
+        r.setIteration(0)
+        got, ref, stats = _compare(r, vol, UCHAR, tff, W, H)
+        li = r.lastLaunchInfo()     # (the production frame of _compare)
+        assert li["phase1_waves"] == 12 and li["phase2_waves"] == 12 and li["empty_skip"] == 1 and li["frames"] == 1, li
+        mt = frontend.Mt19937(5)
+        seeds = [mt() for _ in range(5)]
+        out = torch.zeros((len(seeds), H, W, 4), dtype=torch.float32, device="cuda")
+        r.setRoundBudget(48)
+        r.render_batch(W, H, seeds, out.data_ptr())
+        torch.cuda.synchronize()
+        li = r.lastLaunchInfo()
+        assert li["phase1_waves"] == 12 and li["empty_skip"] == 1 and li["frames"] == 5 and li["round_budget"] == 48, li
+        bat = out.cpu().numpy()
+        for i, sd in enumerate(seeds):
+            r.setSeed(sd)
+            r.setIteration(0)
+            ref_i, _, _ = common.oracle_frame(r, vol, UCHAR, tff, W, H)
+            assert np.abs(bat[i].astype(np.float64) - ref_i).max() <= TOL, i
+    finally:
+        r.close()
+
+
+@pytest.mark.parametrize("size", [(640, 160), (160, 640), (456, 152)])
+def test_patch_classes_on_frames_that_are_not_square(size):
+    """The jitter moves a ray by up to max(gsx, gsy) / gs pixels along an axis (volumeraycast.cl:625-628): on a 4:1
+    or 1:4 frame by four pixels along the short axis.  The pre-pass's patch classes (background patches written
+    without a ray) must hold for every such ray: launch sets of frames with different jitter seeds, and single
+    frames, against the oracle -- along the silhouette of the box and next to the outermost shell."""
+    import torch
+
+    W, H = size
+    res = (256, 256, 256)
+    vol = vro.synth_volume("shells", list(res), UCHAR)
+    tff = common.tffs()["default"]
+    r = VolumeRenderCL()
+    r.initialize()
+    try:
+        r.synthVolume("shells", res, UCHAR)
+        r.setTransferFunction(tff)
+        # background alpha 1: a ray that misses the box keeps it (:655), a class-1 patch's rays end with alpha 0
+        r.params()[1].backgroundColor[:] = [0.25, 0.5, 0.75, 1.0]
+        for view in ("rot30", "default"):
+            r.updateView(common.views()[view])
+            mt = frontend.Mt19937(99)
+            seeds = [mt() for _ in range(6)]
+            out = torch.zeros((len(seeds), H, W, 4), dtype=torch.float32, device="cuda")
+            r.render_batch(W, H, seeds, out.data_ptr())
+            torch.cuda.synchronize()
+            assert r.lastLaunchInfo()["patch_classes"] == 1
+            bat = out.cpu().numpy()
+            for i, sd in enumerate(seeds):
+                r.setSeed(sd)
+                r.setIteration(0)
+                ref_i, _, _ = common.oracle_frame(r, vol, UCHAR, tff, W, H)
+                d = np.abs(bat[i].astype(np.float64) - ref_i)
+                assert d.max() <= TOL, "%s view, frame %d: %g at %s" % (view, i, d.max(), np.unravel_index(d.argmax(), d.shape))
+                if i < 2:
+                    r.setStatsEnabled(False)
+                    one = r.runRaycastNoGL(W, H)
+                    r.setIteration(0)
+                    assert np.array_equal(one, bat[i])
     finally:
         r.close()
 

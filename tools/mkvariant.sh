@@ -15,7 +15,7 @@ for f in vr_raycast vr_pathtrace vr_cells vr_bricks vrhip_api; do
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
-printf 'extern "C" const char *vrhip_build_source_hash(void) { return "%s"; }\n' "$(python3 "$ROOT/volumerenderercl_amd/_srchash.py")" > "$OBJ/vr_srchash.cpp"
+printf 'extern "C" const char *vrhip_build_source_hash(void) { return "%s"; }\n' "$(python3 "$ROOT/volumerenderercl_amd/_srchash.py" "$@")" > "$OBJ/vr_srchash.cpp"
 g++ -O2 -fPIC -c "$OBJ/vr_srchash.cpp" -o "$OBJ/vr_srchash.o"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/volumerenderercl_amd/_variants/libvrhip_$NAME.so" "$OBJ"/*.o
 echo "built _variants/libvrhip_$NAME.so"

@@ -49,6 +49,18 @@ class Stats(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class LaunchInfo(C.Structure):
+    """vrhip_launch_info: what the last render call launched."""
+    _fields_ = [(n, C.c_uint32) for n in (
+        "technique", "frames", "work_items", "prepass", "ray_list", "phase1_waves", "phase2_waves", "round_budget",
+        "footprint", "empty_skip", "skip_in_lds", "instrumented", "extras", "patch_classes", "sorted_phase2",
+        "direct_long")] + [("reserved", C.c_uint32 * 16)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "reserved"}
+
+
+assert C.sizeof(LaunchInfo) == 128
 assert C.sizeof(CameraParams) == 128 and C.sizeof(RenderingParams) == 64
 assert C.sizeof(RaycastParams) == 32 and C.sizeof(PathtraceParams) == 4
 
@@ -106,6 +118,7 @@ SYMBOLS = {
     "vrhip_set_image_ess": (C.c_int, [_H, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "vrhip_last_kernel_seconds": (C.c_double, [_H]),
     "vrhip_last_phase_seconds": (C.c_int, [_H, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "vrhip_last_launch_info": (C.c_int, [_H, C.POINTER(LaunchInfo)]),
     "vrhip_set_phase_timing": (C.c_int, [_H, C.c_int]),
     "vrhip_set_frame_timing": (C.c_int, [_H, C.c_int]),
     "vrhip_build_source_hash": (C.c_char_p, []),

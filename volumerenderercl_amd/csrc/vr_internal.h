@@ -250,6 +250,7 @@ struct RaycastLaunch {
     int num_cus;
     hipEvent_t mid_event;  // optional: recorded between the phase-1 and phase-2 launches
     uint8_t *hit_out;      // imgEss: this frame's hit image (resolved after the march), or nullptr
+    vrhip_launch_info *info;   // optional: the launchers record what they launched (vrhip_last_launch_info)
 };
 
 hipError_t vr_launch_raycast(const RaycastLaunch &a, hipStream_t stream);

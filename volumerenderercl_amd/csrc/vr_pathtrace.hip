@@ -378,6 +378,11 @@ hipError_t launch_pt_typed(const RaycastLaunch &a, hipStream_t stream)
 
 hipError_t vr_launch_pathtrace(const RaycastLaunch &a, hipStream_t stream)
 {
+    if (a.info) {
+        a.info->technique = 1;
+        a.info->work_items = a.frame.n_wave_tiles;
+        a.info->instrumented = (uint32_t)a.instr;
+    }
     switch (a.format) {
     case VRHIP_UCHAR: return launch_pt_typed<uint8_t>(a, stream);
     case VRHIP_USHORT: return launch_pt_typed<uint16_t>(a, stream);

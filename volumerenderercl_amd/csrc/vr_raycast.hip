@@ -1029,9 +1029,11 @@ VR_DEV bool patch_is_clear(const SkipView &skip, const Grid &g, const RayCtx &c,
 // patches with rays that reach a brick to sample go to the `live` list for phase 1.
 // Patch classes: one wave per 8x8 patch, ONCE per camera / parameters / skip bitmap / tile set -- the frames of
 // a set, and the frames after it while nothing changes, differ only in the jitter seed, which moves every
-// ray by less than a pixel (:625-628).  The wave sets up 64 rays WITHOUT jitter on a regular grid over the
-// patch grown by two pixels on every side ([8 tx - 2, 8 tx + 10) x [8 ty - 2, 8 ty + 10)): the jittered rays
-// of the patch's pixels, in any frame, lie inside the hull of these.  Class 1 when
+// ray by less than a pixel on a square frame, by up to max(gsx, gsy) / gs pixels along an axis in general
+// (:625-628).  The wave sets up 64 rays WITHOUT jitter on a regular grid over the patch's pixel positions grown
+// by that jitter range on the + side and by two pixels on every side ([8 tx - 2, 8 tx + 10] x [8 ty - 2,
+// 8 ty + 10] on a square frame): the jittered rays of the patch's pixels, in any frame, lie inside the hull
+// of these.  Class 1 when
 //  * all 64 hull rays hit the box SHRUNK by a thousandth of its size (rays through a convex box from one
 //    eye point -- or parallel rays -- form a convex set, so every ray inside the hull hits the shrunk box,
 //    and the real box by a margin far above the slab test's rounding): c.valid holds for every ray;
@@ -1050,12 +1052,18 @@ __global__ __launch_bounds__(kBlockDim) void vr_patch_class_kernel(SkipView skip
     const uint32_t pi = blockIdx.x * (kBlockDim / 64) + (threadIdx.x >> 6);
     if (pi >= n_patches) return;
     const WaveTile wt = fr.queue[(size_t)pi * set_frames];
-    const float fx = (float)(wt_col(wt) * 8u) - 2.f + (float)(lane & 7u) * (12.f / 7.f);
-    const float fy = (float)(wt_row(wt) * 8u) - 2.f + (float)(lane >> 3) * (12.f / 7.f);
     // make_ray's geometry (:614-650) at a fractional pixel position, no jitter
     const float *V = cam.viewMat;
     const f3 ms = mk3(rp.modelScale[0], rp.modelScale[1], rp.modelScale[2]);
     const int maxImg = (int)(fr.gsx > fr.gsy ? fr.gsx : fr.gsy);
+    // The jitter moves a ray by rnd * 2 / gsx and rnd * 2 / gsy in NDC (:625-628) while a pixel is 2 / maxImg wide:
+    // by up to maxImg / gsx pixels in +x and maxImg / gsy in +y -- one pixel on a square frame, `aspect` pixels
+    // along the short axis of any other.  The hull is the patch's pixel positions [8 t, 8 t + 7] grown by that
+    // (rounded up) on the + side and by two pixels of margin on both: [8 t - 2, 8 t + 9 + ceil(maxImg / gs)].
+    const float spanx = (float)(11u + ((uint32_t)maxImg + fr.gsx - 1u) / fr.gsx);
+    const float spany = (float)(11u + ((uint32_t)maxImg + fr.gsy - 1u) / fr.gsy);
+    const float fx = (float)(wt_col(wt) * 8u) - 2.f + (float)(lane & 7u) * (spanx / 7.f);
+    const float fy = (float)(wt_row(wt) * 8u) - 2.f + (float)(lane >> 3) * (spany / 7.f);
     float icx = (fx / (float)maxImg) * 2.f, icy = (fy / (float)maxImg) * 2.f;
     if (fr.gsx > fr.gsy) { icx -= 1.0f; icy -= fr.ray_aspect; }
     else { icx -= fr.ray_aspect; icy -= 1.0f; }
@@ -2057,6 +2065,22 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
     if (grid.x == 0) return hipSuccess;
     FrameView frame = a.frame;
     if (XS || INSTR != 0 || !ESS) frame.live_rays = nullptr;   // the ray list serves the default kernels
+    if (a.info) {   // what this call launches, for vrhip_last_launch_info (completed below)
+        vrhip_launch_info &li = *a.info;
+        li.technique = 0;
+        li.work_items = a.frame.n_wave_tiles;
+        li.round_budget = a.frame.round_budget;
+        li.footprint = FP ? 1u : 0u;
+        li.instrumented = (uint32_t)INSTR;
+        li.extras = XS ? 1u : 0u;
+        li.skip_in_lds = (ESS && SKIP_LDS) ? 1u : 0u;
+        li.phase1_waves = 4;
+        li.phase2_waves = a.frame.round_budget ? (uint32_t)waves2 : 0u;
+        li.sorted_phase2 = (a.frame.round_budget && a.frame.order) ? 1u : 0u;
+        // the lookahead's condition in the kernels: cells.empty && useLinear (and INSTR != 2, not the XS modes that track every sample)
+        li.empty_skip = (INSTR != 2 && a.cells.empty != nullptr && a.render.useLinear != 0 &&
+                         !(XS && (a.render.illumType == 4 || a.render.showEss))) ? 1u : 0u;
+    }
     if (ESS && INSTR == 0 && frame.live) {
         // what make_grid(bricks, rc, n_words, true) and 1 / resolution give on the device
         Grid hg;
@@ -2072,6 +2096,7 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
                            a.skip, frame, a.cam, a.render, a.raycast, hg, hv);
         hipError_t pe = hipGetLastError();
         if (pe != hipSuccess) return pe;
+        if (a.info) { a.info->prepass = 1; a.info->patch_classes = frame.patch_class ? 1u : 0u; }
     } else {
         frame.live = nullptr;
     }
@@ -2101,6 +2126,7 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kr, dim3(cus * (uint32_t)nbr), dim3(waves_r * 64), lds_r, stream, a.vol, a.bricks, a.tf,
                            a.skip, a.cells, frame, a.cam, a.render, a.raycast);
+        if (a.info) { a.info->ray_list = 1; a.info->phase1_waves = (uint32_t)waves_r; a.info->skip_in_lds = rlds ? 1u : 0u; }
     } else {
         hipLaunchKernelGGL(k1, grid, block, lds, stream, a.vol, a.bricks, a.tf, a.skip, a.cells, frame, a.cam,
                            a.render, a.raycast, a.stats, a.touched);

@@ -149,6 +149,8 @@ struct vrhip_renderer {
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr, evb0 = nullptr, evb1 = nullptr;
     bool timed = false, bricks_timed = false, phase_timed = false;
+    vrhip_launch_info last_info;      // what the last render call launched (vrhip_last_launch_info)
+    bool have_info = false;
 
     vrhip_renderer()
     {
@@ -985,9 +987,16 @@ int launch_timed(vrhip_renderer *r, const RaycastLaunch &a)
         VR_HIP(r, hipMemsetAsync(r->hit_any, 0, (size_t)r->hit_w * r->hit_h, r->stream));
         b.hit_out = r->hit_out;
     }
+    std::memset(&r->last_info, 0, sizeof r->last_info);
+    r->last_info.frames = b.frame.seeds ? r->queue_frames : 1u;
+    b.info = &r->last_info;
+    r->have_info = false;
     VR_HIP(r, vr_launch_frame(b, r->stream));
-    r->ctrl_sel ^= 1u;                 // the first kernel of this set has zeroed the other block
-    r->ctrl_clean[r->ctrl_sel] = true;
+    r->have_info = true;
+    // the first kernel of this set has zeroed the other block (VR_ZERO_NEXT_CTRL) -- unless the set was empty and
+    // nothing ran: then the other block keeps whatever it held, and the next set clears it with a memset
+    r->ctrl_sel ^= 1u;
+    r->ctrl_clean[r->ctrl_sel] = b.frame.n_wave_tiles != 0;
     if (r->frame_timing) VR_HIP(r, hipEventRecord(r->ev1, r->stream));
     r->timed = r->frame_timing;
     if (b.frame.hit_in) std::swap(r->hit_in, r->hit_out);   // runRaycast, volumerendercl.cpp:524-530
@@ -1854,6 +1863,14 @@ int vrhip_last_phase_seconds(const vrhip_renderer *r, double *phase1, double *ph
     if (hipEventElapsedTime(&b, r->evm, r->ev1) != hipSuccess) return VRHIP_ERR_HIP;
     if (phase1) *phase1 = (double)a * 1e-3;
     if (phase2) *phase2 = (double)b * 1e-3;
+    return VRHIP_OK;
+}
+
+int vrhip_last_launch_info(const vrhip_renderer *r, vrhip_launch_info *out)
+{
+    if (!r || !out) return VRHIP_ERR_INVALID;
+    if (!r->have_info) return fail(r, VRHIP_ERR_NODATA, "vrhip_last_launch_info: nothing has been rendered yet");
+    *out = r->last_info;
     return VRHIP_OK;
 }
 

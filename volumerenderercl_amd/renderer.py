@@ -551,6 +551,13 @@ class VolumeRenderCL:
             return 0.0, 0.0
         return float(a.value), float(b.value)
 
+    def lastLaunchInfo(self):
+        """What the last render call launched (vrhip_last_launch_info): kernel variants, waves per workgroup,
+        round budget, lookahead, frames of the set -- as a dict."""
+        li = _lib.LaunchInfo()
+        self._check(self._lib.vrhip_last_launch_info(self._h, C.byref(li)))
+        return li.as_dict()
+
     # ---- test / bench conveniences (not in the reference)
     def setSeed(self, seed):
         """Pin the per-frame jitter seed (None restores the mt19937 sequence).  params() shows a pinned seed at
