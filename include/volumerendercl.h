@@ -15,6 +15,7 @@
 #pragma once
 
 #include <array>
+#include <memory>
 #include <random>
 #include <string>
 #include <valarray>
@@ -99,6 +100,31 @@ public:
     vrhip_renderer *handle() { return _r; }
     const rendering_params &renderingParams() const { return _rendering_params; }
 
+    // ---- the throughput path (no reference counterpart: runRaycast renders one frame per call and waits,
+    // volumerendercl.cpp:506-558; a caller that wants independent frames -- a turntable, an image-tile share of a
+    // multi-GPU split, a benchmark -- hands over several at once)
+    // A second renderer on the same GPU that renders from THIS renderer's voxels, ESS bricks and footprint volume
+    // (vrhip_share_volumes) with a stream, frame buffer and scratch of its own: two launch sets can be in flight over
+    // one copy of the volume.  It starts with this renderer's transfer function and parameters; this renderer must
+    // outlive it.
+    std::unique_ptr<VolumeRenderCL> shareVolumes();
+    // seeds.size() <= 256 INDEPENDENT frames (frame f jittered by seeds[f], iteration 0) in ONE set of launches
+    // (vrhip_render_batch) into DEVICE memory dev_out[f][height][width][4]; returns without waiting.
+    void renderFrames(size_t width, size_t height, const std::vector<unsigned int> &seeds, float *dev_out);
+    // the same for a tile subset: dev_out[f][n_tiles][tile_h][tile_w][4]; frame_stride: pixels between the frames of
+    // dev_out (0 = packed)
+    void renderFramesTiles(size_t width, size_t height, size_t tile_w, size_t tile_h,
+                           const std::vector<unsigned int> &tile_ids, const std::vector<unsigned int> &seeds,
+                           float *dev_out, size_t frame_stride = 0);
+    // the jitter seeds the next n runRaycast calls would use (the default-seeded std::mt19937 member, or the pinned seed)
+    std::vector<unsigned int> drawSeeds(size_t n);
+    // phase-1 sample rounds per ray (vrhip_set_round_budget): 10 for one frame at a time, 48 for launch sets of
+    // several frames; no effect on any pixel
+    void setRoundBudget(unsigned int rounds);
+    // the events around every launch set (what getLastExecTime reads): off for back-to-back launch sets
+    void setFrameTiming(bool on);
+    void *stream();   // the hipStream_t the renderer launches on
+
 private:
     void generateBricks();
     void calcScaling();
@@ -122,5 +148,10 @@ private:
     DatRawReader _dr;
     bool _synthetic = false;
     int _channels = 1;          // 1 = R, 2 = RG, 4 = RGBA (volDataToCLmem, :697-705)
+    std::vector<unsigned char> _tff;          // what setTransferFunction / setTffPrefixSum were last given
+    std::vector<unsigned int> _tffPrefixSum;  // (shareVolumes hands them to the twin)
+    bool _objEss = true;
+    int _device = 0;
+    unsigned int _roundBudget = 0;            // 0 = the library's default
     std::array<unsigned int, 4> _synthRes = {{0, 0, 0, 1}};
 };

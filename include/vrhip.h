@@ -245,6 +245,22 @@ int vrhip_assemble_batch(vrhip_renderer *r, void *hip_stream, const float *const
                          const uint32_t *rank_slot_of_tile_dev, uint32_t width, uint32_t height, uint32_t tile_w,
                          uint32_t tile_h, float *frames_dev);
 
+/* Multi-GPU, every rank: pack the n_slots tile slots of a batch (tile_pixels RGBA float pixels each, one after the
+ * other in tiles_dev: a rank's output of vrhip_render_batch with a tile subset) into the sparse gather message
+ * [spad slot numbers of the whole tiles (int32 bits) | n_slots pixels, one per slot | the whole tiles], spad =
+ * n_slots rounded up to a multiple of 4: a tile whose pixels are all bit-identical travels as its one pixel.  Pure
+ * data compression (no notion of a background).  msg_dev holds spad + 4 n_slots + 4 n_slots tile_pixels floats (the
+ * worst case); count_dev receives the number c of whole tiles: the first spad + 4 n_slots + 4 c tile_pixels floats
+ * are what has to travel.  scratch_dev: n_slots int32.  All device memory, 16-byte aligned; three small kernels on
+ * hip_stream.  The root reads the messages with vrhip_message_positions + vrhip_assemble_batch (maxc = spad). */
+int vrhip_pack_tiles(vrhip_renderer *r, void *hip_stream, const float *tiles_dev, uint32_t n_slots,
+                     uint32_t tile_pixels, int32_t *scratch_dev, float *msg_dev, uint32_t *count_dev);
+/* Multi-GPU, rank 0: pos_dev[rank * n_slots + row] (what vrhip_assemble_batch reads) from the slot lists at the
+ * head of the `world` received messages; counts_host[rank] = that rank's number of whole tiles.  msgs_dev: HOST
+ * array of device pointers. */
+int vrhip_message_positions(vrhip_renderer *r, void *hip_stream, const float *const *msgs_dev,
+                            const uint32_t *counts_host, uint32_t world, uint32_t n_slots, int32_t *pos_dev);
+
 /* A batch of n_frames <= 256 INDEPENDENT frames (n_frames x pixels per frame < 2^32) -- same camera and parameters, frame f with jitter
  * seed seeds[f] (rendering_params.seed is not used) -- in ONE set of launches: the work queue holds
  * every patch once per frame, so a small tile share still fills the GPU and the latency chain of

@@ -596,6 +596,132 @@ def test_cpp_host_tile_ranks_equal_single_renderer(tmp_path, args, frames):
     np.testing.assert_array_equal(outs[0], outs[1])
 
 
+def test_cpp_host_throughput_path_equals_frames_one_by_one(tmp_path):
+    """The C++ host's throughput path (VolumeRenderCL::shareVolumes / renderFrames, TileGather::submitFrames /
+    collectFrames; `vrhip_render --frames-per-launch K`): N independent frames -- jitter seeds = the first N outputs
+    of the default-seeded std::mt19937, iteration 0 -- rendered in launch sets by one or two renderers over a shared
+    volume, and by 1-4 tile ranks with batched, sparse, pipelined exchanges (device copies with --loopback; RCCL's
+    grouped send / recv from the root to itself with --ranks 1 --force-gather), equal `--independent` (one
+    runRaycastNoGL per frame) bit for bit -- and the oracle's frames of those seeds."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "volumerenderercl_amd", "vrhip_render")
+    W, H, N, NF = 200, 136, 96, 7        # (the frame is not a multiple of the tile sizes; 7 frames: ragged sets)
+    base = [exe, "--synth", "shells", str(N), "USHORT", "--size", str(W), str(H), "--rotate", "1", "1", "0", "30",
+            "--frames", str(NF)]
+
+    def run(name, more):
+        out = str(tmp_path / name)
+        res = subprocess.run(base + more + ["--out", out], capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr
+        frames = np.fromfile(out + ".frames.rgba.f32", dtype=np.float32).reshape(NF, H, W, 4)
+        last = np.fromfile(out + ".rgba.f32", dtype=np.float32).reshape(H, W, 4)
+        np.testing.assert_array_equal(last, frames[-1])
+        return frames, res.stdout
+
+    one_by_one, _ = run("single", ["--independent"])
+    assert np.isfinite(one_by_one).all() and one_by_one.std() > 0 and np.abs(one_by_one[0] - one_by_one[1]).max() > 0
+    # the oracle's frames of the same seeds
+    vol = vro.synth_volume("shells", [N, N, N], vro.USHORT)
+    tff = frontend.tff_from_stops()
+    cam, rp, rc, pt = scenes.oracle_params((N, N, N), "rot30", {"background": (1.0, 1.0, 1.0)}, seed=0)   # (setBackground: alpha 0)
+    mt = frontend.Mt19937()
+    for f in range(NF):
+        rp.seed, rp.iteration = mt(), 0
+        ref, _, _ = vro.render_tile(vol, vro.USHORT, tff, cam, rp, rc, pt, W=W, H=H)
+        assert np.abs(one_by_one[f].astype(np.float64) - ref).max() <= TOL, f
+    for name, more in (("b3x2", ["--frames-per-launch", "3", "--frames-in-flight", "2"]),
+                       ("b4x1", ["--frames-per-launch", "4", "--frames-in-flight", "1", "--round-budget", "5"]),
+                       ("b16x3", ["--frames-per-launch", "16", "--frames-in-flight", "3"]),
+                       ("r1", ["--ranks", "1", "--loopback", "--tile", "32", "--frames-per-launch", "3"]),
+                       ("r2", ["--ranks", "2", "--loopback", "--tile", "16", "--frames-per-launch", "2"]),
+                       ("r3", ["--ranks", "3", "--loopback", "--tile", "48", "--frames-per-launch", "7", "--root-share", "0.5"]),
+                       ("r4", ["--ranks", "4", "--loopback", "--tile", "32", "--frames-per-launch", "1"]),
+                       ("rccl", ["--ranks", "1", "--force-gather", "--tile", "32", "--frames-per-launch", "3"]),
+                       ("dense2", ["--ranks", "2", "--loopback", "--tile", "32", "--independent"])):
+        got, stdout = run(name, more)
+        np.testing.assert_array_equal(got, one_by_one, err_msg=name)
+        if name == "rccl":
+            assert '"transport": "RCCL send/recv (root included)"' in stdout, stdout
+        if name.startswith("r") and "--frames-per-launch" in more:
+            import json
+            line = json.loads(stdout.strip().splitlines()[-1])
+            assert line["sent_bytes_per_frame"] > 0
+            if name in ("r2", "r3", "r4"):      # the background tiles travelled as one pixel each
+                assert line["sent_bytes_per_frame"] < line["dense_bytes_per_frame"], line
+
+
+def test_cpp_host_bench_runs_the_benchmarks_schedule(tmp_path):
+    """`vrhip_render --bench` on a 256^3 volume: two renderers over one shared volume, launch sets of 8 frames, round
+    budget 48, HIP-event time per frame -- and the launch info says which kernels ran (the 12-wave instantiations:
+    sets of >= 4 frames)."""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "volumerenderercl_amd", "vrhip_render")
+    out = str(tmp_path / "b")
+    res = subprocess.run([exe, "--synth", "shells", "256", "UCHAR", "--size", "512", "512", "--rotate", "1", "1", "0", "30",
+                          "--frames", "32", "--frames-per-launch", "8", "--bench", "--out", out],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line["bench"] is True and line["renderers"] == 2 and line["launch_sets"] == 4 and line["frames_per_launch_set"] == 8
+    assert line["round_budget"] == 48 and line["phase1_waves"] == 12 and line["phase2_waves"] == 12
+    assert 0.0 < line["ms_per_frame"] < 50.0
+    last = np.fromfile(out + ".rgba.f32", dtype=np.float32).reshape(512, 512, 4)
+    assert np.isfinite(last).all() and last.std() > 0
+
+
+def test_pack_tiles_and_message_positions(vr):
+    """vrhip_pack_tiles / vrhip_message_positions (the C++ host's sparse gather message, packed and read on the GPU)
+    against numpy: slot list, one pixel per slot, the whole tiles in slot order, the count, and the positions the
+    root's assembly reads."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(3)
+    for S, P in ((1, 256), (37, 1024), (1500, 256), (5000, 256)):
+        tiles = np.zeros((S, P, 4), dtype=np.float32)
+        whole = rng.random(S) < 0.4
+        for s_ in range(S):
+            tiles[s_] = rng.random(4).astype(np.float32)
+            if whole[s_]:
+                tiles[s_, rng.integers(0, P)] += 1.0          # one pixel differs (also: the last, the first)
+        if S > 2:
+            tiles[2] = tiles[2, 0]; tiles[2, P - 1, 3] = 7.0; whole[2] = True
+            tiles[1] = tiles[1, 0]; tiles[1, 0, 0] = -0.0; tiles[1, 1:, 0] = 0.0; whole[1] = True   # (-0.0 != 0.0 bit for bit)
+        spad = (S + 3) // 4 * 4
+        t = torch.from_numpy(tiles).cuda()
+        msg = torch.full((spad + 4 * S + 4 * S * P,), -1.0, dtype=torch.float32, device="cuda")
+        scratch = torch.zeros(S, dtype=torch.int32, device="cuda")
+        count = torch.zeros(1, dtype=torch.int32, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        rc = vr.lib.vrhip_pack_tiles(vr.handle, C.c_void_p(st), C.c_void_p(t.data_ptr()), S, P,
+                                     C.c_void_p(scratch.data_ptr()), C.c_void_p(msg.data_ptr()), C.c_void_p(count.data_ptr()))
+        assert rc == 0
+        torch.cuda.synchronize()
+        c = int(count.item())
+        assert c == int(whole.sum())
+        m = msg.cpu().numpy()
+        slots = m[:c].view(np.int32)
+        np.testing.assert_array_equal(slots, np.nonzero(whole)[0])
+        np.testing.assert_array_equal(m[spad:spad + 4 * S].reshape(S, 4).view(np.uint32), tiles[:, 0, :].view(np.uint32))
+        np.testing.assert_array_equal(m[spad + 4 * S: spad + 4 * S + 4 * c * P].reshape(c, P, 4).view(np.uint32),
+                                      tiles[whole].view(np.uint32))
+        pos = torch.zeros(2 * S, dtype=torch.int32, device="cuda")
+        ptrs = (C.c_void_p * 2)(msg.data_ptr(), msg.data_ptr())
+        counts = (C.c_uint32 * 2)(c, 0)
+        rc = vr.lib.vrhip_message_positions(vr.handle, C.c_void_p(st), ptrs, counts, 2, S, C.c_void_p(pos.data_ptr()))
+        assert rc == 0
+        torch.cuda.synchronize()
+        want = np.full(S, -1, dtype=np.int32)
+        want[np.nonzero(whole)[0]] = np.arange(c)
+        got = pos.cpu().numpy()
+        np.testing.assert_array_equal(got[:S], want)
+        assert (got[S:] == -1).all()
+
+
 def test_cpp_host_cli_pathtrace_matches_oracle(tmp_path):
     """Headless path tracing through the C++ host: 3 samples per pixel accumulated with the
     std::mt19937 seed stream of the reference's VolumeRenderCL member."""

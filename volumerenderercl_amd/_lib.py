@@ -82,6 +82,9 @@ SYMBOLS = {
     "vrhip_assemble_batch": (C.c_int, [_H, C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_uint32,
                                        C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                        C.c_uint32, C.c_void_p]),
+    "vrhip_pack_tiles": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vrhip_message_positions": (C.c_int, [_H, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_uint32,
+                                          C.c_uint32, C.c_void_p]),
     "vrhip_assemble_frame": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                        C.c_uint32, C.c_void_p]),
     "vrhip_upload_volume": (C.c_int, [_H, C.c_void_p, _U3, C.c_int, C.c_uint32]),

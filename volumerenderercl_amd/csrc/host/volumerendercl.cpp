@@ -64,6 +64,7 @@ void VolumeRenderCL::initialize(bool useGL, bool useCPU, cl_vendor, const std::s
     else if (platformId >= 0)
         device = platformId;
     if (_r) { vrhip_destroy(_r); _r = nullptr; }
+    _device = device;
     int rc = vrhip_create(device, &_r);
     if (rc != VRHIP_OK) {
         const char *msg = vrhip_last_error(nullptr);
@@ -253,6 +254,7 @@ const std::array<double, 256> &VolumeRenderCL::getHistogram(unsigned int timeste
 void VolumeRenderCL::setTransferFunction(std::vector<unsigned char> &tff)   // :864-891
 {
     if (!_volLoaded) return;
+    _tff = tff;
     check("setTransferFunction",
           vrhip_set_transfer_function(_r, tff.data(), uint32_t(tff.size() / 4)));
     generateBricks();
@@ -266,6 +268,7 @@ void VolumeRenderCL::setTransferFunction(std::vector<unsigned char> &tff)   // :
 void VolumeRenderCL::setTffPrefixSum(std::vector<unsigned int> &tffPrefixSum)   // :898-916
 {
     if (!_volLoaded) return;
+    _tffPrefixSum = tffPrefixSum;
     check("setTffPrefixSum",
           vrhip_set_tff_prefix_sum(_r, tffPrefixSum.data(), uint32_t(tffPrefixSum.size())));
 }
@@ -290,6 +293,7 @@ void VolumeRenderCL::setUseGradient(bool v) { _rendering_params.useGradient = v 
 
 void VolumeRenderCL::setObjEss(bool useEss)   // :1006-1019: kernel-variant switch, no rebuild
 {
+    _objEss = useEss;
     check("setObjEss", vrhip_set_object_ess(_r, useEss ? 1 : 0));
 }
 
@@ -394,3 +398,84 @@ void VolumeRenderCL::createEnvironmentMap(const std::string &file_name)
 
 void VolumeRenderCL::setSeed(unsigned int seed) { _seedPinned = true; _pinnedSeed = seed; }
 void VolumeRenderCL::clearSeed() { _seedPinned = false; }
+
+// ---- the throughput path (include/volumerendercl.h "additions"): launch sets of independent frames on
+// vrhip_share_volumes / vrhip_render_batch
+
+std::unique_ptr<VolumeRenderCL> VolumeRenderCL::shareVolumes()
+{
+    if (!_volLoaded) throw std::runtime_error("No volume data is loaded.");
+    std::unique_ptr<VolumeRenderCL> twin(new VolumeRenderCL());
+    int rc = vrhip_create(_device, &twin->_r);
+    if (rc != VRHIP_OK) {
+        const char *msg = vrhip_last_error(nullptr);
+        throw std::runtime_error(msg && *msg ? msg : "ERROR: vrhip_create");
+    }
+    twin->_device = _device;
+    twin->_currentDevice = _currentDevice;
+    twin->check("shareVolumes", vrhip_share_volumes(twin->_r, _r));
+    twin->_synthetic = true;          // (resolution from _synthRes: the twin holds no DatRawReader data)
+    twin->_synthRes = getResolution();
+    twin->_channels = _channels;
+    twin->_modelScale = _modelScale;
+    twin->_timestep = _timestep;
+    twin->_camera_params = _camera_params;
+    twin->_rendering_params = _rendering_params;
+    twin->_raycast_params = _raycast_params;
+    twin->_pathtrace_params = _pathtrace_params;
+    twin->_seedPinned = _seedPinned;
+    twin->_pinnedSeed = _pinnedSeed;
+    twin->_volLoaded = true;
+    twin->check("setTimestep", vrhip_set_timestep(twin->_r, uint32_t(_timestep)));
+    twin->setObjEss(_objEss);
+    if (!_tff.empty()) {
+        std::vector<unsigned char> tff = _tff;
+        twin->setTransferFunction(tff);     // (takes the owner's bricks: vrhip_build_bricks on a sharer)
+    }
+    if (!_tffPrefixSum.empty()) {
+        std::vector<unsigned int> prefix = _tffPrefixSum;
+        twin->setTffPrefixSum(prefix);
+    }
+    twin->_rendering_params.iteration = _rendering_params.iteration;
+    if (_roundBudget) twin->setRoundBudget(_roundBudget);
+    return twin;
+}
+
+void VolumeRenderCL::renderFrames(size_t width, size_t height, const std::vector<unsigned int> &seeds, float *dev_out)
+{
+    renderFramesTiles(width, height, 0, 0, std::vector<unsigned int>(), seeds, dev_out, 0);
+}
+
+void VolumeRenderCL::renderFramesTiles(size_t width, size_t height, size_t tile_w, size_t tile_h,
+                                       const std::vector<unsigned int> &tile_ids,
+                                       const std::vector<unsigned int> &seeds, float *dev_out, size_t frame_stride)
+{
+    if (!_volLoaded) return;
+    _rendering_params.iteration = 0;   // the frames of a launch set are independent
+    pushParams();
+    check("renderFrames", vrhip_render_batch(_r, uint32_t(width), uint32_t(height), uint32_t(tile_w), uint32_t(tile_h),
+                                             tile_ids.empty() ? nullptr : tile_ids.data(), uint32_t(tile_ids.size()),
+                                             seeds.data(), uint32_t(seeds.size()), dev_out, uint32_t(frame_stride)));
+}
+
+std::vector<unsigned int> VolumeRenderCL::drawSeeds(size_t n)
+{
+    std::vector<unsigned int> out(n);
+    for (size_t i = 0; i < n; ++i) out[i] = _seedPinned ? _pinnedSeed : static_cast<unsigned int>(_generator());
+    return out;
+}
+
+void VolumeRenderCL::setRoundBudget(unsigned int rounds)
+{
+    _roundBudget = rounds;
+    check("setRoundBudget", vrhip_set_round_budget(_r, rounds));
+}
+
+void VolumeRenderCL::setFrameTiming(bool on) { check("setFrameTiming", vrhip_set_frame_timing(_r, on ? 1 : 0)); }
+
+void *VolumeRenderCL::stream()
+{
+    void *s = nullptr;
+    check("stream", vrhip_get_stream(_r, &s));
+    return s;
+}

@@ -19,6 +19,9 @@
 #include <vector>
 
 #include <memory>
+#include <chrono>
+
+#include <hip/hip_runtime_api.h>
 
 #include "tilegather.h"
 #include "volumerendercl.h"
@@ -218,6 +221,17 @@ void write_ppm(const std::string &path, const std::vector<float> &rgba, size_t w
         "                                           renderers on device D, device copies instead of RCCL;\n"
         "                                           --force-gather: the root sends its tiles to itself over RCCL\n"
         "                                           too -- with --ranks 1 the transport runs on one GPU)\n"
+        "         [--independent]                  (--frames N independent frames -- iteration 0 each, jitter seeds = the\n"
+        "                                           first N outputs of the default-seeded mt19937 -- instead of the\n"
+        "                                           running mean; all of them go to PREFIX.frames.rgba.f32)\n"
+        "         [--frames-per-launch K [--frames-in-flight F] [--round-budget B] [--bench] [--root-share X]]\n"
+        "                                          (the throughput path: the N independent frames in launch sets of K\n"
+        "                                           (vrhip_render_batch), F renderers over one shared volume taking the\n"
+        "                                           sets in turn (default 2; with --ranks: one per rank, K frames per\n"
+        "                                           exchange, sparse messages, one exchange in flight), phase-1 round\n"
+        "                                           budget B (default 48); --bench: one untimed set per renderer, then\n"
+        "                                           the N frames timed with HIP events, nothing copied or written but\n"
+        "                                           the last frame; --root-share: rank 0's share of a peer's tiles)\n"
         "writes PREFIX.rgba.f32 (W*H*4 float32, row 0 = top), PREFIX.ppm and prints one JSON line\n";
     std::exit(2);
 }
@@ -241,6 +255,9 @@ int main(int argc, char **argv)
     int frames = 1, device = 0, ranks = 0;
     size_t tile = 64;
     bool loopback = false, force_gather = false;
+    bool independent = false, bench = false;
+    int frames_per_launch = 0, frames_in_flight = 2, round_budget = 48;
+    double root_share = 1.0;
     double rate = 1.5;
     std::array<float, 4> bg = {{1, 1, 1, 1}};
 
@@ -286,6 +303,12 @@ int main(int argc, char **argv)
         else if (a == "--tile") { need(i, 1); tile = size_t(std::atol(argv[++i])); }
         else if (a == "--loopback") loopback = true;
         else if (a == "--force-gather") force_gather = true;
+        else if (a == "--independent") independent = true;
+        else if (a == "--bench") bench = true;
+        else if (a == "--frames-per-launch") { need(i, 1); frames_per_launch = std::atoi(argv[++i]); }
+        else if (a == "--frames-in-flight") { need(i, 1); frames_in_flight = std::atoi(argv[++i]); }
+        else if (a == "--round-budget") { need(i, 1); round_budget = std::atoi(argv[++i]); }
+        else if (a == "--root-share") { need(i, 1); root_share = std::atof(argv[++i]); }
         else if (a == "--out") { need(i, 1); out = argv[++i]; }
         else usage();
     }
@@ -385,29 +408,195 @@ int main(int argc, char **argv)
                 if (!setup(*vrs.back(), devs.back())) return 0;
                 ptrs.push_back(vrs.back().get());
             }
-            TileGather tg(ptrs, devs, W, H, tile, loopback, force_gather);
-            std::vector<float> frame;
+            const bool batched = frames_per_launch > 0;
+            if (batched && (pathtrace || img_ess || use_ao_flag))
+                throw std::runtime_error("--frames-per-launch: ray caster only, no image-order ESS, no ambient occlusion");
+            const size_t K = batched ? size_t(std::min(256, std::max(1, frames_per_launch))) : 0;
+            TileGather tg(ptrs, devs, W, H, tile, loopback, force_gather, root_share, K);
+            std::vector<float> frame, all_frames;
             double secs = 0.0;
-            for (int f = 0; f < frames; ++f) secs += tg.renderFrame(frame);
+            const std::array<float, 16> the_view = have_view ? view : view_matrix(q, tr);
+            if (batched) {
+                // the throughput path: K independent frames per exchange, one exchange in flight
+                for (auto &v : vrs) { v->setRoundBudget(unsigned(round_budget)); v->setFrameTiming(false); }
+                std::vector<std::vector<unsigned int>> sets;
+                std::vector<unsigned int> seeds = vrs[0]->drawSeeds(size_t(frames));
+                for (size_t f0 = 0; f0 < seeds.size(); f0 += K)
+                    sets.emplace_back(seeds.begin() + long(f0), seeds.begin() + long(std::min(seeds.size(), f0 + K)));
+                if (bench) {   // untimed: buffers, work queues, cost maps, communicators
+                    std::mt19937 warm(20261004u);
+                    std::vector<unsigned int> ws(std::min(K, size_t(frames)));
+                    for (int rep = 0; rep < 2; ++rep) {
+                        for (auto &x : ws) x = static_cast<unsigned int>(warm());
+                        tg.submitFrames(ws);
+                    }
+                    tg.collectFrames(nullptr);
+                    tg.collectFrames(nullptr);
+                }
+                const auto t0 = std::chrono::steady_clock::now();
+                for (size_t k = 0; k < sets.size(); ++k) {
+                    tg.submitFrames(sets[k]);
+                    if (tg.pending() == 2) {
+                        tg.collectFrames(bench ? nullptr : &frame);
+                        if (!bench) all_frames.insert(all_frames.end(), frame.begin(), frame.end());
+                    }
+                }
+                while (tg.pending()) {
+                    tg.collectFrames(&frame);
+                    if (!bench) all_frames.insert(all_frames.end(), frame.begin(), frame.end());
+                }
+                secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                frame.erase(frame.begin(), frame.end() - long(W * H * 4));   // the last frame of the last batch
+            } else {
+                for (int f = 0; f < frames; ++f) {
+                    if (independent)
+                        for (auto &v : vrs) v->updateView(the_view);   // (resets the running mean: iteration 0)
+                    secs += tg.renderFrame(frame);
+                    if (independent) all_frames.insert(all_frames.end(), frame.begin(), frame.end());
+                }
+            }
+            if (!all_frames.empty()) {
+                std::ofstream af(out + ".frames.rgba.f32", std::ios::binary);
+                af.write(reinterpret_cast<const char *>(all_frames.data()), std::streamsize(all_frames.size() * sizeof(float)));
+            }
             std::ofstream raw(out + ".rgba.f32", std::ios::binary);
             raw.write(reinterpret_cast<const char *>(frame.data()), std::streamsize(frame.size() * sizeof(float)));
             write_ppm(out + ".ppm", frame, W, H);
             auto res = vrs[0]->getResolution();
             std::printf("{\"device\": \"%s\", \"volume\": [%u, %u, %u], \"width\": %zu, \"height\": %zu, "
                         "\"frames\": %d, \"ranks\": %d, \"tile\": %zu, \"transport\": \"%s\", "
-                        "\"frame_ms\": %.4f, \"out\": \"%s.rgba.f32\"}\n",
+                        "\"frames_per_exchange\": %zu, \"independent\": %s, \"sent_bytes_per_frame\": %.0f, "
+                        "\"dense_bytes_per_frame\": %.0f, \"frame_ms\": %.4f, \"ms_per_frame\": %.4f, "
+                        "\"clock\": \"host, first submit to last assembled batch\", \"out\": \"%s.rgba.f32\"}\n",
                         vrs[0]->getCurrentDeviceName().c_str(), res[0], res[1], res[2], W, H, frames, ranks, tile,
-                        tg.transport().c_str(), secs / frames * 1e3, out.c_str());
+                        tg.transport().c_str(), K, (batched || independent) ? "true" : "false",
+                        batched ? tg.sentBytes() / std::max(1, frames + (bench ? 2 * int(std::min(K, size_t(frames))) : 0)) : 0.0,
+                        batched ? tg.denseBytes() / std::max(1, frames + (bench ? 2 * int(std::min(K, size_t(frames))) : 0)) : 0.0,
+                        secs / frames * 1e3, secs / frames * 1e3, out.c_str());
             return 0;
         }
 
         VolumeRenderCL vr;
         if (!setup(vr, device)) return 0;
-        std::vector<float> frame;
+        std::vector<float> frame, all_frames;
         double kernel_s = 0.0;
+        if (frames_per_launch > 0) {
+            // ---- the throughput path on one GPU: F renderers over one shared volume take launch sets of <= K
+            // independent frames in turn (what bench.py times; volumerenderwidget.cpp:464-486 is the one-frame-per-
+            // paintGL caller this replaces for a caller that has many frames to render)
+            if (pathtrace || img_ess || use_ao_flag)
+                throw std::runtime_error("--frames-per-launch: ray caster only, no image-order ESS, no ambient occlusion");
+            const size_t K = size_t(std::min(256, std::max(1, frames_per_launch)));
+            const size_t F = size_t(std::max(1, frames_in_flight));
+            std::vector<std::unique_ptr<VolumeRenderCL>> twins;
+            std::vector<VolumeRenderCL *> lanes{&vr};
+            vr.setRoundBudget(unsigned(round_budget));
+            for (size_t j = 1; j < F; ++j) {
+                twins.push_back(vr.shareVolumes());
+                lanes.push_back(twins.back().get());
+            }
+            auto hip_ok = [](hipError_t e, const char *what) {
+                if (e != hipSuccess) throw std::runtime_error(std::string("ERROR: ") + what + " (" + hipGetErrorString(e) + ")");
+            };
+            hip_ok(hipSetDevice(device), "hipSetDevice");
+            std::vector<float *> blocks(F, nullptr);
+            std::vector<hipStream_t> streams(F);
+            for (size_t j = 0; j < F; ++j) {
+                hip_ok(hipMalloc(reinterpret_cast<void **>(&blocks[j]), K * W * H * 4 * sizeof(float)), "hipMalloc frames");
+                streams[j] = static_cast<hipStream_t>(lanes[j]->stream());
+                lanes[j]->setFrameTiming(false);   // nobody reads a set's own time: the next set may start under its tail
+            }
+            const std::vector<unsigned int> seeds = vr.drawSeeds(size_t(frames));
+            // launch sets of <= K frames, as many as a multiple of the renderers and all of (nearly) one size
+            size_t n_sets = (size_t(frames) + K - 1) / K;
+            n_sets = std::min(size_t(frames), (n_sets + F - 1) / F * F);
+            std::vector<std::vector<unsigned int>> sets;
+            for (size_t i = 0; i < n_sets; ++i) {
+                const size_t lo = size_t(std::llround(double(i) * frames / double(n_sets)));
+                const size_t hi = size_t(std::llround(double(i + 1) * frames / double(n_sets)));
+                if (hi > lo) sets.emplace_back(seeds.begin() + long(lo), seeds.begin() + long(hi));
+            }
+            if (bench) {   // every renderer once, untimed: buffers, work queue, skip bitmap, cell grid, cost map
+                std::mt19937 warm(20261004u);
+                for (size_t j = 0; j < F; ++j) {
+                    std::vector<unsigned int> ws(sets[0].size());
+                    for (auto &x : ws) x = static_cast<unsigned int>(warm());
+                    lanes[j]->renderFrames(W, H, ws, blocks[j]);
+                }
+                hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize");
+            }
+            hipEvent_t ev0, ev1;
+            std::vector<hipEvent_t> done(F);
+            hip_ok(hipEventCreate(&ev0), "hipEventCreate");
+            hip_ok(hipEventCreate(&ev1), "hipEventCreate");
+            for (auto &e : done) hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+            all_frames.reserve(bench ? 0 : size_t(frames) * W * H * 4);
+            const auto t0 = std::chrono::steady_clock::now();
+            hip_ok(hipEventRecord(ev0, streams[0]), "hipEventRecord");
+            for (size_t j = 1; j < F; ++j) hip_ok(hipStreamWaitEvent(streams[j], ev0, 0), "hipStreamWaitEvent");
+            for (size_t i = 0; i < sets.size(); ++i) {
+                lanes[i % F]->renderFrames(W, H, sets[i], blocks[i % F]);
+                if (!bench && ((i + 1) % F == 0 || i + 1 == sets.size())) {
+                    // the frames of this round of sets to the host, in frame order, before their blocks are reused
+                    hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize");
+                    for (size_t k = i / F * F; k <= i; ++k) {
+                        const size_t at = all_frames.size(), nfl = sets[k].size() * W * H * 4;
+                        all_frames.resize(at + nfl);
+                        hip_ok(hipMemcpy(all_frames.data() + at, blocks[k % F], nfl * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy");
+                    }
+                }
+            }
+            for (size_t j = 1; j < F; ++j) {
+                hip_ok(hipEventRecord(done[j], streams[j]), "hipEventRecord");
+                hip_ok(hipStreamWaitEvent(streams[0], done[j], 0), "hipStreamWaitEvent");
+            }
+            hip_ok(hipEventRecord(ev1, streams[0]), "hipEventRecord");
+            hip_ok(hipEventSynchronize(ev1), "hipEventSynchronize");
+            const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            float ms = 0.f;
+            hip_ok(hipEventElapsedTime(&ms, ev0, ev1), "hipEventElapsedTime");
+            // the last frame of the last set
+            const size_t last = sets.size() - 1;
+            frame.resize(W * H * 4);
+            hip_ok(hipMemcpy(frame.data(), blocks[last % F] + (sets[last].size() - 1) * W * H * 4, frame.size() * sizeof(float),
+                             hipMemcpyDeviceToHost), "hipMemcpy");
+            vrhip_launch_info li;
+            std::memset(&li, 0, sizeof li);
+            (void)vrhip_last_launch_info(lanes[last % F]->handle(), &li);
+            if (!all_frames.empty()) {
+                std::ofstream af(out + ".frames.rgba.f32", std::ios::binary);
+                af.write(reinterpret_cast<const char *>(all_frames.data()), std::streamsize(all_frames.size() * sizeof(float)));
+            }
+            std::ofstream raw(out + ".rgba.f32", std::ios::binary);
+            raw.write(reinterpret_cast<const char *>(frame.data()), std::streamsize(frame.size() * sizeof(float)));
+            write_ppm(out + ".ppm", frame, W, H);
+            auto res = vr.getResolution();
+            std::printf("{\"device\": \"%s\", \"volume\": [%u, %u, %u], \"width\": %zu, \"height\": %zu, \"frames\": %d, "
+                        "\"renderers\": %zu, \"launch_sets\": %zu, \"frames_per_launch_set\": %zu, \"round_budget\": %u, "
+                        "\"phase1_waves\": %u, \"phase2_waves\": %u, \"empty_skip\": %u, "
+                        "\"ms_per_frame\": %.5f, \"ms_per_frame_host_clock\": %.5f, \"bench\": %s, "
+                        "\"clock\": \"HIP events around the region on the first renderer's stream, the other renderers' "
+                        "streams joined before the second%s\", \"out\": \"%s.rgba.f32\"}\n",
+                        vr.getCurrentDeviceName().c_str(), res[0], res[1], res[2], W, H, frames, F, sets.size(),
+                        sets[0].size(), li.round_budget, li.phase1_waves, li.phase2_waves, li.empty_skip,
+                        double(ms) / frames, wall / frames * 1e3, bench ? "true" : "false",
+                        bench ? "" : " (frames copied to the host inside the region)", out.c_str());
+            for (float *b : blocks) (void)hipFree(b);
+            (void)hipEventDestroy(ev0);
+            (void)hipEventDestroy(ev1);
+            for (auto &e : done) (void)hipEventDestroy(e);
+            return 0;
+        }
+        const std::array<float, 16> the_view = have_view ? view : view_matrix(q, tr);
         for (int f = 0; f < frames; ++f) {
+            if (independent) vr.updateView(the_view);   // (resets the running mean: iteration 0, volumerendercl.cpp:379-390)
             vr.runRaycastNoGL(W, H, frame);   // frames accumulate (running mean), like the reference
             kernel_s += vr.getLastExecTime();
+            if (independent) all_frames.insert(all_frames.end(), frame.begin(), frame.end());
+        }
+        if (!all_frames.empty()) {
+            std::ofstream af(out + ".frames.rgba.f32", std::ios::binary);
+            af.write(reinterpret_cast<const char *>(all_frames.data()), std::streamsize(all_frames.size() * sizeof(float)));
         }
         std::ofstream raw(out + ".rgba.f32", std::ios::binary);
         raw.write(reinterpret_cast<const char *>(frame.data()), std::streamsize(frame.size() * sizeof(float)));

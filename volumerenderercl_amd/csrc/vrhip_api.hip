@@ -1146,11 +1146,140 @@ __global__ __launch_bounds__(256) void vr_assemble_batch_kernel(GatherMsgs msgs,
     }
 }
 
+// ---- the sparse gather message of a batch, packed on the GPU (vrhip_pack_tiles; the C++ host's TileGather):
+// [spad slot numbers | one pixel per slot | the whole tiles], spad = n_slots rounded up to 4 -- the format
+// vr_assemble_batch_kernel reads with maxc = spad (tiles.py packs the same with torch ops and maxc = the ranks'
+// largest count).
+
+// one workgroup per slot: is any pixel of the tile different (bit for bit) from its first?  Also the slot's pixel.
+__global__ __launch_bounds__(256) void vr_pack_flags_kernel(const uint4 *tiles, uint32_t P, int32_t *flags, uint4 *uni)
+{
+    const uint32_t s = blockIdx.x;
+    const uint4 *t = tiles + (size_t)s * P;
+    const uint4 first = t[0];
+    bool diff = false;
+    for (uint32_t i = threadIdx.x; i < P; i += 256u) {
+        const uint4 v = t[i];
+        diff = diff || v.x != first.x || v.y != first.y || v.z != first.z || v.w != first.w;
+    }
+    __shared__ uint32_t any;
+    if (threadIdx.x == 0) any = 0u;
+    __syncthreads();
+    if (__ballot(diff) && (threadIdx.x & 63u) == 0u) atomicOr(&any, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        flags[s] = any ? 1 : 0;
+        uni[s] = first;
+    }
+}
+
+// one workgroup: flags -> position among the whole tiles (or -1), the slot list and the count
+__global__ __launch_bounds__(1024) void vr_pack_scan_kernel(int32_t *flags_pos, uint32_t S, int32_t *slots, uint32_t *count)
+{
+    __shared__ uint32_t wave_sums[16];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0u;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t base = 0; base < S; base += 1024u) {
+        const uint32_t s = base + threadIdx.x;
+        const bool f = s < S && flags_pos[s] != 0;
+        const unsigned long long m = __ballot(f);
+        const uint32_t below = (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_sums[wave] = (uint32_t)__builtin_popcountll(m);
+        __syncthreads();
+        uint32_t off = carry;
+        for (uint32_t w = 0; w < wave; ++w) off += wave_sums[w];
+        if (s < S) {
+            flags_pos[s] = f ? (int32_t)(off + below) : -1;
+            if (f) slots[off + below] = (int32_t)s;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t t = 0;
+            for (uint32_t w = 0; w < 16u; ++w) t += wave_sums[w];
+            carry += t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count = carry;
+}
+
+// one workgroup per slot: a whole tile to its place in the message
+__global__ __launch_bounds__(256) void vr_pack_copy_kernel(const uint4 *tiles, uint32_t P, const int32_t *pos, uint4 *out)
+{
+    const int32_t p = pos[blockIdx.x];
+    if (p < 0) return;
+    const uint4 *t = tiles + (size_t)blockIdx.x * P;
+    uint4 *o = out + (size_t)p * P;
+    for (uint32_t i = threadIdx.x; i < P; i += 256u) o[i] = t[i];
+}
+
+// root: pos[rank][row] = -1, then the position of every listed slot
+__global__ __launch_bounds__(256) void vr_msg_pos_fill_kernel(int32_t *pos, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) pos[i] = -1;
+}
+struct GatherCounts { uint32_t c[kMaxGatherRanks]; };
+__global__ __launch_bounds__(256) void vr_msg_pos_scatter_kernel(GatherMsgs msgs, GatherCounts counts, uint32_t S, int32_t *pos)
+{
+    const uint32_t rank = blockIdx.y, i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= counts.c[rank]) return;
+    const uint32_t slot = (uint32_t)reinterpret_cast<const int32_t *>(msgs.p[rank])[i];
+    if (slot < S) pos[(size_t)rank * S + slot] = (int32_t)i;
+}
+
 } // namespace
 
 extern "C" {
 
 int vrhip_abi_version(void) { return VRHIP_ABI_VERSION; }
+
+int vrhip_pack_tiles(vrhip_renderer *r, void *hip_stream, const float *tiles_dev, uint32_t n_slots, uint32_t tile_pixels,
+                     int32_t *scratch_dev, float *msg_dev, uint32_t *count_dev)
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    VR_REQUIRE(r, tiles_dev && scratch_dev && msg_dev && count_dev && n_slots && tile_pixels &&
+                      ((uintptr_t)tiles_dev & 15u) == 0 && ((uintptr_t)msg_dev & 15u) == 0,
+               VRHIP_ERR_INVALID, "vrhip_pack_tiles: invalid argument (buffers must be 16-byte aligned)");
+    if (set_device(r)) return VRHIP_ERR_HIP;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const uint32_t spad = (n_slots + 3u) / 4u * 4u;
+    hipLaunchKernelGGL(vr_pack_flags_kernel, dim3(n_slots), dim3(256), 0, st, (const uint4 *)tiles_dev, tile_pixels,
+                       scratch_dev, (uint4 *)(msg_dev + spad));
+    hipLaunchKernelGGL(vr_pack_scan_kernel, dim3(1), dim3(1024), 0, st, scratch_dev, n_slots, (int32_t *)msg_dev, count_dev);
+    hipLaunchKernelGGL(vr_pack_copy_kernel, dim3(n_slots), dim3(256), 0, st, (const uint4 *)tiles_dev, tile_pixels,
+                       (const int32_t *)scratch_dev, (uint4 *)(msg_dev + spad + 4u * (size_t)n_slots));
+    VR_HIP(r, hipGetLastError());
+    return VRHIP_OK;
+}
+
+int vrhip_message_positions(vrhip_renderer *r, void *hip_stream, const float *const *msgs_dev, const uint32_t *counts_host,
+                            uint32_t world, uint32_t n_slots, int32_t *pos_dev)
+{
+    if (!r) return VRHIP_ERR_INVALID;
+    VR_REQUIRE(r, msgs_dev && counts_host && pos_dev && world >= 1 && world <= kMaxGatherRanks && n_slots,
+               VRHIP_ERR_INVALID, "vrhip_message_positions: invalid argument");
+    if (set_device(r)) return VRHIP_ERR_HIP;
+    hipStream_t st = (hipStream_t)hip_stream;
+    GatherMsgs g;
+    GatherCounts c;
+    uint32_t maxc = 0;
+    for (uint32_t i = 0; i < kMaxGatherRanks; ++i) {
+        g.p[i] = i < world ? msgs_dev[i] : nullptr;
+        c.c[i] = i < world ? counts_host[i] : 0u;
+        VR_REQUIRE(r, c.c[i] <= n_slots && (i >= world || g.p[i]), VRHIP_ERR_INVALID,
+                   "vrhip_message_positions: a count exceeds the number of slots, or a message is NULL");
+        maxc = std::max(maxc, c.c[i]);
+    }
+    const uint32_t n = world * n_slots;
+    hipLaunchKernelGGL(vr_msg_pos_fill_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, pos_dev, n);
+    if (maxc)
+        hipLaunchKernelGGL(vr_msg_pos_scatter_kernel, dim3((maxc + 255u) / 256u, world), dim3(256), 0, st, g, c, n_slots, pos_dev);
+    VR_HIP(r, hipGetLastError());
+    return VRHIP_OK;
+}
 
 int vrhip_create(int device_id, vrhip_renderer **out)
 {
