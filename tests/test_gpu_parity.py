@@ -647,7 +647,7 @@ def test_cpp_host_throughput_path_equals_frames_one_by_one(tmp_path):
         if name.startswith("r") and "--frames-per-launch" in more:
             import json
             line = json.loads(stdout.strip().splitlines()[-1])
-            assert line["sent_bytes_per_frame"] > 0
+            assert line["sent_bytes_per_frame"] > 0 or name == "r1"    # (one rank without --force-gather sends nothing)
             if name in ("r2", "r3", "r4"):      # the background tiles travelled as one pixel each
                 assert line["sent_bytes_per_frame"] < line["dense_bytes_per_frame"], line
 
