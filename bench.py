@@ -309,10 +309,18 @@ def main():
     # world > 1: `--frames-per-gather` independent frames share one collective (fewer, larger
     # gathers: the host-side cost of a collective is comparable to a rank's rendering time)
     fpg_want = args.frames_per_gather if args.frames_per_gather > 0 else max(64, 32 * world)
-    fpg = max(1, min(fpg_want, args.steps, 256 * max(1, args.frames_in_flight)))
     fif = max(1, args.frames_in_flight) if technique == 0 else 1
     fpl = max(1, min(args.frames_per_launch, 256)) if technique == 0 else 1
     throughput = fif > 1 or fpl > 1
+    # A SHORT run -- all the timed frames fit one launch set (the round driver's --steps 20) -- goes to ONE renderer
+    # as ONE set: two renderers with half the frames each pay a set's ramp and tail (pre-pass before anything marches,
+    # the last rays of phase 1, phase 2's tail: ~0.5 ms) side by side without hiding each other's, which is what a
+    # second renderer is for when sets follow one another.  Measured (tools/short_run_sweep.sh, tools/share_time.py
+    # TOTAL=20): 20 frames as 1 x 20 against 2 x 10: 0.197 against 0.221 ms per frame on one box, 0.190 / 0.193 on
+    # another; an 8-rank tile share 0.038 against 0.043.
+    if throughput and fif > 1 and args.steps <= fpl:
+        fif = 1
+    fpg = max(1, min(fpg_want, args.steps, 256 * fif))
     if args.round_budget <= 0:
         # One GPU: 48 rounds (rays stay in the leaner one-lane phase while other frames hide its latency).  A rank's
         # tile share of a short run cannot fill its GPU, and the set's time is the chain of its longest rays: fewer

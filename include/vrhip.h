@@ -316,6 +316,11 @@ typedef struct vrhip_launch_info {
 /* VRHIP_ERR_NODATA before the first render call. */
 int vrhip_last_launch_info(const vrhip_renderer *r, vrhip_launch_info *out);
 
+/* The per-pixel cost map of the two-phase march (no reference counterpart; a schedule, not a result): for every
+ * pixel of the last width x height frame the 4-lane rounds (16 samples each) its ray needed when it last reached
+ * the 4-lane kernel -- the key suspended rays are sorted by and rays are routed by.  n = width * height.  For tools. */
+int vrhip_download_cost_map(vrhip_renderer *r, uint16_t *out, size_t n);
+
 /* ---- measurement helpers ------------------------------------------- */
 /* When enabled, render calls run the instrumented kernel variant that accumulates
  * vrhip_stats (one atomic per wave). */

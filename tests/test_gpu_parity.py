@@ -2242,6 +2242,34 @@ def test_bench_multi_gpu_path_rehearsed_over_rccl_on_one_gpu(tmp_path):
         assert d["gather"]["mode"].startswith("sparse") and d["gather"]["sent_bytes_per_frame_to_root"] > 0
 
 
+def test_bench_multi_gpu_path_rehearsed_with_two_ranks_over_gloo(tmp_path):
+    """bench.py as torch.distributed.run launches it for N = 2 -- two ranks, every collective, tile shares, the sparse
+    batched gather, rank 0's assembly and its parity check of the timed region's own frames -- with both ranks on this
+    box's one GPU over gloo (VRHIP_BENCH_REHEARSAL=1; RCCL refuses two ranks on one device): nothing of the N > 1 path
+    runs for the first time on the 8-GPU node except the transport."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VRHIP_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for i, extra in enumerate((["--steps", "20", "--warmup", "5"],            # the round driver's arguments: one batch
+                               ["--steps", "12", "--warmup", "2", "--frames-per-gather", "5"],
+                               ["--steps", "6", "--warmup", "1", "--frames-in-flight", "1", "--frames-per-launch", "1"])):
+        out = tmp_path / ("line%d.json" % i)
+        p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                            "--master-addr", "127.0.0.1", "--master-port", str(29561 + i), os.path.join(root, "bench.py"),
+                            "--gpus", "2", "--workload", "sphere64", "--viewport", "192", "--tile", "32",
+                            "--out-json", str(out)] + extra, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-3000:])
+        d = json.loads(out.read_text())
+        assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+        assert d["parity"]["max_abs_diff"] <= TOL and d["parity"]["counters_equal"]
+        assert len(d["parity"]["timed_frames"]) >= 1 and all(c["max_abs_diff"] <= TOL for c in d["parity"]["timed_frames"])
+        assert d["cpu_baseline"] is None          # (rank 0 at N = 1 only)
+        assert len(d["gather"]["tiles_per_rank"]) == 2
+
+
 def test_control_blocks_alternate_cleanly(vr):
     """The work-queue control words live in two blocks; the first kernel of a set of launches zeroes the
     block of the next set (no memset launch per frame).  Whatever is interleaved -- instrumented frames,

@@ -122,6 +122,7 @@ SYMBOLS = {
     "vrhip_last_kernel_seconds": (C.c_double, [_H]),
     "vrhip_last_phase_seconds": (C.c_int, [_H, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vrhip_last_launch_info": (C.c_int, [_H, C.POINTER(LaunchInfo)]),
+    "vrhip_download_cost_map": (C.c_int, [_H, C.c_void_p, C.c_size_t]),
     "vrhip_set_phase_timing": (C.c_int, [_H, C.c_int]),
     "vrhip_set_frame_timing": (C.c_int, [_H, C.c_int]),
     "vrhip_build_source_hash": (C.c_char_p, []),

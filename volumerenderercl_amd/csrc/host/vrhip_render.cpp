@@ -487,7 +487,10 @@ int main(int argc, char **argv)
             if (pathtrace || img_ess || use_ao_flag)
                 throw std::runtime_error("--frames-per-launch: ray caster only, no image-order ESS, no ambient occlusion");
             const size_t K = size_t(std::min(256, std::max(1, frames_per_launch)));
-            const size_t F = size_t(std::max(1, frames_in_flight));
+            // (a short run -- all the frames fit one launch set -- goes to ONE renderer as one set: two renderers with
+            // half the frames each pay a set's ramp and tail side by side without hiding each other's; bench.py does
+            // the same)
+            const size_t F = size_t(frames) <= K ? 1 : size_t(std::max(1, frames_in_flight));
             std::vector<std::unique_ptr<VolumeRenderCL>> twins;
             std::vector<VolumeRenderCL *> lanes{&vr};
             vr.setRoundBudget(unsigned(round_budget));

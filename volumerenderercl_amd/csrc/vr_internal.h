@@ -173,6 +173,14 @@ struct FrameView {
     uint16_t *cost;        // W*H, or nullptr
     uint32_t *order;       // permutation of the suspended rays, or nullptr (append order)
     uint32_t *sort_ws;     // kSortBins counts + kSortBins cursors, zeroed before each launch
+    // Direct routing (one frame at a time; a schedule, not a result): a ray whose pixel needed at least
+    // `direct_min` 4-lane rounds in the previous frame is handed by the pre-pass straight to the 4-lane kernel,
+    // through a list of its own, instead of marching its first rounds with one lane: that kernel is launched on
+    // a second stream right behind the pre-pass and runs BESIDE phase 1 of the other rays -- the chain of the
+    // frame's longest rays starts ~130 us earlier (phase 1 + sort).  nullptr / 0: off.
+    ContRec *direct;
+    uint32_t *direct_count, *direct_head;   // zeroed before each launch (control words)
+    uint32_t direct_min;
     // Image-order ESS (rendering_params.imgEss, volumeraycast.cl:659-670, :912-925): one texel per
     // 8x8 work-group, (W/8 + 1) x (H/8 + 1) of them (volumerendercl.cpp:482-488).
     const uint8_t *hit_in; // last frame's hit image
@@ -186,7 +194,8 @@ struct FrameView {
     uint32_t env_w, env_h;
 };
 constexpr uint32_t kSortBins = 256;
-constexpr uint32_t kControlWords = 4 + 2 * kSortBins;   // queue head, cont count, cont head, pad, sort_ws
+// queue head, cont count, cont head, live count, sort_ws (bins + cursors), direct count, direct head, 2 x pad
+constexpr uint32_t kControlWords = 4 + 2 * kSortBins + 4;
 // first kernel of a set of launches, first workgroup: the control words of the next set (FrameView::next_ctrl)
 #define VR_ZERO_NEXT_CTRL(fr)                                                                              \
     do {                                                                                                   \
@@ -249,6 +258,10 @@ struct RaycastLaunch {
     uint32_t *touched;
     int num_cus;
     hipEvent_t mid_event;  // optional: recorded between the phase-1 and phase-2 launches
+    // direct routing (FrameView::direct): the second stream its 4-lane launch goes to, the event that orders it
+    // behind the pre-pass and the one the frame's own stream waits for at the end
+    hipStream_t aux_stream;
+    hipEvent_t fork_event, join_event;
     uint8_t *hit_out;      // imgEss: this frame's hit image (resolved after the march), or nullptr
     vrhip_launch_info *info;   // optional: the launchers record what they launched (vrhip_last_launch_info)
 };

@@ -480,32 +480,76 @@ struct EvalFront {
     uint32_t slot[kBatch];
 };
 
-// divergent part 1: density, transfer function, slots of the samples with an opacity, staged to LDS.
-// Returns the number of slots (the same in every lane that calls).
+// part 1: density, transfer function, slots of the samples with an opacity, staged to LDS.
+// Returns the number of slots (the same in every lane).
+//
+// -DVR_FRONT_GATHER (A/B builds only; measured in round 4 and not adopted): the density fetch and the
+// transfer-function lookup gathered as well -- the wave's VALID samples get slots of their own (ballot / mbcnt), their
+// positions go through the stage, all 64 lanes fetch and classify them in ceil(n / 64) dense passes and hand the four
+// TF values back through the same slots.  Bit-identical, phase 1 -4.8 % VALU instructions on the headline (a batch
+// runs with ~30 of 64 rays), no register spills left in the 12-wave kernels -- and +9 % frame time one frame at a
+// time, +7 % on dense volumes (every lane evaluates there anyway), -2 % only in the headline's throughput mode: the
+// two extra LDS round trips per batch cost more than the idle lanes (HISTORY.md).
 template <typename VT, bool FP, typename V>
 VR_DEV uint32_t eval_front(const V &vol, const float4 *s_tff, int tffn, float *s_stage, const RayCtx &c,
                            const vrhip_rendering_params &rp, const float (&tk)[kBatch], const bool (&vk)[kBatch],
                            bool ev, EvalFront &ef)
 {
     // Called by the whole wave: a VALU instruction costs the same with 30 lanes as with 64, and straight
-    // code spares the exec-mask bookkeeping of a divergent region around the batch.  Lanes whose ray does
-    // not evaluate this round (ev false: every vk false) only skip the voxel loads.
+    // code spares the exec-mask bookkeeping of a divergent region around the batch.
     f3 pk[kBatch];
-    float dens[kBatch];
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
         f3 pos = add3(c.cam, scale3(c.dir, tk[k] - c.offset));
         pk[k] = mk3(pos.x * 0.5f + 0.5f, pos.y * 0.5f + 0.5f, pos.z * 0.5f + 0.5f);
-        dens[k] = 0.f;
     }
+    const uint32_t lane = threadIdx.x & 63u;
+#ifndef VR_FRONT_GATHER
+    float dens[kBatch];
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) dens[k] = 0.f;
     if (ev) {
 #pragma unroll
         for (int k = 0; k < kBatch; ++k) dens[k] = vol.linear(pk[k].x, pk[k].y, pk[k].z);
     }
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) ef.tfc[k] = tff_linear(s_tff, tffn, dens[k]);
+#else
+    (void)ev;
+    {
+        uint32_t s1[kBatch], n1 = 0;
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+            const unsigned long long m = __ballot(vk[k]);
+            s1[k] = n1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            n1 += (uint32_t)__builtin_popcountll(m);
+        }
+        float4 *q4 = reinterpret_cast<float4 *>(s_stage);
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k)
+            if (vk[k]) q4[s1[k]] = make_float4(pk[k].x, pk[k].y, pk[k].z, 0.f);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t base = 0; base < n1; base += 64u) {
+            const uint32_t sidx = base + lane;
+            const bool mine = sidx < n1;
+            const float4 p = q4[mine ? sidx : 0u];
+            const float dv = vol.linear(p.x, p.y, p.z);   // (lanes past the end fetch slot 0's sample again: a valid address)
+            const float4 t = tff_linear(s_tff, tffn, dv);
+            if (mine) q4[sidx] = t;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+            ef.tfc[k] = make_float4(0.f, 0.f, 0.f, 0.f);   // (a sample that is not valid is never composited)
+            if (vk[k]) ef.tfc[k] = q4[s1[k]];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // the slots are free for the second gather
+    }
+#endif
     const bool shade_mode = rp.illumType == 1;   // :809
-    const uint32_t lane = threadIdx.x & 63u;
     uint32_t n_slots = 0;
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
@@ -1168,12 +1212,25 @@ __global__ __launch_bounds__(kBlockDim) void vr_dda_prepass_kernel(
     }
     if (fr.live_rays) {
         // ray list for phase 1 (vr_raycast_rays_kernel): the live rays with the DDA state they have
-        // reached, so that phase 1 neither repeats the walk nor carries the patch's dead lanes
+        // reached, so that phase 1 neither repeats the walk nor carries the patch's dead lanes.
+        // Direct routing (FrameView::direct): rays predicted long by last frame's cost of their pixel go to the
+        // 4-lane kernel's list instead (same record; the key rides along for a sort)
         if (m) {
-            uint32_t base = 0;
-            if (lane == (uint32_t)__builtin_ctzll(m))
-                base = atomicAdd(fr.live_count, (uint32_t)__builtin_popcountll(m));
-            base = __shfl(base, __builtin_ctzll(m), 64);
+            uint32_t key = 0;
+            if (fr.direct && live) key = (uint32_t)fr.cost[(size_t)gy * fr.W + gx];
+            const bool dl = live && fr.direct && key >= fr.direct_min;
+            const unsigned long long md = __ballot(dl), ms = m & ~md;
+            uint32_t base = 0, based = 0;
+            if (ms) {
+                if (lane == (uint32_t)__builtin_ctzll(ms))
+                    base = atomicAdd(fr.live_count, (uint32_t)__builtin_popcountll(ms));
+                base = __shfl(base, __builtin_ctzll(ms), 64);
+            }
+            if (md) {
+                if (lane == (uint32_t)__builtin_ctzll(md))
+                    based = atomicAdd(fr.direct_count, (uint32_t)__builtin_popcountll(md));
+                based = __shfl(based, __builtin_ctzll(md), 64);
+            }
             if (live) {
                 ContRec r;
                 r.pix = gx | (gy << 16);
@@ -1183,8 +1240,10 @@ __global__ __launch_bounds__(kBlockDim) void vr_dda_prepass_kernel(
                 r.r0 = d.r0; r.r1 = d.r1; r.r2 = d.r2;
                 r.cx = d.c0; r.cy = d.c1; r.cz = d.c2;
                 r.tv0 = d.tv0; r.tv1 = d.tv1; r.tv2 = d.tv2;
-                r.pad = 0;
-                fr.live_rays[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = r;
+                r.pad = key;
+                const unsigned long long below = (1ull << lane) - 1ull;
+                if (dl) fr.direct[based + (uint32_t)__builtin_popcountll(md & below)] = r;
+                else fr.live_rays[base + (uint32_t)__builtin_popcountll(ms & below)] = r;
             }
         }
         return;
@@ -2065,6 +2124,8 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
     if (grid.x == 0) return hipSuccess;
     FrameView frame = a.frame;
     if (XS || INSTR != 0 || !ESS) frame.live_rays = nullptr;   // the ray list serves the default kernels
+    if (XS || INSTR != 0 || !ESS || !frame.live_rays || !frame.cost || !a.aux_stream) frame.direct = nullptr;
+    bool direct_launched = false;
     if (a.info) {   // what this call launches, for vrhip_last_launch_info (completed below)
         vrhip_launch_info &li = *a.info;
         li.technique = 0;
@@ -2097,6 +2158,29 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
         hipError_t pe = hipGetLastError();
         if (pe != hipSuccess) return pe;
         if (a.info) { a.info->prepass = 1; a.info->patch_classes = frame.patch_class ? 1u : 0u; }
+        if (frame.direct && frame.live_rays && !XS && a.frame.round_budget && a.aux_stream) {
+            // direct routing: the 4-lane kernel on the pre-pass's list of predicted-long rays, on the second stream,
+            // beside phase 1 (one workgroup per CU: workgroups that find the list drained leave at once)
+            FrameView fd = frame;
+            fd.cont = frame.direct;
+            fd.cont_count = frame.direct_count;
+            fd.cont_head = frame.direct_head;
+            fd.order = nullptr;
+            fd.next_ctrl = nullptr;
+            auto kd = vr_raycast_split_kernel<VT, ESS, INSTR, SKIP_LDS, XS, FP>;
+            int nbd = 0;
+            hipError_t de = prepare_variant(kd, lds, &nbd, "raycast phase 2 (direct)", a.num_cus);
+            if (de == hipSuccess) de = hipEventRecord(a.fork_event, stream);
+            if (de == hipSuccess) de = hipStreamWaitEvent(a.aux_stream, a.fork_event, 0);
+            if (de != hipSuccess) return de;
+            hipLaunchKernelGGL(kd, dim3(cus), block, lds, a.aux_stream, a.vol, a.bricks, a.tf, a.skip, a.cells, fd, a.cam,
+                               a.render, a.raycast, a.stats, a.touched);
+            de = hipGetLastError();
+            if (de == hipSuccess) de = hipEventRecord(a.join_event, a.aux_stream);
+            if (de != hipSuccess) return de;
+            direct_launched = true;
+            if (a.info) a.info->direct_long = 1;
+        }
     } else {
         frame.live = nullptr;
     }
@@ -2133,7 +2217,7 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
     }
     e = hipGetLastError();
     if (e == hipSuccess && a.mid_event) e = hipEventRecord(a.mid_event, stream);
-    if (e != hipSuccess || a.frame.round_budget == 0) return e;
+    if (e != hipSuccess || a.frame.round_budget == 0) return e;   // (no direct launch without a round budget)
     if (a.frame.order) {   // longest rays first (keys: last frame's phase-2 rounds per pixel)
         hipLaunchKernelGGL(vr_cont_hist_kernel, dim3(128), block, 0, stream, a.frame.cont,
                            a.frame.cont_count, a.frame.sort_ws);
@@ -2147,7 +2231,10 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
     dim3 grid2(cus * (uint32_t)nb2);
     hipLaunchKernelGGL(k2, grid2, dim3(waves2 * 64), lds2, stream, a.vol, a.bricks, a.tf, a.skip, a.cells, frame, a.cam,
                        a.render, a.raycast, a.stats, a.touched);
-    return hipGetLastError();
+    e = hipGetLastError();
+    // the frame is complete when the direct rays' kernel is, too
+    if (e == hipSuccess && direct_launched) e = hipStreamWaitEvent(stream, a.join_event, 0);
+    return e;
 }
 
 template <typename VT>

@@ -126,6 +126,12 @@ struct vrhip_renderer {
     bool prepass = true;              // VRHIP_NO_PREPASS=1 disables
     ContRec *cont = nullptr;          // suspended rays of the two-phase march
     size_t cont_cap = 0;
+    ContRec *direct = nullptr;        // direct routing: the pre-pass's list of predicted-long rays (FrameView::direct)
+    size_t direct_cap = 0;
+    uint32_t direct_min = 0;          // VRHIP_DIRECT_MIN: 4-lane rounds last frame from which a ray goes direct (0 = off, the default:
+                                      // measured slower at every threshold)
+    hipStream_t aux_stream = nullptr; // the direct rays' 4-lane kernel runs here, beside phase 1
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint32_t round_budget = 10;       // phase-1 sample rounds per patch (0 = single phase)
     uint32_t refill_min = 16;         // phase 2: idle ray slots per wave before a refill (VRHIP_REFILL_MIN)
     std::vector<uint32_t> queue_key;   // W, H, tile_w, tile_h, tile ids...
@@ -823,6 +829,14 @@ int ensure_queue(vrhip_renderer *r, uint32_t W, uint32_t H, uint32_t tile_w, uin
         VR_HIP(r, hipMalloc((void **)&r->live_rays, need * sizeof(ContRec)));
         r->cont_cap = need;
     }
+    // direct routing serves one frame at a time: its list (worst case every ray) exists for single-frame queues only
+    if (n_frames == 1 && r->direct_min && need > r->direct_cap) {
+        if (r->direct) VR_HIP(r, hipFree(r->direct));
+        r->direct = nullptr;
+        r->direct_cap = 0;
+        VR_HIP(r, hipMalloc((void **)&r->direct, need * sizeof(ContRec)));
+        r->direct_cap = need;
+    }
     return VRHIP_OK;
 }
 
@@ -878,6 +892,18 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
     a->frame.cost = r->sort_cont ? r->cost : nullptr;
     a->frame.order = r->sort_cont && r->cost ? r->order : nullptr;
     a->frame.sort_ws = ctrl + 4;
+    // direct routing: one frame per launch set, the default schedule's pieces in place (pre-pass, ray list, cost map,
+    // a round budget), production kernels (launch_variant looks at the kernel variant)
+    if (r->queue_frames == 1 && r->direct_min && r->direct && r->direct_cap >= (size_t)r->queue_n * 64 && r->prepass &&
+        r->ray_list && r->sort_cont && r->cost && r->round_budget && !r->stats_enabled) {
+        a->frame.direct = r->direct;
+        a->frame.direct_count = ctrl + 4 + 2 * kSortBins;
+        a->frame.direct_head = ctrl + 5 + 2 * kSortBins;
+        a->frame.direct_min = r->direct_min;
+        a->aux_stream = r->aux_stream;
+        a->fork_event = r->ev_fork;
+        a->join_event = r->ev_join;
+    }
     a->frame.fb = r->fb;
     if (r->render.imgEss && r->render.technique == 0) {
         a->frame.hit_in = r->hit_in;
@@ -1302,6 +1328,9 @@ int vrhip_create(int device_id, vrhip_renderer **out)
         (e = hipEventCreate(&r->evm)) != hipSuccess ||
         (e = hipEventCreate(&r->evb0)) != hipSuccess ||
         (e = hipEventCreate(&r->evb1)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&r->aux_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&r->ev_join, hipEventDisableTiming)) != hipSuccess ||
         (e = hipMalloc((void **)&r->stats_dev, sizeof(DevStats))) != hipSuccess ||
         (e = hipMalloc((void **)&r->queue_head, 2 * kControlWords * sizeof(uint32_t))) != hipSuccess) {
         std::string msg = std::string("ERROR: vrhip_create (") + hipGetErrorString(e) + ")";
@@ -1329,6 +1358,7 @@ int vrhip_create(int device_id, vrhip_renderer **out)
     if (const char *e = getenv("VRHIP_MARCH_MICRO")) r->march_micro = (uint32_t)atoi(e);
     if (const char *e = getenv("VRHIP_MARCH_FILL")) r->march_fill = (uint32_t)atoi(e);
     if (getenv("VRHIP_NO_SORT")) r->sort_cont = false;         // experiments: phase 2 in append order
+    if (const char *e = getenv("VRHIP_DIRECT_MIN")) r->direct_min = (uint32_t)std::max(0, atoi(e));   // A/B: 0 = no direct routing
     if (getenv("VRHIP_NO_PATCH_CLASS")) r->use_patch_classes = false;   // A/B: every patch sets up its rays
     auto occ_env = [](const char *name, int dflt) {
         const char *e = getenv(name);
@@ -1369,6 +1399,7 @@ void vrhip_destroy(vrhip_renderer *r)
     if (r->queue_dev) (void)hipFree(r->queue_dev);
     if (r->queue_head) (void)hipFree(r->queue_head);
     if (r->cont) (void)hipFree(r->cont);
+    if (r->direct) (void)hipFree(r->direct);
     if (r->cost) (void)hipFree(r->cost);
     for (uint8_t *p : {r->hit_in, r->hit_out, r->hit_status, r->hit_any})
         if (p) (void)hipFree(p);
@@ -1391,6 +1422,9 @@ void vrhip_destroy(vrhip_renderer *r)
     if (r->evm) (void)hipEventDestroy(r->evm);
     if (r->evb0) (void)hipEventDestroy(r->evb0);
     if (r->evb1) (void)hipEventDestroy(r->evb1);
+    if (r->ev_fork) (void)hipEventDestroy(r->ev_fork);
+    if (r->ev_join) (void)hipEventDestroy(r->ev_join);
+    if (r->aux_stream) { (void)hipStreamSynchronize(r->aux_stream); (void)hipStreamDestroy(r->aux_stream); }
     if (r->own_stream) (void)hipStreamDestroy(r->own_stream);
     delete r;
 }
@@ -2000,6 +2034,17 @@ int vrhip_last_launch_info(const vrhip_renderer *r, vrhip_launch_info *out)
     if (!r || !out) return VRHIP_ERR_INVALID;
     if (!r->have_info) return fail(r, VRHIP_ERR_NODATA, "vrhip_last_launch_info: nothing has been rendered yet");
     *out = r->last_info;
+    return VRHIP_OK;
+}
+
+int vrhip_download_cost_map(vrhip_renderer *r, uint16_t *out, size_t n)
+{
+    if (!r || !out) return VRHIP_ERR_INVALID;
+    if (set_device(r)) return VRHIP_ERR_HIP;
+    VR_REQUIRE(r, r->cost && n == (size_t)r->fb_w * r->fb_h, VRHIP_ERR_NODATA,
+               "vrhip_download_cost_map: no cost map of this size (render a frame first)");
+    VR_HIP(r, hipStreamSynchronize(r->stream));
+    VR_HIP(r, hipMemcpy(out, r->cost, n * sizeof(uint16_t), hipMemcpyDeviceToHost));
     return VRHIP_OK;
 }
 
