@@ -75,9 +75,10 @@ def parse():
     ap.add_argument("--frame-timing", type=int, default=0,
                     help="throughput mode on one GPU: 1 = keep the renderers' own events around every launch set "
                          "(vrhip_set_frame_timing; the region is timed as a whole either way)")
-    ap.add_argument("--frames-in-flight", type=int, default=2,
-                    help="single GPU: renderers (one stream each, sharing the volume) that alternate "
-                         "frames, so that the tail of one frame overlaps the head of the next")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="renderers (one stream each, sharing the volume) that take the launch sets in turn, so that "
+                         "the tail of one set overlaps the head of the next; 0 = two, or one when all the timed frames "
+                         "fit ONE launch set (--steps <= --frames-per-launch)")
     ap.add_argument("--root-share", default="auto",
                     help="multi-GPU: the fraction of a peer's tiles rank 0 renders (it also assembles every frame); "
                          "auto = (1 + a - N a) / (1 + a) with a = 0.055, the assembly's share of a whole frame's "
@@ -309,7 +310,7 @@ def main():
     # world > 1: `--frames-per-gather` independent frames share one collective (fewer, larger
     # gathers: the host-side cost of a collective is comparable to a rank's rendering time)
     fpg_want = args.frames_per_gather if args.frames_per_gather > 0 else max(64, 32 * world)
-    fif = max(1, args.frames_in_flight) if technique == 0 else 1
+    fif = (args.frames_in_flight if args.frames_in_flight > 0 else 2) if technique == 0 else 1
     fpl = max(1, min(args.frames_per_launch, 256)) if technique == 0 else 1
     throughput = fif > 1 or fpl > 1
     # A SHORT run -- all the timed frames fit one launch set (the round driver's --steps 20) -- goes to ONE renderer
@@ -318,7 +319,7 @@ def main():
     # second renderer is for when sets follow one another.  Measured (tools/short_run_sweep.sh, tools/share_time.py
     # TOTAL=20): 20 frames as 1 x 20 against 2 x 10: 0.197 against 0.221 ms per frame on one box, 0.190 / 0.193 on
     # another; an 8-rank tile share 0.038 against 0.043.
-    if throughput and fif > 1 and args.steps <= fpl:
+    if throughput and args.frames_in_flight <= 0 and args.steps <= fpl:
         fif = 1
     fpg = max(1, min(fpg_want, args.steps, 256 * fif))
     if args.round_budget <= 0:

@@ -311,7 +311,8 @@ typedef struct vrhip_launch_info {
     uint32_t patch_classes;  /* 1: the pre-pass used per-patch classes                                  */
     uint32_t sorted_phase2;  /* 1: suspended rays were counting-sorted, longest first                   */
     uint32_t direct_long;    /* 1: rays predicted long went straight to the 4-lane kernel               */
-    uint32_t reserved[16];
+    uint32_t sorted_phase1;  /* 1: the pre-pass's ray list was counting-sorted by predicted length      */
+    uint32_t reserved[15];
 } vrhip_launch_info;
 /* VRHIP_ERR_NODATA before the first render call. */
 int vrhip_last_launch_info(const vrhip_renderer *r, vrhip_launch_info *out);

@@ -1217,14 +1217,22 @@ __global__ __launch_bounds__(kBlockDim) void vr_dda_prepass_kernel(
         // 4-lane kernel's list instead (same record; the key rides along for a sort)
         if (m) {
             uint32_t key = 0;
-            if (fr.direct && live) key = (uint32_t)fr.cost[(size_t)gy * fr.W + gx];
+            if ((fr.direct || fr.live_short_count) && live) key = (uint32_t)fr.cost[(size_t)gy * fr.W + gx];
             const bool dl = live && fr.direct && key >= fr.direct_min;
-            const unsigned long long md = __ballot(dl), ms = m & ~md;
-            uint32_t base = 0, based = 0;
+            const unsigned long long md = __ballot(dl);
+            // long rays first: the patch's rays of known long pixels to the front of the list, the others to its back
+            const bool sh = live && !dl && fr.live_short_count && key < fr.long_min;
+            const unsigned long long mb = __ballot(sh), ms = m & ~md & ~mb;
+            uint32_t base = 0, based = 0, baseb = 0;
             if (ms) {
                 if (lane == (uint32_t)__builtin_ctzll(ms))
                     base = atomicAdd(fr.live_count, (uint32_t)__builtin_popcountll(ms));
                 base = __shfl(base, __builtin_ctzll(ms), 64);
+            }
+            if (mb) {
+                if (lane == (uint32_t)__builtin_ctzll(mb))
+                    baseb = atomicAdd(fr.live_short_count, (uint32_t)__builtin_popcountll(mb));
+                baseb = __shfl(baseb, __builtin_ctzll(mb), 64);
             }
             if (md) {
                 if (lane == (uint32_t)__builtin_ctzll(md))
@@ -1243,6 +1251,7 @@ __global__ __launch_bounds__(kBlockDim) void vr_dda_prepass_kernel(
                 r.pad = key;
                 const unsigned long long below = (1ull << lane) - 1ull;
                 if (dl) fr.direct[based + (uint32_t)__builtin_popcountll(md & below)] = r;
+                else if (sh) fr.live_rays[fr.live_cap - 1u - (baseb + (uint32_t)__builtin_popcountll(mb & below))] = r;
                 else fr.live_rays[base + (uint32_t)__builtin_popcountll(ms & below)] = r;
             }
         }
@@ -1279,7 +1288,10 @@ __global__ __launch_bounds__(WAVES * 64) void vr_raycast_rays_kernel(
     VolView vv, BrickView bricks, TfView tf, SkipView skip, CellView cells, FrameView fr,
     vrhip_camera_params cam, vrhip_rendering_params rp, vrhip_raycast_params rc)
 {
-    const uint32_t n_rays = *fr.live_count;   // written by the pre-pass (previous kernel on the stream)
+    // written by the pre-pass (previous kernel on the stream): the rays at the front of the list (all of them, or the
+    // long ones) and, with long rays first, the others at its back
+    const uint32_t n_front = *fr.live_count;
+    const uint32_t n_rays = n_front + (fr.live_short_count ? *fr.live_short_count : 0u);
     if (n_rays == 0) return;
     extern __shared__ float4 s_mem[];
     float *s_stage = reinterpret_cast<float *>(s_mem) + (threadIdx.x >> 6) * kStageFloatsPerWave;
@@ -1304,6 +1316,7 @@ __global__ __launch_bounds__(WAVES * 64) void vr_raycast_rays_kernel(
     const uint32_t leap_iters = fr.march_micro;
 #endif
     const uint32_t budget = fr.round_budget ? fr.round_budget : 0xffffffffu;
+    uint32_t my_budget = budget;   // long rays first: by the ray's predicted length (FrameView::live_short_count)
     const uint32_t kRefillLanes = (fr.refill_min ? fr.refill_min : 16u) * 4u;   // idle lanes before a refill
 
     unsigned long long n0 = 0, n1 = 0;
@@ -1333,6 +1346,8 @@ __global__ __launch_bounds__(WAVES * 64) void vr_raycast_rays_kernel(
                 VR_MS(8, 1);                                                   // refills
                 if (idle && have) {   // retire a finished ray (suspended ones have given up `have`)
                     write_pixel<false>(fr, rp, c, d, voxLen, gx, gy, (size_t)out_index);
+                    // the ray's length for the next frame's schedules, in units of 16 samples (FrameView::cost)
+                    if (fr.cost) fr.cost[(size_t)gy * fr.W + gx] = (uint16_t)((my_rounds + 3u) >> 2);
                     have = false;
                 }
                 if (!drained) {
@@ -1344,11 +1359,15 @@ __global__ __launch_bounds__(WAVES * 64) void vr_raycast_rays_kernel(
                         const uint32_t ri = base + (uint32_t)__builtin_popcountll(idle_m & ((1ull << lane) - 1ull));
                         have = ri < n_rays;
                         if (have) {
-                            const ContRec rec = fr.live_rays[ri];
+                            const ContRec rec = fr.live_rays[ri < n_front ? ri : fr.live_cap - 1u - (ri - n_front)];
                             gx = rec.pix & 0xffffu;
                             gy = rec.pix >> 16;
                             out_index = rec.out_index;
-                            frame_idx = (uint32_t)rec.state >> 8;
+                            frame_idx = ((uint32_t)rec.state >> kRecFrameShift) & 0xffu;
+                            // a ray whose length is known (key = 16-sample units = 4 rounds each) marches twice its
+                            // predicted rounds plus a margin before it is handed to the 4-lane kernel; an unknown
+                            // one the set's budget
+                            my_budget = (fr.live_short_count && ri < n_front) ? 8u * rec.pad + 16u : budget;
                             setup_ray<true>(gx, gy, true, fr, cam, rp, rc, resf, voxLen, grid, c, d,
                                             fr.seeds ? fr.seeds[frame_idx] : rp.seed);
                             d.state = rec.state & 0xff;
@@ -1387,7 +1406,7 @@ __global__ __launch_bounds__(WAVES * 64) void vr_raycast_rays_kernel(
         VR_MARK("R_susp");
         // a ray that has used its rounds goes to the continuation buffer (phase 2)
         {
-            const bool susp = d.state != S_DONE && my_rounds >= budget;
+            const bool susp = d.state != S_DONE && my_rounds >= my_budget;
             const unsigned long long cm = __ballot(susp);
             if (cm) {
                 uint32_t base = 0;
@@ -1398,7 +1417,8 @@ __global__ __launch_bounds__(WAVES * 64) void vr_raycast_rays_kernel(
                     ContRec r;
                     r.pix = gx | (gy << 16);
                     r.out_index = out_index;
-                    r.state = d.state | (int32_t)(frame_idx << 8);
+                    r.state = d.state | (int32_t)(frame_idx << kRecFrameShift) |
+                              (int32_t)((my_rounds < 65535u ? my_rounds : 65535u) << kRecRoundsShift);
                     r.t = d.t; r.t_exit = d.t_exit; r.alpha = d.alpha;
                     r.r0 = d.r0; r.r1 = d.r1; r.r2 = d.r2;
                     r.cx = d.c0; r.cy = d.c1; r.cz = d.c2;
@@ -1748,7 +1768,7 @@ __global__ __launch_bounds__(WAVES * 64) void vr_raycast_split_kernel(
     unsigned long long dummy0 = 0, dummy1 = 0;
     const bool count = INSTR && slot == 0;
     bool have = false, drained = false;
-    uint32_t gx = 0, gy = 0, out_index = 0, my_rounds = 0;
+    uint32_t gx = 0, gy = 0, out_index = 0, my_rounds = 0, p1_units = 0;
     bool guess_empty = true;   // identical in the four lanes of a ray, like all of its state
     uint32_t cool = 0;         // evaluation batches before the ray guesses "empty" again
     RayCtx c;
@@ -1769,8 +1789,10 @@ __global__ __launch_bounds__(WAVES * 64) void vr_raycast_split_kernel(
                         apply_ao<VT, INSTR>(vol, s_tff, tffn, c, d, rp, gx, gy);
                     if (slot == 0) {
                         write_pixel<XS>(fr, rp, c, d, voxLen, gx, gy, (size_t)out_index);
-                        if (fr.cost)
-                            fr.cost[(size_t)gy * fr.W + gx] = (uint16_t)(my_rounds < 65535u ? my_rounds : 65535u);
+                        if (fr.cost) {
+                            const uint32_t units = p1_units + my_rounds;   // the ray's whole length, 16 samples per unit
+                            fr.cost[(size_t)gy * fr.W + gx] = (uint16_t)(units < 65535u ? units : 65535u);
+                        }
                     }
                     have = false;
                 }
@@ -1791,7 +1813,8 @@ __global__ __launch_bounds__(WAVES * 64) void vr_raycast_split_kernel(
                             gx = rec.pix & 0xffffu;
                             gy = rec.pix >> 16;
                             out_index = rec.out_index;
-                            const uint32_t f = (uint32_t)rec.state >> 8;
+                            const uint32_t f = ((uint32_t)rec.state >> kRecFrameShift) & 0xffu;
+                            p1_units = (((uint32_t)rec.state >> kRecRoundsShift) + 3u) >> 2;   // one-lane rounds so far, in 16-sample units
                             setup_ray<ESS>(gx, gy, true, fr, cam, rp, rc, resf, voxLen, grid, c, d,
                                            fr.seeds ? fr.seeds[f] : rp.seed);
                             d.state = rec.state & 0xff;
@@ -2125,6 +2148,7 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
     FrameView frame = a.frame;
     if (XS || INSTR != 0 || !ESS) frame.live_rays = nullptr;   // the ray list serves the default kernels
     if (XS || INSTR != 0 || !ESS || !frame.live_rays || !frame.cost || !a.aux_stream) frame.direct = nullptr;
+    if (XS || INSTR != 0 || !ESS || !frame.live_rays || !frame.cost || !frame.live) frame.live_short_count = nullptr;
     bool direct_launched = false;
     if (a.info) {   // what this call launches, for vrhip_last_launch_info (completed below)
         vrhip_launch_info &li = *a.info;
@@ -2191,6 +2215,7 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
         return launch_march<VT, SKIP_LDS, FP>(a, frame, block, cus, stream);   // the whole frame in one launch
 #endif
     if (ESS && INSTR == 0 && !XS && frame.live && frame.live_rays) {   // phase 1 on the ray list
+        if (a.info) a.info->sorted_phase1 = frame.live_short_count ? 1u : 0u;   // (long rays first)
         // phase 1 picks its own schedule: two or three waves per SIMD (three: footprint volume only), the skip
         // bitmap in LDS whenever it fits
         constexpr bool kWideR = FP;

@@ -115,6 +115,8 @@ struct vrhip_renderer {
     bool frame_timing = true;         // vrhip_set_frame_timing: events around a frame's launches (vrhip_last_kernel_seconds)
     uint16_t *cost = nullptr;         // per pixel: phase-2 rounds of the previous frame (sort key)
     uint32_t *order = nullptr;        // sorted permutation of the suspended rays
+    int long_first = -1;              // VRHIP_LONG_FIRST=0|1: long rays first in phase 1 off / for every launch set (-1: sets of >= 4 frames)
+    uint32_t long_min = 0;            // VRHIP_LONG_MIN: cost (16-sample units) from which a ray is long (0 = beyond the round budget)
     ContRec *live_rays = nullptr;     // pre-pass output: live rays with their DDA state (phase 1's list)
     bool ray_list = true;             // VRHIP_NO_RAYLIST=1: phase 1 walks the live patches instead
     bool march = false;               // VRHIP_MARCH=1: vr_march_kernel instead of the two-phase march (measured, not faster)
@@ -892,6 +894,14 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
     a->frame.cost = r->sort_cont ? r->cost : nullptr;
     a->frame.order = r->sort_cont && r->cost ? r->order : nullptr;
     a->frame.sort_ws = ctrl + 4;
+    // long rays first (FrameView::live_short_count): launch sets of several frames -- where rays stay 48 rounds and
+    // more in the one-lane phase and a set ends with the 4-lane chain of its few longest rays
+    if ((r->long_first < 0 ? r->queue_frames >= 4u : r->long_first != 0) && r->prepass && r->ray_list && r->sort_cont &&
+        r->cost && r->round_budget && !r->stats_enabled && r->live_rays) {
+        a->frame.live_short_count = ctrl + 6 + 2 * kSortBins;
+        a->frame.live_cap = (uint32_t)r->cont_cap;
+        a->frame.long_min = r->long_min ? r->long_min : r->round_budget / 4u + 1u;
+    }
     // direct routing: one frame per launch set, the default schedule's pieces in place (pre-pass, ray list, cost map,
     // a round budget), production kernels (launch_variant looks at the kernel variant)
     if (r->queue_frames == 1 && r->direct_min && r->direct && r->direct_cap >= (size_t)r->queue_n * 64 && r->prepass &&
@@ -1358,6 +1368,8 @@ int vrhip_create(int device_id, vrhip_renderer **out)
     if (const char *e = getenv("VRHIP_MARCH_MICRO")) r->march_micro = (uint32_t)atoi(e);
     if (const char *e = getenv("VRHIP_MARCH_FILL")) r->march_fill = (uint32_t)atoi(e);
     if (getenv("VRHIP_NO_SORT")) r->sort_cont = false;         // experiments: phase 2 in append order
+    if (const char *e = getenv("VRHIP_LONG_FIRST")) r->long_first = atoi(e) != 0 ? 1 : 0;   // A/B: long rays first off / always
+    if (const char *e = getenv("VRHIP_LONG_MIN")) r->long_min = (uint32_t)std::max(0, atoi(e));
     if (const char *e = getenv("VRHIP_DIRECT_MIN")) r->direct_min = (uint32_t)std::max(0, atoi(e));   // A/B: 0 = no direct routing
     if (getenv("VRHIP_NO_PATCH_CLASS")) r->use_patch_classes = false;   // A/B: every patch sets up its rays
     auto occ_env = [](const char *name, int dflt) {
