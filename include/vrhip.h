@@ -310,16 +310,14 @@ typedef struct vrhip_launch_info {
     uint32_t extras;         /* 1: the variants with the rarer modes (illumType 2-5, AO, contours, ...) */
     uint32_t patch_classes;  /* 1: the pre-pass used per-patch classes                                  */
     uint32_t sorted_phase2;  /* 1: suspended rays were counting-sorted, longest first                   */
-    uint32_t direct_long;    /* 1: rays predicted long went straight to the 4-lane kernel               */
-    uint32_t sorted_phase1;  /* 1: the pre-pass's ray list was counting-sorted by predicted length      */
-    uint32_t reserved[15];
+    uint32_t reserved[17];
 } vrhip_launch_info;
 /* VRHIP_ERR_NODATA before the first render call. */
 int vrhip_last_launch_info(const vrhip_renderer *r, vrhip_launch_info *out);
 
 /* The per-pixel cost map of the two-phase march (no reference counterpart; a schedule, not a result): for every
  * pixel of the last width x height frame the 4-lane rounds (16 samples each) its ray needed when it last reached
- * the 4-lane kernel -- the key suspended rays are sorted by and rays are routed by.  n = width * height.  For tools. */
+ * the 4-lane kernel -- the key suspended rays are sorted by.  n = width * height.  For tools (tools/costmap.py). */
 int vrhip_download_cost_map(vrhip_renderer *r, uint16_t *out, size_t n);
 
 /* ---- measurement helpers ------------------------------------------- */

@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/single_sweep.sh [WORKLOAD] -- one frame at a time under a set of schedule knobs (first line of tools/costmap.py)
 WL=${1:-shells2048}
-run() { echo "== $*"; env VRHIP_DIRECT_MIN=0 "$@" python3 tools/costmap.py $WL 2>&1 | head -1 | cut -c1-110; }
+run() { echo "== $*"; env "$@" python3 tools/costmap.py $WL 2>&1 | head -1 | cut -c1-110; }
 run A=0
 run VRHIP_OCC_P2=3
 run VRHIP_OCC_P1=3

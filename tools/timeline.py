@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/timeline.py KERNEL_TRACE.csv [SKIP_FRAMES] -- one frame at a time: when does every launch of a frame start
 and end, relative to the start of the frame's pre-pass (means over the frames of a rocprofv3 --kernel-trace csv of
-`bench.py --profile-region --frames-in-flight 1 --frames-per-launch 1`)?  Launches on the second stream (direct
+`bench.py --profile-region --frames-in-flight 1 --frames-per-launch 1`)?  Launches on a second stream (e.g. an experiment with
 routing) overlap the others: durations alone (tools/gaps.py) do not show that."""
 import csv
 import re

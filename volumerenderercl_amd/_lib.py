@@ -53,8 +53,7 @@ class LaunchInfo(C.Structure):
     """vrhip_launch_info: what the last render call launched."""
     _fields_ = [(n, C.c_uint32) for n in (
         "technique", "frames", "work_items", "prepass", "ray_list", "phase1_waves", "phase2_waves", "round_budget",
-        "footprint", "empty_skip", "skip_in_lds", "instrumented", "extras", "patch_classes", "sorted_phase2",
-        "direct_long", "sorted_phase1")] + [("reserved", C.c_uint32 * 15)]
+        "footprint", "empty_skip", "skip_in_lds", "instrumented", "extras", "patch_classes", "sorted_phase2")] + [("reserved", C.c_uint32 * 17)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "reserved"}

@@ -173,24 +173,6 @@ struct FrameView {
     uint16_t *cost;        // W*H, or nullptr
     uint32_t *order;       // permutation of the suspended rays, or nullptr (append order)
     uint32_t *sort_ws;     // kSortBins counts + kSortBins cursors, zeroed before each launch
-    // Direct routing (one frame at a time; a schedule, not a result): a ray whose pixel needed at least
-    // `direct_min` 4-lane rounds in the previous frame is handed by the pre-pass straight to the 4-lane kernel,
-    // through a list of its own, instead of marching its first rounds with one lane: that kernel is launched on
-    // a second stream right behind the pre-pass and runs BESIDE phase 1 of the other rays -- the chain of the
-    // frame's longest rays starts ~130 us earlier (phase 1 + sort).  nullptr / 0: off.
-    ContRec *direct;
-    uint32_t *direct_count, *direct_head;   // zeroed before each launch (control words)
-    uint32_t direct_min;
-    // Long rays first (launch sets of several frames; a schedule, not a result).  `cost` holds a ray's WHOLE length
-    // in units of 16 samples, written by whichever kernel retires the ray.  The pre-pass appends the rays whose
-    // pixel's cost is at least `long_min` to the FRONT of the ray list and the others to its BACK (a second cursor
-    // counting down from `live_cap`): phase 1 draws the long rays first, in waves of their own, and lets a ray of
-    // known length march its predicted rounds (twice that, plus a margin) with one lane instead of `round_budget` --
-    // the set's longest chains start at its beginning, and phase 2's ~0.3 ms at the end of a set, with the machine
-    // nearly idle, is left to the mispredicted.  Both halves keep the pre-pass's append order (a counting sort of the
-    // list by cost was 12 % slower than no order at all: neighbouring rays share cache lines).  nullptr: one list.
-    uint32_t *live_short_count;   // zeroed before each launch (control words)
-    uint32_t live_cap, long_min;
     // Image-order ESS (rendering_params.imgEss, volumeraycast.cl:659-670, :912-925): one texel per
     // 8x8 work-group, (W/8 + 1) x (H/8 + 1) of them (volumerendercl.cpp:482-488).
     const uint8_t *hit_in; // last frame's hit image
@@ -204,11 +186,7 @@ struct FrameView {
     uint32_t env_w, env_h;
 };
 constexpr uint32_t kSortBins = 256;
-// queue head, cont count, cont head, live count, sort_ws (bins + cursors), direct count, direct head, short count, pad
-constexpr uint32_t kControlWords = 4 + 2 * kSortBins + 4;
-// ContRec::state: bits 0..7 the ray's state, 8..15 the frame of the launch set, 16..31 the one-lane rounds (4 samples
-// each) the ray had marched when phase 1 suspended it (the 4-lane kernel adds them to the cost it writes)
-constexpr uint32_t kRecFrameShift = 8, kRecRoundsShift = 16;
+constexpr uint32_t kControlWords = 4 + 2 * kSortBins;   // queue head, cont count, cont head, pad, sort_ws
 // first kernel of a set of launches, first workgroup: the control words of the next set (FrameView::next_ctrl)
 #define VR_ZERO_NEXT_CTRL(fr)                                                                              \
     do {                                                                                                   \
@@ -271,10 +249,6 @@ struct RaycastLaunch {
     uint32_t *touched;
     int num_cus;
     hipEvent_t mid_event;  // optional: recorded between the phase-1 and phase-2 launches
-    // direct routing (FrameView::direct): the second stream its 4-lane launch goes to, the event that orders it
-    // behind the pre-pass and the one the frame's own stream waits for at the end
-    hipStream_t aux_stream;
-    hipEvent_t fork_event, join_event;
     uint8_t *hit_out;      // imgEss: this frame's hit image (resolved after the march), or nullptr
     vrhip_launch_info *info;   // optional: the launchers record what they launched (vrhip_last_launch_info)
 };

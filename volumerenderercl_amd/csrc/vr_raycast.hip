@@ -480,76 +480,32 @@ struct EvalFront {
     uint32_t slot[kBatch];
 };
 
-// part 1: density, transfer function, slots of the samples with an opacity, staged to LDS.
-// Returns the number of slots (the same in every lane).
-//
-// -DVR_FRONT_GATHER (A/B builds only; measured in round 4 and not adopted): the density fetch and the
-// transfer-function lookup gathered as well -- the wave's VALID samples get slots of their own (ballot / mbcnt), their
-// positions go through the stage, all 64 lanes fetch and classify them in ceil(n / 64) dense passes and hand the four
-// TF values back through the same slots.  Bit-identical, phase 1 -4.8 % VALU instructions on the headline (a batch
-// runs with ~30 of 64 rays), no register spills left in the 12-wave kernels -- and +9 % frame time one frame at a
-// time, +7 % on dense volumes (every lane evaluates there anyway), -2 % only in the headline's throughput mode: the
-// two extra LDS round trips per batch cost more than the idle lanes (HISTORY.md).
+// divergent part 1: density, transfer function, slots of the samples with an opacity, staged to LDS.
+// Returns the number of slots (the same in every lane that calls).
 template <typename VT, bool FP, typename V>
 VR_DEV uint32_t eval_front(const V &vol, const float4 *s_tff, int tffn, float *s_stage, const RayCtx &c,
                            const vrhip_rendering_params &rp, const float (&tk)[kBatch], const bool (&vk)[kBatch],
                            bool ev, EvalFront &ef)
 {
     // Called by the whole wave: a VALU instruction costs the same with 30 lanes as with 64, and straight
-    // code spares the exec-mask bookkeeping of a divergent region around the batch.
+    // code spares the exec-mask bookkeeping of a divergent region around the batch.  Lanes whose ray does
+    // not evaluate this round (ev false: every vk false) only skip the voxel loads.
     f3 pk[kBatch];
+    float dens[kBatch];
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
         f3 pos = add3(c.cam, scale3(c.dir, tk[k] - c.offset));
         pk[k] = mk3(pos.x * 0.5f + 0.5f, pos.y * 0.5f + 0.5f, pos.z * 0.5f + 0.5f);
+        dens[k] = 0.f;
     }
-    const uint32_t lane = threadIdx.x & 63u;
-#ifndef VR_FRONT_GATHER
-    float dens[kBatch];
-#pragma unroll
-    for (int k = 0; k < kBatch; ++k) dens[k] = 0.f;
     if (ev) {
 #pragma unroll
         for (int k = 0; k < kBatch; ++k) dens[k] = vol.linear(pk[k].x, pk[k].y, pk[k].z);
     }
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) ef.tfc[k] = tff_linear(s_tff, tffn, dens[k]);
-#else
-    (void)ev;
-    {
-        uint32_t s1[kBatch], n1 = 0;
-#pragma unroll
-        for (int k = 0; k < kBatch; ++k) {
-            const unsigned long long m = __ballot(vk[k]);
-            s1[k] = n1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            n1 += (uint32_t)__builtin_popcountll(m);
-        }
-        float4 *q4 = reinterpret_cast<float4 *>(s_stage);
-#pragma unroll
-        for (int k = 0; k < kBatch; ++k)
-            if (vk[k]) q4[s1[k]] = make_float4(pk[k].x, pk[k].y, pk[k].z, 0.f);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t base = 0; base < n1; base += 64u) {
-            const uint32_t sidx = base + lane;
-            const bool mine = sidx < n1;
-            const float4 p = q4[mine ? sidx : 0u];
-            const float dv = vol.linear(p.x, p.y, p.z);   // (lanes past the end fetch slot 0's sample again: a valid address)
-            const float4 t = tff_linear(s_tff, tffn, dv);
-            if (mine) q4[sidx] = t;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int k = 0; k < kBatch; ++k) {
-            ef.tfc[k] = make_float4(0.f, 0.f, 0.f, 0.f);   // (a sample that is not valid is never composited)
-            if (vk[k]) ef.tfc[k] = q4[s1[k]];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();   // the slots are free for the second gather
-    }
-#endif
     const bool shade_mode = rp.illumType == 1;   // :809
+    const uint32_t lane = threadIdx.x & 63u;
     uint32_t n_slots = 0;
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
@@ -1212,33 +1168,12 @@ __global__ __launch_bounds__(kBlockDim) void vr_dda_prepass_kernel(
     }
     if (fr.live_rays) {
         // ray list for phase 1 (vr_raycast_rays_kernel): the live rays with the DDA state they have
-        // reached, so that phase 1 neither repeats the walk nor carries the patch's dead lanes.
-        // Direct routing (FrameView::direct): rays predicted long by last frame's cost of their pixel go to the
-        // 4-lane kernel's list instead (same record; the key rides along for a sort)
+        // reached, so that phase 1 neither repeats the walk nor carries the patch's dead lanes
         if (m) {
-            uint32_t key = 0;
-            if ((fr.direct || fr.live_short_count) && live) key = (uint32_t)fr.cost[(size_t)gy * fr.W + gx];
-            const bool dl = live && fr.direct && key >= fr.direct_min;
-            const unsigned long long md = __ballot(dl);
-            // long rays first: the patch's rays of known long pixels to the front of the list, the others to its back
-            const bool sh = live && !dl && fr.live_short_count && key < fr.long_min;
-            const unsigned long long mb = __ballot(sh), ms = m & ~md & ~mb;
-            uint32_t base = 0, based = 0, baseb = 0;
-            if (ms) {
-                if (lane == (uint32_t)__builtin_ctzll(ms))
-                    base = atomicAdd(fr.live_count, (uint32_t)__builtin_popcountll(ms));
-                base = __shfl(base, __builtin_ctzll(ms), 64);
-            }
-            if (mb) {
-                if (lane == (uint32_t)__builtin_ctzll(mb))
-                    baseb = atomicAdd(fr.live_short_count, (uint32_t)__builtin_popcountll(mb));
-                baseb = __shfl(baseb, __builtin_ctzll(mb), 64);
-            }
-            if (md) {
-                if (lane == (uint32_t)__builtin_ctzll(md))
-                    based = atomicAdd(fr.direct_count, (uint32_t)__builtin_popcountll(md));
-                based = __shfl(based, __builtin_ctzll(md), 64);
-            }
+            uint32_t base = 0;
+            if (lane == (uint32_t)__builtin_ctzll(m))
+                base = atomicAdd(fr.live_count, (uint32_t)__builtin_popcountll(m));
+            base = __shfl(base, __builtin_ctzll(m), 64);
             if (live) {
                 ContRec r;
                 r.pix = gx | (gy << 16);
@@ -1248,11 +1183,8 @@ __global__ __launch_bounds__(kBlockDim) void vr_dda_prepass_kernel(
                 r.r0 = d.r0; r.r1 = d.r1; r.r2 = d.r2;
                 r.cx = d.c0; r.cy = d.c1; r.cz = d.c2;
                 r.tv0 = d.tv0; r.tv1 = d.tv1; r.tv2 = d.tv2;
-                r.pad = key;
-                const unsigned long long below = (1ull << lane) - 1ull;
-                if (dl) fr.direct[based + (uint32_t)__builtin_popcountll(md & below)] = r;
-                else if (sh) fr.live_rays[fr.live_cap - 1u - (baseb + (uint32_t)__builtin_popcountll(mb & below))] = r;
-                else fr.live_rays[base + (uint32_t)__builtin_popcountll(ms & below)] = r;
+                r.pad = 0;
+                fr.live_rays[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = r;
             }
         }
         return;
@@ -1288,10 +1220,7 @@ __global__ __launch_bounds__(WAVES * 64) void vr_raycast_rays_kernel(
     VolView vv, BrickView bricks, TfView tf, SkipView skip, CellView cells, FrameView fr,
     vrhip_camera_params cam, vrhip_rendering_params rp, vrhip_raycast_params rc)
 {
-    // written by the pre-pass (previous kernel on the stream): the rays at the front of the list (all of them, or the
-    // long ones) and, with long rays first, the others at its back
-    const uint32_t n_front = *fr.live_count;
-    const uint32_t n_rays = n_front + (fr.live_short_count ? *fr.live_short_count : 0u);
+    const uint32_t n_rays = *fr.live_count;   // written by the pre-pass (previous kernel on the stream)
     if (n_rays == 0) return;
     extern __shared__ float4 s_mem[];
     float *s_stage = reinterpret_cast<float *>(s_mem) + (threadIdx.x >> 6) * kStageFloatsPerWave;
@@ -1316,7 +1245,6 @@ __global__ __launch_bounds__(WAVES * 64) void vr_raycast_rays_kernel(
     const uint32_t leap_iters = fr.march_micro;
 #endif
     const uint32_t budget = fr.round_budget ? fr.round_budget : 0xffffffffu;
-    uint32_t my_budget = budget;   // long rays first: by the ray's predicted length (FrameView::live_short_count)
     const uint32_t kRefillLanes = (fr.refill_min ? fr.refill_min : 16u) * 4u;   // idle lanes before a refill
 
     unsigned long long n0 = 0, n1 = 0;
@@ -1346,8 +1274,6 @@ __global__ __launch_bounds__(WAVES * 64) void vr_raycast_rays_kernel(
                 VR_MS(8, 1);                                                   // refills
                 if (idle && have) {   // retire a finished ray (suspended ones have given up `have`)
                     write_pixel<false>(fr, rp, c, d, voxLen, gx, gy, (size_t)out_index);
-                    // the ray's length for the next frame's schedules, in units of 16 samples (FrameView::cost)
-                    if (fr.cost) fr.cost[(size_t)gy * fr.W + gx] = (uint16_t)((my_rounds + 3u) >> 2);
                     have = false;
                 }
                 if (!drained) {
@@ -1359,15 +1285,11 @@ __global__ __launch_bounds__(WAVES * 64) void vr_raycast_rays_kernel(
                         const uint32_t ri = base + (uint32_t)__builtin_popcountll(idle_m & ((1ull << lane) - 1ull));
                         have = ri < n_rays;
                         if (have) {
-                            const ContRec rec = fr.live_rays[ri < n_front ? ri : fr.live_cap - 1u - (ri - n_front)];
+                            const ContRec rec = fr.live_rays[ri];
                             gx = rec.pix & 0xffffu;
                             gy = rec.pix >> 16;
                             out_index = rec.out_index;
-                            frame_idx = ((uint32_t)rec.state >> kRecFrameShift) & 0xffu;
-                            // a ray whose length is known (key = 16-sample units = 4 rounds each) marches twice its
-                            // predicted rounds plus a margin before it is handed to the 4-lane kernel; an unknown
-                            // one the set's budget
-                            my_budget = (fr.live_short_count && ri < n_front) ? 8u * rec.pad + 16u : budget;
+                            frame_idx = (uint32_t)rec.state >> 8;
                             setup_ray<true>(gx, gy, true, fr, cam, rp, rc, resf, voxLen, grid, c, d,
                                             fr.seeds ? fr.seeds[frame_idx] : rp.seed);
                             d.state = rec.state & 0xff;
@@ -1406,7 +1328,7 @@ __global__ __launch_bounds__(WAVES * 64) void vr_raycast_rays_kernel(
         VR_MARK("R_susp");
         // a ray that has used its rounds goes to the continuation buffer (phase 2)
         {
-            const bool susp = d.state != S_DONE && my_rounds >= my_budget;
+            const bool susp = d.state != S_DONE && my_rounds >= budget;
             const unsigned long long cm = __ballot(susp);
             if (cm) {
                 uint32_t base = 0;
@@ -1417,8 +1339,7 @@ __global__ __launch_bounds__(WAVES * 64) void vr_raycast_rays_kernel(
                     ContRec r;
                     r.pix = gx | (gy << 16);
                     r.out_index = out_index;
-                    r.state = d.state | (int32_t)(frame_idx << kRecFrameShift) |
-                              (int32_t)((my_rounds < 65535u ? my_rounds : 65535u) << kRecRoundsShift);
+                    r.state = d.state | (int32_t)(frame_idx << 8);
                     r.t = d.t; r.t_exit = d.t_exit; r.alpha = d.alpha;
                     r.r0 = d.r0; r.r1 = d.r1; r.r2 = d.r2;
                     r.cx = d.c0; r.cy = d.c1; r.cz = d.c2;
@@ -1768,7 +1689,7 @@ __global__ __launch_bounds__(WAVES * 64) void vr_raycast_split_kernel(
     unsigned long long dummy0 = 0, dummy1 = 0;
     const bool count = INSTR && slot == 0;
     bool have = false, drained = false;
-    uint32_t gx = 0, gy = 0, out_index = 0, my_rounds = 0, p1_units = 0;
+    uint32_t gx = 0, gy = 0, out_index = 0, my_rounds = 0;
     bool guess_empty = true;   // identical in the four lanes of a ray, like all of its state
     uint32_t cool = 0;         // evaluation batches before the ray guesses "empty" again
     RayCtx c;
@@ -1789,10 +1710,8 @@ __global__ __launch_bounds__(WAVES * 64) void vr_raycast_split_kernel(
                         apply_ao<VT, INSTR>(vol, s_tff, tffn, c, d, rp, gx, gy);
                     if (slot == 0) {
                         write_pixel<XS>(fr, rp, c, d, voxLen, gx, gy, (size_t)out_index);
-                        if (fr.cost) {
-                            const uint32_t units = p1_units + my_rounds;   // the ray's whole length, 16 samples per unit
-                            fr.cost[(size_t)gy * fr.W + gx] = (uint16_t)(units < 65535u ? units : 65535u);
-                        }
+                        if (fr.cost)
+                            fr.cost[(size_t)gy * fr.W + gx] = (uint16_t)(my_rounds < 65535u ? my_rounds : 65535u);
                     }
                     have = false;
                 }
@@ -1813,8 +1732,7 @@ __global__ __launch_bounds__(WAVES * 64) void vr_raycast_split_kernel(
                             gx = rec.pix & 0xffffu;
                             gy = rec.pix >> 16;
                             out_index = rec.out_index;
-                            const uint32_t f = ((uint32_t)rec.state >> kRecFrameShift) & 0xffu;
-                            p1_units = (((uint32_t)rec.state >> kRecRoundsShift) + 3u) >> 2;   // one-lane rounds so far, in 16-sample units
+                            const uint32_t f = (uint32_t)rec.state >> 8;
                             setup_ray<ESS>(gx, gy, true, fr, cam, rp, rc, resf, voxLen, grid, c, d,
                                            fr.seeds ? fr.seeds[f] : rp.seed);
                             d.state = rec.state & 0xff;
@@ -2147,9 +2065,6 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
     if (grid.x == 0) return hipSuccess;
     FrameView frame = a.frame;
     if (XS || INSTR != 0 || !ESS) frame.live_rays = nullptr;   // the ray list serves the default kernels
-    if (XS || INSTR != 0 || !ESS || !frame.live_rays || !frame.cost || !a.aux_stream) frame.direct = nullptr;
-    if (XS || INSTR != 0 || !ESS || !frame.live_rays || !frame.cost || !frame.live) frame.live_short_count = nullptr;
-    bool direct_launched = false;
     if (a.info) {   // what this call launches, for vrhip_last_launch_info (completed below)
         vrhip_launch_info &li = *a.info;
         li.technique = 0;
@@ -2182,29 +2097,6 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
         hipError_t pe = hipGetLastError();
         if (pe != hipSuccess) return pe;
         if (a.info) { a.info->prepass = 1; a.info->patch_classes = frame.patch_class ? 1u : 0u; }
-        if (frame.direct && frame.live_rays && !XS && a.frame.round_budget && a.aux_stream) {
-            // direct routing: the 4-lane kernel on the pre-pass's list of predicted-long rays, on the second stream,
-            // beside phase 1 (one workgroup per CU: workgroups that find the list drained leave at once)
-            FrameView fd = frame;
-            fd.cont = frame.direct;
-            fd.cont_count = frame.direct_count;
-            fd.cont_head = frame.direct_head;
-            fd.order = nullptr;
-            fd.next_ctrl = nullptr;
-            auto kd = vr_raycast_split_kernel<VT, ESS, INSTR, SKIP_LDS, XS, FP>;
-            int nbd = 0;
-            hipError_t de = prepare_variant(kd, lds, &nbd, "raycast phase 2 (direct)", a.num_cus);
-            if (de == hipSuccess) de = hipEventRecord(a.fork_event, stream);
-            if (de == hipSuccess) de = hipStreamWaitEvent(a.aux_stream, a.fork_event, 0);
-            if (de != hipSuccess) return de;
-            hipLaunchKernelGGL(kd, dim3(cus), block, lds, a.aux_stream, a.vol, a.bricks, a.tf, a.skip, a.cells, fd, a.cam,
-                               a.render, a.raycast, a.stats, a.touched);
-            de = hipGetLastError();
-            if (de == hipSuccess) de = hipEventRecord(a.join_event, a.aux_stream);
-            if (de != hipSuccess) return de;
-            direct_launched = true;
-            if (a.info) a.info->direct_long = 1;
-        }
     } else {
         frame.live = nullptr;
     }
@@ -2215,7 +2107,6 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
         return launch_march<VT, SKIP_LDS, FP>(a, frame, block, cus, stream);   // the whole frame in one launch
 #endif
     if (ESS && INSTR == 0 && !XS && frame.live && frame.live_rays) {   // phase 1 on the ray list
-        if (a.info) a.info->sorted_phase1 = frame.live_short_count ? 1u : 0u;   // (long rays first)
         // phase 1 picks its own schedule: two or three waves per SIMD (three: footprint volume only), the skip
         // bitmap in LDS whenever it fits
         constexpr bool kWideR = FP;
@@ -2242,7 +2133,7 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
     }
     e = hipGetLastError();
     if (e == hipSuccess && a.mid_event) e = hipEventRecord(a.mid_event, stream);
-    if (e != hipSuccess || a.frame.round_budget == 0) return e;   // (no direct launch without a round budget)
+    if (e != hipSuccess || a.frame.round_budget == 0) return e;
     if (a.frame.order) {   // longest rays first (keys: last frame's phase-2 rounds per pixel)
         hipLaunchKernelGGL(vr_cont_hist_kernel, dim3(128), block, 0, stream, a.frame.cont,
                            a.frame.cont_count, a.frame.sort_ws);
@@ -2256,10 +2147,7 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
     dim3 grid2(cus * (uint32_t)nb2);
     hipLaunchKernelGGL(k2, grid2, dim3(waves2 * 64), lds2, stream, a.vol, a.bricks, a.tf, a.skip, a.cells, frame, a.cam,
                        a.render, a.raycast, a.stats, a.touched);
-    e = hipGetLastError();
-    // the frame is complete when the direct rays' kernel is, too
-    if (e == hipSuccess && direct_launched) e = hipStreamWaitEvent(stream, a.join_event, 0);
-    return e;
+    return hipGetLastError();
 }
 
 template <typename VT>

@@ -115,8 +115,6 @@ struct vrhip_renderer {
     bool frame_timing = true;         // vrhip_set_frame_timing: events around a frame's launches (vrhip_last_kernel_seconds)
     uint16_t *cost = nullptr;         // per pixel: phase-2 rounds of the previous frame (sort key)
     uint32_t *order = nullptr;        // sorted permutation of the suspended rays
-    int long_first = -1;              // VRHIP_LONG_FIRST=0|1: long rays first in phase 1 off / for every launch set (-1: sets of >= 4 frames)
-    uint32_t long_min = 0;            // VRHIP_LONG_MIN: cost (16-sample units) from which a ray is long (0 = beyond the round budget)
     ContRec *live_rays = nullptr;     // pre-pass output: live rays with their DDA state (phase 1's list)
     bool ray_list = true;             // VRHIP_NO_RAYLIST=1: phase 1 walks the live patches instead
     bool march = false;               // VRHIP_MARCH=1: vr_march_kernel instead of the two-phase march (measured, not faster)
@@ -128,12 +126,6 @@ struct vrhip_renderer {
     bool prepass = true;              // VRHIP_NO_PREPASS=1 disables
     ContRec *cont = nullptr;          // suspended rays of the two-phase march
     size_t cont_cap = 0;
-    ContRec *direct = nullptr;        // direct routing: the pre-pass's list of predicted-long rays (FrameView::direct)
-    size_t direct_cap = 0;
-    uint32_t direct_min = 0;          // VRHIP_DIRECT_MIN: 4-lane rounds last frame from which a ray goes direct (0 = off, the default:
-                                      // measured slower at every threshold)
-    hipStream_t aux_stream = nullptr; // the direct rays' 4-lane kernel runs here, beside phase 1
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint32_t round_budget = 10;       // phase-1 sample rounds per patch (0 = single phase)
     uint32_t refill_min = 16;         // phase 2: idle ray slots per wave before a refill (VRHIP_REFILL_MIN)
     std::vector<uint32_t> queue_key;   // W, H, tile_w, tile_h, tile ids...
@@ -831,14 +823,6 @@ int ensure_queue(vrhip_renderer *r, uint32_t W, uint32_t H, uint32_t tile_w, uin
         VR_HIP(r, hipMalloc((void **)&r->live_rays, need * sizeof(ContRec)));
         r->cont_cap = need;
     }
-    // direct routing serves one frame at a time: its list (worst case every ray) exists for single-frame queues only
-    if (n_frames == 1 && r->direct_min && need > r->direct_cap) {
-        if (r->direct) VR_HIP(r, hipFree(r->direct));
-        r->direct = nullptr;
-        r->direct_cap = 0;
-        VR_HIP(r, hipMalloc((void **)&r->direct, need * sizeof(ContRec)));
-        r->direct_cap = need;
-    }
     return VRHIP_OK;
 }
 
@@ -894,26 +878,6 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
     a->frame.cost = r->sort_cont ? r->cost : nullptr;
     a->frame.order = r->sort_cont && r->cost ? r->order : nullptr;
     a->frame.sort_ws = ctrl + 4;
-    // long rays first (FrameView::live_short_count): launch sets of several frames -- where rays stay 48 rounds and
-    // more in the one-lane phase and a set ends with the 4-lane chain of its few longest rays
-    if ((r->long_first < 0 ? r->queue_frames >= 4u : r->long_first != 0) && r->prepass && r->ray_list && r->sort_cont &&
-        r->cost && r->round_budget && !r->stats_enabled && r->live_rays) {
-        a->frame.live_short_count = ctrl + 6 + 2 * kSortBins;
-        a->frame.live_cap = (uint32_t)r->cont_cap;
-        a->frame.long_min = r->long_min ? r->long_min : r->round_budget / 4u + 1u;
-    }
-    // direct routing: one frame per launch set, the default schedule's pieces in place (pre-pass, ray list, cost map,
-    // a round budget), production kernels (launch_variant looks at the kernel variant)
-    if (r->queue_frames == 1 && r->direct_min && r->direct && r->direct_cap >= (size_t)r->queue_n * 64 && r->prepass &&
-        r->ray_list && r->sort_cont && r->cost && r->round_budget && !r->stats_enabled) {
-        a->frame.direct = r->direct;
-        a->frame.direct_count = ctrl + 4 + 2 * kSortBins;
-        a->frame.direct_head = ctrl + 5 + 2 * kSortBins;
-        a->frame.direct_min = r->direct_min;
-        a->aux_stream = r->aux_stream;
-        a->fork_event = r->ev_fork;
-        a->join_event = r->ev_join;
-    }
     a->frame.fb = r->fb;
     if (r->render.imgEss && r->render.technique == 0) {
         a->frame.hit_in = r->hit_in;
@@ -1338,9 +1302,6 @@ int vrhip_create(int device_id, vrhip_renderer **out)
         (e = hipEventCreate(&r->evm)) != hipSuccess ||
         (e = hipEventCreate(&r->evb0)) != hipSuccess ||
         (e = hipEventCreate(&r->evb1)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&r->aux_stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&r->ev_join, hipEventDisableTiming)) != hipSuccess ||
         (e = hipMalloc((void **)&r->stats_dev, sizeof(DevStats))) != hipSuccess ||
         (e = hipMalloc((void **)&r->queue_head, 2 * kControlWords * sizeof(uint32_t))) != hipSuccess) {
         std::string msg = std::string("ERROR: vrhip_create (") + hipGetErrorString(e) + ")";
@@ -1368,9 +1329,6 @@ int vrhip_create(int device_id, vrhip_renderer **out)
     if (const char *e = getenv("VRHIP_MARCH_MICRO")) r->march_micro = (uint32_t)atoi(e);
     if (const char *e = getenv("VRHIP_MARCH_FILL")) r->march_fill = (uint32_t)atoi(e);
     if (getenv("VRHIP_NO_SORT")) r->sort_cont = false;         // experiments: phase 2 in append order
-    if (const char *e = getenv("VRHIP_LONG_FIRST")) r->long_first = atoi(e) != 0 ? 1 : 0;   // A/B: long rays first off / always
-    if (const char *e = getenv("VRHIP_LONG_MIN")) r->long_min = (uint32_t)std::max(0, atoi(e));
-    if (const char *e = getenv("VRHIP_DIRECT_MIN")) r->direct_min = (uint32_t)std::max(0, atoi(e));   // A/B: 0 = no direct routing
     if (getenv("VRHIP_NO_PATCH_CLASS")) r->use_patch_classes = false;   // A/B: every patch sets up its rays
     auto occ_env = [](const char *name, int dflt) {
         const char *e = getenv(name);
@@ -1411,7 +1369,6 @@ void vrhip_destroy(vrhip_renderer *r)
     if (r->queue_dev) (void)hipFree(r->queue_dev);
     if (r->queue_head) (void)hipFree(r->queue_head);
     if (r->cont) (void)hipFree(r->cont);
-    if (r->direct) (void)hipFree(r->direct);
     if (r->cost) (void)hipFree(r->cost);
     for (uint8_t *p : {r->hit_in, r->hit_out, r->hit_status, r->hit_any})
         if (p) (void)hipFree(p);
@@ -1434,9 +1391,6 @@ void vrhip_destroy(vrhip_renderer *r)
     if (r->evm) (void)hipEventDestroy(r->evm);
     if (r->evb0) (void)hipEventDestroy(r->evb0);
     if (r->evb1) (void)hipEventDestroy(r->evb1);
-    if (r->ev_fork) (void)hipEventDestroy(r->ev_fork);
-    if (r->ev_join) (void)hipEventDestroy(r->ev_join);
-    if (r->aux_stream) { (void)hipStreamSynchronize(r->aux_stream); (void)hipStreamDestroy(r->aux_stream); }
     if (r->own_stream) (void)hipStreamDestroy(r->own_stream);
     delete r;
 }
