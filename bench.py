@@ -633,12 +633,15 @@ def main():
                      "streaming kernel of the path is vr_build_bricks (see bricks_build)") +
                     ("" if frac_ok else "; no fraction printed: the counters' traffic is BELOW the algorithmic bytes"),
         }
-        # What actually bounds the march: VALU issue.  A gfx950 SIMD issues one wave64 VALU
-        # instruction per 2 cycles (MI355X_MICROARCH.md "Wave scheduling"; = the 157.3 TFLOP/s fp32
-        # vector peak / 128 flops), so the chip peaks at 256 CUs x 4 SIMDs x 2.4 GHz / 2.
+        # What actually bounds the march: VALU issue.  A gfx950 SIMD has 16 lanes: a wave64 VALU instruction occupies
+        # it for FOUR cycles -- plain or packed (v_pk_fma_f32: two fp32 operations per lane in the same four cycles;
+        # the guide's 157.3 TFLOP/s = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz x 2 (FMA) x 2 (packed) is the packed
+        # figure, "2 cycles per instruction" is that figure read as plain fp32).  tools/micro_occ.hip measures it with
+        # the shader clock read beside the wall clock (profiles/r4/micro_occ.txt: 4.1-4.2 cycles at 2.2-2.4 GHz under
+        # an all-CU burn, v_fma_f32 and v_pk_fma_f32 alike: 5.8e11 wave-instructions/s, 148 TFLOP/s packed).
         issue, issue_stale = find_profile("issue", key, src) if not multi else (None, None)
         if issue:
-            peak_wi = 256 * 4 * 2.4e9 / 2.0
+            peak_wi = 256 * 4 * 2.4e9 / 4.0
             ach_wi = issue["valu_wave_insts_per_frame"] / kernel_s
             roofline_valu = {
                 "bound": "valu_issue",
@@ -646,10 +649,14 @@ def main():
                 "peak": peak_wi / 1e9,
                 "unit": "G wave-instructions/s",
                 "frac": ach_wi / peak_wi,
+                "peak_note": "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction on a 16-lane SIMD "
+                             "(measured: tools/micro_occ.hip -> profiles/r4/micro_occ.txt, shader clock and wall clock "
+                             "read together; packed fp32 costs the same slot); the guide's fp32 vector peak / 128 flops "
+                             "would be 1228.8, which is the PACKED rate (two operations per lane and slot)",
                 # what the chip sustains on independent v_fma_f32 chains with every CU busy
-                # (tools/micro_occ.hip, MI355X: 4.9e11/s at two waves per SIMD, 5.76e11 at eight)
-                "peak_measured": 576.0,
-                "frac_of_measured": ach_wi / 5.76e11,
+                # (tools/micro_occ.hip, MI355X: 4.4e11/s at two waves per SIMD, 5.8e11 at eight)
+                "peak_measured": 582.0,
+                "frac_of_measured": ach_wi / 5.82e11,
                 "valu_wave_insts_per_frame": issue["valu_wave_insts_per_frame"],
                 "valu_lane_utilisation": issue.get("valu_lane_utilisation"),
                 "source": issue.get("file"),

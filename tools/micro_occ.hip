@@ -6,10 +6,10 @@
 // dependent chain (what a wave with no instruction-level parallelism sees):
 //   * wall time by HIP events -> wave-instructions per second for the whole chip;
 //   * inside the kernel, around the loop: s_memtime (the shader-clock counter, clock64()) and s_memrealtime (the
-//     constant 100 MHz counter, wall_clock64()) -> the shader clock the loop actually ran at, and the SIMD cycles
-//     one wave-instruction occupied = (wave's shader cycles) / (instructions it issued) / (waves sharing the SIMD).
-// bench.py's roofline_valu_issue.peak is taken from this output (profiles/r4/micro_occ.txt): 256 CUs x 4 SIMDs x
-// clock / cycles per instruction.
+//     constant 100 MHz counter, wall_clock64()) -> the shader clock the loop actually ran at; the SIMD cycles one
+//     wave-instruction occupies = 1024 SIMDs x that clock / the chip-wide rate.
+// bench.py's roofline_valu_issue.peak is taken from this output (profiles/r4/micro_occ.txt): a wave64 VALU
+// instruction -- plain or packed -- occupies a 16-lane SIMD for four cycles: 256 CUs x 4 SIMDs x 2.4 GHz / 4.
 // Build on the box: hipcc --offload-arch=gfx950 -O3 tools/micro_occ.hip -o /tmp/micro_occ
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -130,10 +130,14 @@ int main()
             const double insts = 256.0 * w * 4 * per_wave;                     // wave-instructions, whole chip
             const double rate = insts / (ms * 1e-3);
             const double clock_mhz = mhz[mhz.size() / 2];
-            const double simd_cycles = sh[sh.size() / 2] / per_wave / w;       // SIMD cycles per wave-instruction
+            // SIMD cycles one wave-instruction occupies, from the chip-wide rate and the clock the waves measured
+            // (the waves of a launch do not all run at once -- the dispatcher does not spread W blocks per CU
+            // evenly -- so a single wave's own cycle count divided by W would flatter the SIMD)
+            const double simd_cycles = 1024.0 * clock_mhz * 1e6 / rate;
             printf("%-36s %d wave(s)/SIMD: %7.3f ms  %.3e wave-instr/s  %6.2f TFLOP/s  shader clock %6.0f MHz  "
-                   "SIMD cycles per wave-instruction %.2f  (one wave sees %.2f)\n",
-                   kd.name, w, ms, rate, rate * 64.0 * kd.flops_per_lane / 1e12, clock_mhz, simd_cycles, simd_cycles * w);
+                   "SIMD cycles per wave-instruction %.2f  (a wave's own view: %.2f cycles between its instructions)\n",
+                   kd.name, w, ms, rate, rate * 64.0 * kd.flops_per_lane / 1e12, clock_mhz, simd_cycles,
+                   sh[sh.size() / 2] / per_wave);
         }
     return 0;
 }

@@ -271,6 +271,15 @@ class TileDriver:
         self._start_gather(b, n)
 
     # ---- the collective of a batch: dense, or uniform tiles as one pixel (sparse)
+    def _gpu_pack(self):
+        """True when the sparse message can be packed (and later read) by the library's kernels -- vrhip_pack_tiles /
+        vrhip_message_positions / vrhip_assemble_batch, the C++ host's TileGather uses the same -- instead of a dozen
+        torch ops per batch: a real renderer on a GPU."""
+        lib = getattr(self.vr, "lib", None)
+        return (lib is not None and self.render_tiles_fn is None and not os.environ.get("VRHIP_NO_FUSED_ASSEMBLY")
+                and getattr(self.device, "type", str(self.device)) == "cuda" and self.split.world <= 64
+                and self.split.cap <= 65536)
+
     def _start_gather(self, b, n):
         s = self.split
         if not self.sparse:
@@ -283,35 +292,67 @@ class TileDriver:
         self._issue_payloads()
         torch = self.torch
         S, P = n * s.cap, s.th * s.tw
+        counts = [torch.zeros(1, dtype=torch.int32, device=self.device) for _ in range(s.world)]
+        if self._gpu_pack():
+            # message = [spad slot numbers | S pixels | whole tiles], spad = S rounded up to 4: packed by three small
+            # kernels on the current stream into a buffer sized for the worst case; only its used prefix travels
+            import ctypes as C
+            Smax = self.batch * s.cap
+            if not hasattr(self, "_msg"):
+                full = (Smax + 3) // 4 * 4 + 4 * Smax + 4 * Smax * P
+                self._msg = [torch.empty(full, dtype=torch.float32, device=self.device) for _ in range(2)]
+                self._scratch = [torch.empty(Smax, dtype=torch.int32, device=self.device) for _ in range(2)]
+                self._count = [torch.zeros(1, dtype=torch.int32, device=self.device) for _ in range(2)]
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            rc = self.vr.lib.vrhip_pack_tiles(self.vr.handle, C.c_void_p(stream), C.c_void_p(self.local[b].data_ptr()), S, P,
+                                              C.c_void_p(self._scratch[b].data_ptr()), C.c_void_p(self._msg[b].data_ptr()),
+                                              C.c_void_p(self._count[b].data_ptr()))
+            if rc != 0:
+                raise RuntimeError("vrhip_pack_tiles failed (%d)" % rc)
+            cwork = self.dist.all_gather(counts, self._count[b], async_op=True)
+            self.pending.append({"b": b, "n": n, "work": None, "packed": True, "counts": counts, "cwork": cwork})
+            return
         x = self.local[b].view(self.batch * s.cap, P, 4)[:S]
         xi = x.view(torch.int32)
         whole = (xi != xi[:, :1, :]).view(S, -1).any(dim=1)          # not all pixels bit-identical
         uni = x[:, 0, :].contiguous()                                 # one pixel per slot
         count = whole.sum().to(torch.int32).view(1)
-        counts = [torch.zeros(1, dtype=torch.int32, device=self.device) for _ in range(s.world)]
         cwork = self.dist.all_gather(counts, count, async_op=True)
         self.pending.append({"b": b, "n": n, "work": None, "whole": whole, "uni": uni, "x": x,
                              "counts": counts, "cwork": cwork})
 
     def _issue_payloads(self):
-        """Sparse: start the payload gather of every batch that has none yet (host synchronisation on the
-        ranks' counts of those batches)."""
+        """Sparse: start the payload gather of every batch that has none yet (ONE host synchronisation per batch:
+        the ranks' counts)."""
         s, torch = self.split, self.torch
         for e in self.pending:
             if e["work"] is not None or "cwork" not in e:
                 continue
             e["cwork"].wait()
-            cs = [int(c.item()) for c in e["counts"]]                # (the synchronisation)
-            maxc = (max(1, max(cs)) + 3) // 4 * 4          # (a multiple of 4: the pixels behind it stay 16-byte aligned)
+            cs = [int(v) for v in torch.cat(e["counts"]).cpu().tolist()]     # (the synchronisation)
             S, P = e["n"] * s.cap, s.th * s.tw
-            slots = torch.nonzero(e["whole"]).view(-1).to(torch.int32)   # cs[rank] entries
-            msg = torch.zeros(maxc + 4 * S + maxc * P * 4, dtype=torch.float32, device=self.device)
-            k = cs[s.rank]
-            if k:
-                msg[:k].view(torch.int32).copy_(slots)
-                msg[maxc + 4 * S: maxc + 4 * S + k * P * 4].view(k, P, 4).copy_(e["x"].index_select(0, slots.to(torch.int64)))
-            msg[maxc: maxc + 4 * S].view(S, 4).copy_(e["uni"])
-            recv = ([torch.empty_like(msg) for _ in range(s.world)] if s.rank == 0 else None)
+            if e.get("packed"):
+                # the library's layout: the slot-number block is spad wide whatever the counts; all ranks send the
+                # same length (a gather wants equal sizes): the prefix that holds the largest count's tiles
+                maxc = (S + 3) // 4 * 4
+                length = maxc + 4 * S + 4 * max(cs) * P
+                msg = self._msg[e["b"]][:length]
+                recv = None
+                if s.rank == 0:
+                    if not hasattr(self, "_recv") or self._recv[0].shape[1] < self._msg[0].numel():
+                        self._recv = [torch.empty((s.world, self._msg[0].numel()), dtype=torch.float32, device=self.device)
+                                      for _ in range(2)]
+                    recv = [self._recv[e["b"]][r][:length] for r in range(s.world)]
+            else:
+                maxc = (max(1, max(cs)) + 3) // 4 * 4          # (a multiple of 4: the pixels behind it stay 16-byte aligned)
+                slots = torch.nonzero(e["whole"]).view(-1).to(torch.int32)   # cs[rank] entries
+                msg = torch.zeros(maxc + 4 * S + maxc * P * 4, dtype=torch.float32, device=self.device)
+                k = cs[s.rank]
+                if k:
+                    msg[:k].view(torch.int32).copy_(slots)
+                    msg[maxc + 4 * S: maxc + 4 * S + k * P * 4].view(k, P, 4).copy_(e["x"].index_select(0, slots.to(torch.int64)))
+                msg[maxc: maxc + 4 * S].view(S, 4).copy_(e["uni"])
+                recv = ([torch.empty_like(msg) for _ in range(s.world)] if s.rank == 0 else None)
             e["work"] = self.dist.gather(msg, recv, dst=0, async_op=True)
             e.update(cs=cs, maxc=maxc, recv=recv, msg=msg)
             for key in ("whole", "uni", "x", "counts", "cwork"):
@@ -335,12 +376,9 @@ class TileDriver:
             return False
         import ctypes as C
         n, S, maxc = e["n"], e["n"] * s.cap, e["maxc"]
-        pos = torch.full((s.world, S), -1, dtype=torch.int32, device=self.device)
-        for r in range(s.world):
-            k = e["cs"][r]
-            if k:
-                pos[r].index_copy_(0, e["recv"][r][:k].view(torch.int32).to(torch.int64),
-                                   torch.arange(k, dtype=torch.int32, device=self.device))
+        if not hasattr(self, "_pos") or self._pos.numel() < s.world * self.batch * s.cap:
+            self._pos = torch.empty(s.world * self.batch * s.cap, dtype=torch.int32, device=self.device)
+        pos = self._pos[: s.world * S]
         if not hasattr(self, "_rank_slot"):
             rs = np.zeros(s.n_tiles, dtype=np.uint32)
             for r in range(s.world):
@@ -348,12 +386,17 @@ class TileDriver:
                 rs[ids] = (np.uint32(r) << np.uint32(16)) | np.arange(len(ids), dtype=np.uint32)
             self._rank_slot = torch.as_tensor(rs.astype(np.int64), device=self.device).to(torch.int32)
         ptrs = (C.c_void_p * s.world)(*[m.data_ptr() for m in e["recv"]])
+        counts = (C.c_uint32 * s.world)(*e["cs"])
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        rc = lib.vrhip_assemble_batch(self.vr.handle, C.c_void_p(stream), ptrs, s.world, n, s.cap, maxc,
-                                      C.c_void_p(pos.data_ptr()), C.c_void_p(self._rank_slot.data_ptr()), s.W, s.H,
-                                      s.tw, s.th, C.c_void_p(frames.data_ptr()))
+        # pos[rank][row] from the slot lists at the head of the messages (one kernel), then the frames (one kernel)
+        rc = lib.vrhip_message_positions(self.vr.handle, C.c_void_p(stream), ptrs, counts, s.world, S,
+                                         C.c_void_p(pos.data_ptr()))
+        if rc == 0:
+            rc = lib.vrhip_assemble_batch(self.vr.handle, C.c_void_p(stream), ptrs, s.world, n, s.cap, maxc,
+                                          C.c_void_p(pos.data_ptr()), C.c_void_p(self._rank_slot.data_ptr()), s.W, s.H,
+                                          s.tw, s.th, C.c_void_p(frames.data_ptr()))
         if rc != 0:
-            raise RuntimeError("vrhip_assemble_batch failed (%d)" % rc)
+            raise RuntimeError("vrhip_message_positions / vrhip_assemble_batch failed (%d)" % rc)
         e["keep"] = (pos, ptrs)     # (alive until the kernel has run: the caller synchronises before reuse)
         self._last_assembled = e
         return True
