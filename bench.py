@@ -35,6 +35,7 @@ WORKLOADS = {
     "sphere2048": ("sphere", 2048, "UCHAR", 1, "default", True),
     "haze2048": ("sphere", 2048, "UCHAR", 1, "haze", True),     # dense regime: no ERT
     "shells1024u16": ("shells", 1024, "USHORT", 1, "default", True),
+    "shells1024": ("shells", 1024, "UCHAR", 1, "default", True),    # north_star's 1024^3 UCHAR grid
     "haze1024": ("sphere", 1024, "UCHAR", 1, "haze", True),     # mid-sized dense volumes
     "sphere512f": ("sphere", 512, "FLOAT", 1, "default", True),
     "sphere256": ("sphere", 256, "UCHAR", 1, "default", True),
@@ -81,8 +82,9 @@ def parse():
                          "fit ONE launch set (--steps <= --frames-per-launch)")
     ap.add_argument("--root-share", default="auto",
                     help="multi-GPU: the fraction of a peer's tiles rank 0 renders (it also assembles every frame); "
-                         "auto = (1 + a - N a) / (1 + a) with a = 0.055, the assembly's share of a whole frame's "
-                         "time measured on one MI355X (tools/assemble_time.py: 0.0108 of 0.194 ms at 1024^2)")
+                         "auto = 1 for a run of one batch, else (1 + a - N a) / (1 + a) with a = 0.03, the assembly's "
+                         "share of a whole frame's time measured on one MI355X (tools/assemble_time.py: 0.006 of 0.19 ms "
+                         "at 1024^2)")
     ap.add_argument("--dense-gather", action="store_true",
                     help="multi-GPU: gather every tile whole (default: tiles of one colour travel as one pixel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -300,12 +302,6 @@ def main():
     mt = frontend.Mt19937()
     seeds = [mt() for _ in range(args.warmup + args.steps)]
 
-    if args.root_share == "auto":
-        a_asm = 0.055
-        root_share = max(0.25, (1.0 + a_asm - world * a_asm) / (1.0 + a_asm)) if world > 1 else 1.0
-    else:
-        root_share = float(args.root_share)
-    split = vtiles.TileSplit(W, H, args.tile, args.tile, world, rank, root_share)
     frame = torch.empty((H, W, 4), dtype=torch.float32, device=dev) if rank == 0 else None
     # world > 1: `--frames-per-gather` independent frames share one collective (fewer, larger
     # gathers: the host-side cost of a collective is comparable to a rank's rendering time)
@@ -322,6 +318,19 @@ def main():
     if throughput and args.frames_in_flight <= 0 and args.steps <= fpl:
         fif = 1
     fpg = max(1, min(fpg_want, args.steps, 256 * fif))
+    # Rank 0 also assembles every batch (time it does not render in): when batches FOLLOW one another -- the assembly of
+    # batch k shares rank 0's GPU with its rendering of batch k + 1 -- it takes a smaller share of the tiles, (1 + a -
+    # N a) / (1 + a) of a peer's with a = the assembly's share of a whole frame's time (0.006 of 0.19 ms at 1024^2 since
+    # round 4: tools/assemble_time.py).  A run of ONE batch (the round driver's --steps 20) has nothing for the
+    # assembly to overlap: every rank renders, then the gather, then the assembly -- an equal share is the shortest.
+    if args.root_share == "auto":
+        a_asm = 0.03
+        one_batch = args.steps <= fpg
+        root_share = (max(0.25, (1.0 + a_asm - world * a_asm) / (1.0 + a_asm))
+                      if (world > 1 and throughput and not one_batch) else 1.0)
+    else:
+        root_share = float(args.root_share)
+    split = vtiles.TileSplit(W, H, args.tile, args.tile, world, rank, root_share)
     if args.round_budget <= 0:
         # One GPU: 48 rounds (rays stay in the leaner one-lane phase while other frames hide its latency).  A rank's
         # tile share of a short run cannot fill its GPU, and the set's time is the chain of its longest rays: fewer

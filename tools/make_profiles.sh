@@ -39,6 +39,7 @@ region pt1024f pt1024f --warmup 1 --steps 16
 region sphere256_plain_512 sphere256_plain --viewport 512 --warmup 4 --steps 64
 region sphere256 sphere256 --warmup 4 --steps 64
 region shells1024u16 shells1024u16 --warmup 4 --steps 64
+region shells1024 shells1024 --warmup 4 --steps 64
 fi
 b() {   # NAME ARGS...
   local name=$1; shift
@@ -53,6 +54,7 @@ b shells2048_single --frames-in-flight 1 --frames-per-launch 1 --steps 32 --warm
 b sphere256_plain_512 --workload sphere256_plain --viewport 512
 b sphere256 --workload sphere256
 b shells1024u16 --workload shells1024u16
+b shells1024 --workload shells1024
 b pt1024f_sphere_64spp --workload pt1024f_sphere --steps 64
 b pt1024f_64spp --workload pt1024f --steps 64
 b haze2048 --workload haze2048 --steps 64 --warmup 0
