@@ -168,7 +168,7 @@ def check_library_sources(lib):
     from volumerenderercl_amd import _srchash
     lib.vrhip_build_source_hash.restype = ctypes.c_char_p
     built, tree = lib.vrhip_build_source_hash().decode(), _srchash.source_hash()
-    if built.split("+")[0] != tree:
+    if built.split("+")[0] != tree and os.environ.get("VRHIP_BENCH_ALLOW_STALE") != "1":   # (A/B against an older build)
         raise SystemExit("bench.py: libvrhip.so was built from kernel sources %s, the tree holds %s -- rebuild "
                          "(python -c 'import __graft_entry__ as g; g.build()') before measuring" % (built, tree))
     _BUILT_HASH = built

@@ -637,18 +637,20 @@ VR_DEV uint32_t empty_mask(const CellView &cv, const V &vol, const RayCtx &c, fl
     const float du = (c.dir.x * c.stepSize) * (0.5f * su);
     const float dv = (c.dir.y * c.stepSize) * (0.5f * sv);
     const float ds = (c.dir.z * c.stepSize) * (0.5f * ss);
-    const int mx = cv.ecx - 1, my = cv.ecy - 1, mz = cv.ecz - 1;
+    const float mx = (float)(cv.ecx - 1), my = (float)(cv.ecy - 1), mz = (float)(cv.ecz - 1);
     uint32_t w[kLook], sh[kLook];
 #pragma unroll
     for (int k = 0; k < kLook; ++k) {
         const float fk = (float)k;
-        // Signed clamp (one v_med3_i32): real samples near tnear lie up to 2 |voxLen| BEFORE the entry
-        // face (t - offset, :733 / :791) and are fetched clamp-to-edge, i.e. they read column 0 -- on an
-        // anisotropic grid that is several cells below 0, and an unsigned clamp would send them to the
-        // far border's cell.
-        const uint32_t x = (uint32_t)iclamp((int)__builtin_fmaf(fk, du, u0), 0, mx);
-        const uint32_t y = (uint32_t)iclamp((int)__builtin_fmaf(fk, dv, v0), 0, my);
-        const uint32_t z = (uint32_t)iclamp((int)__builtin_fmaf(fk, ds, s0), 0, mz);
+        // Signed clamp: real samples near tnear lie up to 2 |voxLen| BEFORE the entry face (t - offset, :733 /
+        // :791) and are fetched clamp-to-edge, i.e. they read column 0 -- on an anisotropic grid that is several
+        // cells below 0, and an unsigned clamp would send them to the far border's cell.  The clamp is taken in
+        // the float domain, BEFORE the conversion (one v_med3_f32 instead of an integer max and min: the compiler
+        // cannot prove 0 <= mx for a v_med3_i32): trunc(clamp(v, 0, mx)) == clamp(trunc(v), 0, mx) for every
+        // finite v and integer mx >= 0 -- an index, not an fp32 result of the image.
+        const uint32_t x = (uint32_t)(int)__builtin_amdgcn_fmed3f(__builtin_fmaf(fk, du, u0), 0.f, mx);
+        const uint32_t y = (uint32_t)(int)__builtin_amdgcn_fmed3f(__builtin_fmaf(fk, dv, v0), 0.f, my);
+        const uint32_t z = (uint32_t)(int)__builtin_amdgcn_fmed3f(__builtin_fmaf(fk, ds, s0), 0.f, mz);
         const uint32_t idx = (z * (uint32_t)cv.ecy + y) * (uint32_t)cv.ecx + x;
         w[k] = cv.empty[idx >> 5];
         sh[k] = idx & 31u;
@@ -662,25 +664,50 @@ VR_DEV uint32_t empty_mask(const CellView &cv, const V &vol, const RayCtx &c, fl
 // Step over the leading empty samples of the run (the reference's own t sequence and loop
 // exits, :790 and :868-879; nothing else of the loop body has an effect for them).  Returns
 // true when all kLook1 samples were consumed and the run may continue.
+//
+// Branch-free (round 4): sample k of the run is stepped over when the samples before it were, its cell is empty
+// (k < n1, the number of leading ones of the mask) and the inner loop's condition and the check after the sample
+// let the ray go on -- t < t_exit (:790) and not t >= tfar (:868) -- i.e. t < lim = min(t_exit, tfar).  Once one of
+// the two fails it fails for every later k (t stays), so the run needs no flag: one integer and one float compare,
+// the add and a select per sample, where the nested ifs compiled to ~8 VALU and ~10 SALU instructions and a branch
+// each.  The sample at which the run stops is looked at once, afterwards: still in an empty cell and t < t_exit, so
+// t >= tfar -- the reference takes that sample (it composites nothing) and leaves the loop at :868.
+template <int kLook>
+VR_DEV uint32_t skip_empty_steps(uint32_t n1, const RayCtx &c, RayDyn &d, bool count, unsigned long long &c_taken)
+{
+    const float lim = vmin(d.t_exit, c.tfar);
+    float tk = d.t;
+    uint32_t n = 0;
+#pragma unroll
+    for (int k = 0; k < kLook; ++k) {
+        const bool adv = (uint32_t)k < n1 && tk < lim;
+        n += adv ? 1u : 0u;
+        tk = adv ? tk + c.stepSize : tk;
+    }
+    d.t = tk;
+    const bool far_hit = n < (uint32_t)kLook && n < n1 && tk < d.t_exit;   // (t >= tfar: the sample is taken, then :868)
+    if (count) c_taken += n + (far_hit ? 1u : 0u);
+#ifdef VR_RAYLEN
+    d.nsmp += n + (far_hit ? 1u : 0u);
+#endif
+    if (far_hit) d.state = S_DONE;
+    return n;
+}
+
+// number of leading ones among the low kLook bits of a mask
+template <int kLook>
+VR_DEV uint32_t leading_ones(uint32_t mask)
+{
+    if (kLook < 32) return (uint32_t)__builtin_ctz(~mask | (1u << (kLook & 31)));
+    return mask == 0xffffffffu ? 32u : (uint32_t)__builtin_ctz(~mask);
+}
+
 VR_DEV bool skip_empty_run(uint32_t mask, const RayCtx &c, RayDyn &d, bool count,
                            unsigned long long &c_taken)
 {
-    constexpr int kLook = kLook1;
-    bool run = d.state == S_SAMPLE;
-    float tk = d.t;
-#pragma unroll
-    for (int k = 0; k < kLook; ++k) {
-        if (run) {
-            if (!(tk < d.t_exit) || !((mask >> k) & 1u)) run = false;
-            else {
-                if (count) c_taken++;
-                VR_RAYLEN_INC(d);
-                if (tk >= c.tfar) { d.state = S_DONE; run = false; }
-                else { tk = tk + c.stepSize; d.t = tk; }
-            }
-        }
-    }
-    return run;
+    // leading samples in empty cells; a lane that is not sampling steps over nothing
+    const uint32_t n1 = d.state == S_SAMPLE ? leading_ones<kLook1>(mask) : 0u;
+    return skip_empty_steps<kLook1>(n1, c, d, count, c_taken) == (uint32_t)kLook1;
 }
 
 // Phase 2: the four lanes of a ray look at four consecutive windows of kLook2 samples; the run is
@@ -688,25 +715,12 @@ VR_DEV bool skip_empty_run(uint32_t mask, const RayCtx &c, RayDyn &d, bool count
 VR_DEV bool skip_empty_run_wide(const uint32_t (&masks)[4], const RayCtx &c, RayDyn &d, bool count,
                                 unsigned long long &c_taken)
 {
-    constexpr int kLook = kLook2;
     bool run = d.state == S_SAMPLE;
-    float tk = d.t;
 #pragma unroll
     for (int chunk = 0; chunk < 4; ++chunk) {
         if (!__ballot(run)) break;
-        const uint32_t m = masks[chunk];
-#pragma unroll
-        for (int k = 0; k < kLook; ++k) {
-            if (run) {
-                if (!(tk < d.t_exit) || !((m >> k) & 1u)) run = false;
-                else {
-                    if (count) c_taken++;
-                    VR_RAYLEN_INC(d);
-                    if (tk >= c.tfar) { d.state = S_DONE; run = false; }
-                    else { tk = tk + c.stepSize; d.t = tk; }
-                }
-            }
-        }
+        const uint32_t n1 = run ? leading_ones<kLook2>(masks[chunk]) : 0u;
+        run = skip_empty_steps<kLook2>(n1, c, d, count, c_taken) == (uint32_t)kLook2;
     }
     return run;
 }

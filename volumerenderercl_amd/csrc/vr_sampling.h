@@ -97,15 +97,20 @@ struct Vol {
     const FpEntry<VT> *fp;          // FP: footprint volume (VolView::fp)
     uint32_t fp_ystride, fp_zstride;   // entries per brick row / brick slice of it
 
-    // FP: the entry for low-corner texel (ix, iy, iz) -- any integers; what lies outside
-    // [-1, res - 1] reads the same (edge-clamped) voxels as the nearest entry inside
-    VR_DEV FpEntry<VT> entry(int ix, int iy, int iz) const
+    // FP: the entry at entry coordinates (ex, ey, ez) = low-corner texel + 1, already in [0, res]
+    VR_DEV FpEntry<VT> entry_at(uint32_t ex, uint32_t ey, uint32_t ez) const   // entry coordinates, already in range
     {
-        const uint32_t ex = (uint32_t)(iclamp(ix, -1, w1) + 1), ey = (uint32_t)(iclamp(iy, -1, h1) + 1);
-        const uint32_t ez = (uint32_t)(iclamp(iz, -1, d1) + 1);
         const uint32_t in = __umul24(ey >> 2, fp_ystride) + ((ex >> 2) << 6) + ((ez & 3u) << 4) +
                             ((ey & 3u) << 2) + (ex & 3u);
         return fp[(unsigned long long)(ez >> 2) * (unsigned long long)fp_zstride + (unsigned long long)in];
+    }
+    // The entry coordinate of low-corner texel fx + off (fx = floor(..), a whole number as a float; off a small whole
+    // number): clamp(ix + off, -1, res - 1) + 1 taken in the float domain -- one v_med3_f32 and the conversion instead
+    // of a conversion and an integer max, min and add (the compiler cannot prove -1 <= res - 1 for a v_med3_i32).
+    // Whole numbers far below 2^24: every step is exact, the index is the same.
+    VR_DEV uint32_t ecoord(float fx, float off1, float fres) const   // off1 = off + 1, fres = (float)res
+    {
+        return (uint32_t)(int)__builtin_amdgcn_fmed3f(fx + off1, 0.f, fres);
     }
 
     // this volume's channel ch >= 1 as a single-channel volume
@@ -153,9 +158,8 @@ struct Vol {
         float ub = u - 0.5f, vb = v - 0.5f, sb = s - 0.5f;
         float fx = floorf(ub), fy = floorf(vb), fz = floorf(sb);
         float a = ub - fx, b = vb - fy, c = sb - fz;
-        int ix = (int)fx, iy = (int)fy, iz = (int)fz;
         if (FP) {   // the same eight voxels and the same blend, from one load
-            const FpEntry<VT> e = entry(ix, iy, iz);
+            const FpEntry<VT> e = entry_at(ecoord(fx, 1.f, fw), ecoord(fy, 1.f, fh), ecoord(fz, 1.f, fd));
             float c00 = lerpf(e.template v<0>(), e.template v<1>(), a);
             float c10 = lerpf(e.template v<2>(), e.template v<3>(), a);
             float c01 = lerpf(e.template v<4>(), e.template v<5>(), a);
@@ -164,6 +168,7 @@ struct Vol {
             float c1 = lerpf(c01, c11, b);
             return lerpf(c0, c1, c) * inv_max;
         }
+        int ix = (int)fx, iy = (int)fy, iz = (int)fz;
         int x0 = iclamp(ix, 0, w1), x1 = iclamp(ix + 1, 0, w1);
         int y0 = iclamp(iy, 0, h1), y1 = iclamp(iy + 1, 0, h1);
         int z0 = iclamp(iz, 0, d1), z1 = iclamp(iz + 1, 0, d1);
@@ -224,8 +229,8 @@ struct Vol {
         float ub = px * fw - 0.5f, vb = py * fh - 0.5f, sb = pz * fd - 0.5f;
         float fx = floorf(ub), fy = floorf(vb), fz = floorf(sb);
         float a = ub - fx, b = vb - fy, c = sb - fz;
+        if (FP) return neg_gradient_fp(fx, fy, fz, a, b, c);
         int ix = (int)fx, iy = (int)fy, iz = (int)fz;
-        if (FP) return neg_gradient_fp(ix, iy, iz, a, b, c);
         int X[4], Y[4], Z[4];
         uint32_t xo[4], yo[4];
         unsigned long long zo[4];
@@ -273,12 +278,16 @@ struct Vol {
     // neg_gradient() on the footprint volume: the 4x4x4 neighbourhood is the eight entries at
     // (ix - 1 + 2i, iy - 1 + 2j, iz - 1 + 2k); texel (xi, yi, zi) of it is value
     // (xi & 1) + 2 (yi & 1) + 4 (zi & 1) of entry (xi >> 1, yi >> 1, zi >> 1).  Same taps, same blends.
-    VR_DEV f3 neg_gradient_fp(int ix, int iy, int iz, float a, float b, float c) const
+    VR_DEV f3 neg_gradient_fp(float fx, float fy, float fz, float a, float b, float c) const
     {
-        const FpEntry<VT> e000 = entry(ix - 1, iy - 1, iz - 1), e100 = entry(ix + 1, iy - 1, iz - 1);
-        const FpEntry<VT> e010 = entry(ix - 1, iy + 1, iz - 1), e110 = entry(ix + 1, iy + 1, iz - 1);
-        const FpEntry<VT> e001 = entry(ix - 1, iy - 1, iz + 1), e101 = entry(ix + 1, iy - 1, iz + 1);
-        const FpEntry<VT> e011 = entry(ix - 1, iy + 1, iz + 1), e111 = entry(ix + 1, iy + 1, iz + 1);
+        // (entry coordinates of the low-corner texels ix - 1 and ix + 1 per axis: ecoord)
+        const uint32_t xm = ecoord(fx, 0.f, fw), xp = ecoord(fx, 2.f, fw);
+        const uint32_t ym = ecoord(fy, 0.f, fh), yp = ecoord(fy, 2.f, fh);
+        const uint32_t zm = ecoord(fz, 0.f, fd), zp = ecoord(fz, 2.f, fd);
+        const FpEntry<VT> e000 = entry_at(xm, ym, zm), e100 = entry_at(xp, ym, zm);
+        const FpEntry<VT> e010 = entry_at(xm, yp, zm), e110 = entry_at(xp, yp, zm);
+        const FpEntry<VT> e001 = entry_at(xm, ym, zp), e101 = entry_at(xp, ym, zp);
+        const FpEntry<VT> e011 = entry_at(xm, yp, zp), e111 = entry_at(xp, yp, zp);
 #define VR_E(xi, yi, zi)                                                                             \
     (((zi) >> 1) == 0 ? (((yi) >> 1) == 0 ? (((xi) >> 1) == 0 ? e000 : e100)                        \
                                           : (((xi) >> 1) == 0 ? e010 : e110))                        \
