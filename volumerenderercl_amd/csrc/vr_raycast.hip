@@ -1185,9 +1185,13 @@ __global__ __launch_bounds__(kBlockDim) void vr_dda_prepass_kernel(
         // reached, so that phase 1 neither repeats the walk nor carries the patch's dead lanes
         if (m) {
             uint32_t base = 0;
+#ifdef VR_DIAG_NO_LIVE_ATOMIC   // diagnostic build (WRONG frames: the list is not compact and its count stays 0, so the
+            base = q * 64u;     // marching kernels leave at once): what does the pre-pass cost without its one shared counter?
+#else
             if (lane == (uint32_t)__builtin_ctzll(m))
                 base = atomicAdd(fr.live_count, (uint32_t)__builtin_popcountll(m));
             base = __shfl(base, __builtin_ctzll(m), 64);
+#endif
             if (live) {
                 ContRec r;
                 r.pix = gx | (gy << 16);
@@ -1262,7 +1266,7 @@ __global__ __launch_bounds__(WAVES * 64) void vr_raycast_rays_kernel(
     const uint32_t kRefillLanes = (fr.refill_min ? fr.refill_min : 16u) * 4u;   // idle lanes before a refill
 
     unsigned long long n0 = 0, n1 = 0;
-    bool have = false, drained = false;
+    bool have = false, drained = false, first_draw = true;
     uint32_t gx = 0, gy = 0, out_index = 0, my_rounds = 0, frame_idx = 0;
     bool guess_empty = true;
     uint32_t cool = 0;   // evaluation batches before the ray guesses "empty" again (see the lookahead below)
@@ -1291,9 +1295,17 @@ __global__ __launch_bounds__(WAVES * 64) void vr_raycast_rays_kernel(
                     have = false;
                 }
                 if (!drained) {
+                    // a wave's FIRST 64 rays are its own by position -- no ticket: 2 048 - 3 072 waves drawing from one
+                    // counter at the same instant is a queue at one L2 address before anything marches --, the
+                    // later ones are drawn behind those
                     uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(fr.queue_head, n_idle);
-                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (first_draw) {
+                        base = (blockIdx.x * (uint32_t)WAVES + (threadIdx.x >> 6)) * 64u;
+                    } else {
+                        if (lane == 0) base = atomicAdd(fr.queue_head, n_idle);
+                        base = __builtin_amdgcn_readfirstlane(base) + gridDim.x * (uint32_t)WAVES * 64u;
+                    }
+                    first_draw = false;
                     if (base + n_idle >= n_rays) drained = true;
                     if (idle) {
                         const uint32_t ri = base + (uint32_t)__builtin_popcountll(idle_m & ((1ull << lane) - 1ull));
@@ -1702,7 +1714,7 @@ __global__ __launch_bounds__(WAVES * 64) void vr_raycast_split_kernel(
     const uint32_t refill_min = fr.refill_min ? fr.refill_min : kRaysPerWave;
     unsigned long long dummy0 = 0, dummy1 = 0;
     const bool count = INSTR && slot == 0;
-    bool have = false, drained = false;
+    bool have = false, drained = false, first_draw = true;
     uint32_t gx = 0, gy = 0, out_index = 0, my_rounds = 0;
     bool guess_empty = true;   // identical in the four lanes of a ray, like all of its state
     uint32_t cool = 0;         // evaluation batches before the ray guesses "empty" again
@@ -1730,9 +1742,16 @@ __global__ __launch_bounds__(WAVES * 64) void vr_raycast_split_kernel(
                     have = false;
                 }
                 if (!drained) {
+                    // (a wave's first 16 rays are its own by position, the later ones are drawn behind those: see
+                    // vr_raycast_rays_kernel)
                     uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(fr.cont_head, n_idle);
-                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (first_draw) {
+                        base = (blockIdx.x * (uint32_t)WAVES + (threadIdx.x >> 6)) * kRaysPerWave;
+                    } else {
+                        if (lane == 0) base = atomicAdd(fr.cont_head, n_idle);
+                        base = __builtin_amdgcn_readfirstlane(base) + gridDim.x * (uint32_t)WAVES * kRaysPerWave;
+                    }
+                    first_draw = false;
                     if (base + n_idle >= n_rays) drained = true;
                     if (idle) {
                         // my quad's rank among the idle quads (every lane of a quad is idle or none is)
