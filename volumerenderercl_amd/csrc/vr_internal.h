@@ -1,6 +1,7 @@
 // vr_internal.h -- descriptors shared by the kernels and the C-ABI implementation.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include <cstdio>
@@ -248,10 +249,31 @@ struct RaycastLaunch {
     DevStats *stats;
     uint32_t *touched;
     int num_cus;
-    hipEvent_t mid_event;  // optional: recorded between the phase-1 and phase-2 launches
+    hipEvent_t mid_event;  // optional: the end of phase 1
+    // optional: the end of the frame's last launch.  Both events are BOUND to a kernel's own completion signal
+    // (hipExtLaunchKernelGGL's stopEvent) rather than recorded behind it: a recorded event is a marker packet of its
+    // own between two launches (~6 us of GPU time each).  *stop_bound tells the caller that the launchers have done
+    // so (false: nothing was launched, or bind_events is off -- the caller records the event itself).
+    hipEvent_t stop_event;
+    bool *stop_bound;
+    // optional, likewise: the start of the frame's first launch (hipExtLaunchKernelGGL's startEvent)
+    hipEvent_t start_event;
+    bool *start_bound;
+    int bind_events;       // 0: record events behind the launches instead (VRHIP_EVENT_BIND=0, A/B)
     uint8_t *hit_out;      // imgEss: this frame's hit image (resolved after the march), or nullptr
     vrhip_launch_info *info;   // optional: the launchers record what they launched (vrhip_last_launch_info)
 };
+
+// hipLaunchKernelGGL, or -- with an event -- the launch whose completion the event is bound to
+template <typename F, typename... Args>
+inline void vr_launch_kernel(F k, dim3 grid, dim3 block, size_t lds, hipStream_t stream, hipEvent_t start,
+                             hipEvent_t stop, Args... args)
+{
+    if (start || stop)
+        hipExtLaunchKernelGGL(k, grid, block, (uint32_t)lds, stream, start, stop, 0u, args...);
+    else
+        hipLaunchKernelGGL(k, grid, block, lds, stream, args...);
+}
 
 hipError_t vr_launch_raycast(const RaycastLaunch &a, hipStream_t stream);
 // FrameView::patch_class for the n_patches patches of a set of set_frames frames (work item p * set_frames = patch

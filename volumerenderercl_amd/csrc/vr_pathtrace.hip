@@ -25,7 +25,7 @@
 namespace {
 
 #ifndef VR_PT_BATCH
-#define VR_PT_BATCH 4
+#define VR_PT_BATCH 6
 #endif
 constexpr int kPtBatch = VR_PT_BATCH;
 
@@ -126,13 +126,14 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
 
     // Exit condition reached by every wave: the queue head only grows, every walk ends after at
     // most 513 steps, and the refill / transition stages run unconditionally once no lane walks.
+    // The lanes by state, as wave masks kept across the rounds (a round in which nobody is handed a pixel or shaded --
+    // most rounds -- recomputes only the two that stage 2 changes): idle (P_FETCH), walking, walk ended (P_ENDED).
+    unsigned long long idle_m = ~0ull, walk_m = 0ull;
     for (;;) {
-        const unsigned long long walk_m = __ballot(state >= P_PRIMARY && state <= P_SHADOW);
-
         // ---- stage 1: hand out pixels to idle lanes -- when enough lanes are idle to pay for the
         //      ray set-up code, or when nothing else is left to do
-        unsigned long long idle = __ballot(state == P_FETCH);
-        if (!drained && idle && ((int)__builtin_popcountll(idle) >= kStageMin || !walk_m)) {
+        if (!drained && idle_m && ((int)__builtin_popcountll(idle_m) >= kStageMin || !walk_m)) {
+            unsigned long long idle = idle_m;
             while (idle && !drained) {
                 if (patch_taken >= 64) {
                     uint32_t q = 0;
@@ -181,11 +182,13 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
                 patch_taken += n_take;
                 idle = __ballot(state == P_FETCH);
             }
+            idle_m = idle;
+            walk_m = __ballot(state >= P_PRIMARY && state <= P_SHADOW);
         }
 
         // ---- stage 2: kPtBatch consecutive tracking steps of every walking lane (:419-431)
         const bool walking = state >= P_PRIMARY && state <= P_SHADOW;
-        if (__ballot(walking)) {
+        if (walk_m) {
             float tk[B], dens[B], al[B];
             f3 pk[B];
             bool ink[B], need[B];
@@ -212,47 +215,63 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
                 const float ax = __builtin_fmaf(px.org.x, hx, hx), bx = px.wdir.x * hx;
                 const float ay = __builtin_fmaf(px.org.y, hy, hy), by = px.wdir.y * hy;
                 const float az = __builtin_fmaf(px.org.z, hz, hz), bz = px.wdir.z * hz;
-                const int mx = grid.cx - 1, my = grid.cy - 1, mz = grid.cz - 1;
+                // (the clamp in the float domain -- one v_med3_f32, where the integer clamp is a max and a min; the
+                // conversion truncates towards zero, so the cell is the same: a coordinate in (-1, 0) becomes 0 either way)
+                const float mx = (float)(grid.cx - 1), my = (float)(grid.cy - 1), mz = (float)(grid.cz - 1);
                 float bnd[B];
 #pragma unroll
                 for (int k = 0; k < B; ++k) {
-                    const uint32_t x = (uint32_t)iclamp((int)__builtin_fmaf(bx, tk[k], ax), 0, mx);
-                    const uint32_t y = (uint32_t)iclamp((int)__builtin_fmaf(by, tk[k], ay), 0, my);
-                    const uint32_t z = (uint32_t)iclamp((int)__builtin_fmaf(bz, tk[k], az), 0, mz);
+                    const uint32_t x = (uint32_t)(int)__builtin_amdgcn_fmed3f(__builtin_fmaf(bx, tk[k], ax), 0.f, mx);
+                    const uint32_t y = (uint32_t)(int)__builtin_amdgcn_fmed3f(__builtin_fmaf(by, tk[k], ay), 0.f, my);
+                    const uint32_t z = (uint32_t)(int)__builtin_amdgcn_fmed3f(__builtin_fmaf(bz, tk[k], az), 0.f, mz);
                     bnd[k] = grid.bound[(z * (uint32_t)grid.cy + y) * (uint32_t)grid.cx + x];
                 }
 #pragma unroll
                 for (int k = 0; k < B; ++k) need[k] = need[k] && !(bnd[k] < px.thr);
             }
+            // fetch and transfer function -- behind ONE wave-uniform test: with the cull, seven rounds in eight need
+            // neither for any lane, and a guard per step is a handful of scalar instructions each
+            bool any_need = !cull;
 #pragma unroll
             for (int k = 0; k < B; ++k) {
                 dens[k] = 0.f;
-                if (need[k] || (INSTR < 2 && !cull))
-                    dens[k] = vol.linear(pk[k].x * 0.5f + 0.5f, pk[k].y * 0.5f + 0.5f, pk[k].z * 0.5f + 0.5f);
+                al[k] = 0.f;
+                any_need = any_need || need[k];
             }
-            // (the opacity only matters where the step was fetched: :432 below tests `need` first)
+            if (__ballot(any_need)) {
 #pragma unroll
-            for (int k = 0; k < B; ++k) al[k] = (need[k] || !cull) ? tff_linear_alpha(s_tff, tffn, dens[k]) : 0.f;
-            // the walk's exit conditions, in step order
+                for (int k = 0; k < B; ++k)
+                    if (need[k] || (INSTR < 2 && !cull))
+                        dens[k] = vol.linear(pk[k].x * 0.5f + 0.5f, pk[k].y * 0.5f + 0.5f, pk[k].z * 0.5f + 0.5f);
+                // (the opacity only matters where the step was fetched: :432 below tests `need` first)
+#pragma unroll
+                for (int k = 0; k < B; ++k)
+                    if (need[k] || !cull) al[k] = tff_linear_alpha(s_tff, tffn, dens[k]);
+            }
+            // the walk's exit conditions, in step order -- as selects, not branches (the bodies are assignments; as
+            // nested ifs they were ~25 scalar mask instructions per step): step k happens while `run`; it leaves the
+            // volume (:426-427), exceeds the step limit (:430-431) or is accepted (:432), in that order
             bool run = walking;
 #pragma unroll
             for (int k = 0; k < B; ++k) {
-                if (run) {
-                    ++px.cnt;
-                    px.t = tk[k];
-                    if (!ink[k]) { run = false; px.accepted = false; }               // :426-427
-                    else {
-                        if (INSTR) c_taken++;
-                        if (INSTR && !need[k]) c_culled++;
-                        if (px.cnt > 512) { run = false; px.accepted = false; }      // :430-431
-                        else if (need[k] && !(al[k] < px.thr)) {                     // :432
-                            run = false;
-                            px.accepted = true;
-                            px.apos = pk[k];
-                            px.adens = dens[k];
-                        }
-                    }
+                const bool st = run;
+                px.cnt += st ? 1u : 0u;
+                px.t = st ? tk[k] : px.t;
+                const bool out = !ink[k];
+                const bool over = px.cnt > 512u;
+                const bool acc = need[k] && !(al[k] < px.thr);
+                const bool accept = st && !out && !over && acc;
+                const bool stop = st && (out || over || acc);
+                if (INSTR) {
+                    c_taken += (st && !out) ? 1u : 0u;
+                    c_culled += (st && !out && !need[k]) ? 1u : 0u;
                 }
+                px.accepted = stop ? accept : px.accepted;
+                px.apos.x = accept ? pk[k].x : px.apos.x;
+                px.apos.y = accept ? pk[k].y : px.apos.y;
+                px.apos.z = accept ? pk[k].z : px.apos.z;
+                px.adens = accept ? dens[k] : px.adens;
+                run = st && !stop;
             }
             if (walking && !run) state |= P_ENDED;
         }
@@ -260,8 +279,9 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
         // ---- stage 3: trace_volume's control flow (:463-503) for lanes whose walk ended -- again
         //      only when enough lanes wait, or no lane walks any more
         const unsigned long long pend = __ballot((state & P_ENDED) != 0);
-        const unsigned long long still = __ballot(state >= P_PRIMARY && state <= P_SHADOW);
-        if (pend && ((int)__builtin_popcountll(pend) >= kStageMin || !still) && (state & P_ENDED)) {
+        walk_m = __ballot(state >= P_PRIMARY && state <= P_SHADOW);
+        const bool shade = pend && ((int)__builtin_popcountll(pend) >= kStageMin || !walk_m);
+        if (shade && (state & P_ENDED)) {
             const int ended = state & ~P_ENDED;
             bool start_shadow = false;
             if (ended == P_PRIMARY) {
@@ -327,7 +347,11 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
                 state = P_FETCH;
             }
         }
-        if (drained && !__ballot(state != P_FETCH)) break;
+        if (shade) {
+            idle_m = __ballot(state == P_FETCH);
+            walk_m = __ballot(state >= P_PRIMARY && state <= P_SHADOW);
+        }
+        if (drained && idle_m == ~0ull) break;
     }
 
     if (INSTR) {
@@ -358,9 +382,13 @@ hipError_t launch_pt(const RaycastLaunch &a, hipStream_t stream)
     const uint32_t cap = cus * (uint32_t)nb;
     dim3 grid(want < cap ? want : cap), block(kBlockDim);
     if (grid.x == 0) return hipSuccess;
-    hipLaunchKernelGGL(k, grid, block, lds, stream, a.vol, a.tf, a.cells, a.frame, a.cam, a.render,
-                       a.pathtrace, a.stats, a.touched);
+    const bool bind_stop = a.bind_events && a.stop_event && a.stop_bound;   // (one launch: it carries the frame's end)
+    const bool bind_start = a.bind_events && a.start_event && a.start_bound;
+    vr_launch_kernel(k, grid, block, lds, stream, bind_start ? a.start_event : nullptr, bind_stop ? a.stop_event : nullptr, a.vol, a.tf, a.cells, a.frame, a.cam,
+                     a.render, a.pathtrace, a.stats, a.touched);
     hipError_t e = hipGetLastError();
+    if (e == hipSuccess && bind_stop) *a.stop_bound = true;
+    if (e == hipSuccess && bind_start) *a.start_bound = true;
     if (e == hipSuccess && a.mid_event) e = hipEventRecord(a.mid_event, stream);
     return e;
 }

@@ -2114,6 +2114,8 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
         li.empty_skip = (INSTR != 2 && a.cells.empty != nullptr && a.render.useLinear != 0 &&
                          !(XS && (a.render.illumType == 4 || a.render.showEss))) ? 1u : 0u;
     }
+    // the events of the frame's timing ride on the launches themselves (RaycastLaunch::stop_event, start_event)
+    hipEvent_t start_ev = (a.bind_events && a.start_bound) ? a.start_event : nullptr;
     if (ESS && INSTR == 0 && frame.live) {
         // what make_grid(bricks, rc, n_words, true) and 1 / resolution give on the device
         Grid hg;
@@ -2125,19 +2127,26 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
         hg.brickDia = sqrtf(((hg.bl0 * hg.bl0) + (hg.bl1 * hg.bl1)) + (hg.bl2 * hg.bl2)) * 2.f;
         f3 hv;
         hv.x = 1.f / a.vol.fw; hv.y = 1.f / a.vol.fh; hv.z = 1.f / a.vol.fd;
-        hipLaunchKernelGGL(vr_dda_prepass_kernel<VT>, dim3(want), block, 0, stream, a.vol, a.bricks,
-                           a.skip, frame, a.cam, a.render, a.raycast, hg, hv);
+        vr_launch_kernel(vr_dda_prepass_kernel<VT>, dim3(want), block, 0, stream, start_ev, nullptr, a.vol, a.bricks,
+                         a.skip, frame, a.cam, a.render, a.raycast, hg, hv);
         hipError_t pe = hipGetLastError();
         if (pe != hipSuccess) return pe;
+        if (start_ev) { *a.start_bound = true; start_ev = nullptr; }
         if (a.info) { a.info->prepass = 1; a.info->patch_classes = frame.patch_class ? 1u : 0u; }
     } else {
         frame.live = nullptr;
     }
     hipError_t e;
+    const bool resolve_follows = a.render.imgEss && a.hit_out && a.frame.n_wave_tiles;
+    const bool bind_stop = a.bind_events && a.stop_event && a.stop_bound && !resolve_follows;
+    const bool p1_last = a.frame.round_budget == 0;
+    const hipEvent_t p1_ev = !a.bind_events ? nullptr : (p1_last && bind_stop) ? a.stop_event : a.mid_event;
 #ifdef VR_EXPERIMENTS
     if (ESS && INSTR == 0 && !XS && frame.live && frame.live_rays && frame.march && !a.raycast.contours &&
-        !a.raycast.aerial)
+        !a.raycast.aerial) {
+        if (start_ev && hipEventRecord(start_ev, stream) == hipSuccess) *a.start_bound = true;
         return launch_march<VT, SKIP_LDS, FP>(a, frame, block, cus, stream);   // the whole frame in one launch
+    }
 #endif
     if (ESS && INSTR == 0 && !XS && frame.live && frame.live_rays) {   // phase 1 on the ray list
         // phase 1 picks its own schedule: two or three waves per SIMD (three: footprint volume only), the skip
@@ -2157,16 +2166,18 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
         int nbr = 0;
         e = prepare_variant(kr, lds_r, &nbr, "raycast phase 1 (ray list)", a.num_cus, waves_r * 64);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kr, dim3(cus * (uint32_t)nbr), dim3(waves_r * 64), lds_r, stream, a.vol, a.bricks, a.tf,
-                           a.skip, a.cells, frame, a.cam, a.render, a.raycast);
+        vr_launch_kernel(kr, dim3(cus * (uint32_t)nbr), dim3(waves_r * 64), lds_r, stream, start_ev, p1_ev, a.vol, a.bricks,
+                         a.tf, a.skip, a.cells, frame, a.cam, a.render, a.raycast);
         if (a.info) { a.info->ray_list = 1; a.info->phase1_waves = (uint32_t)waves_r; a.info->skip_in_lds = rlds ? 1u : 0u; }
     } else {
-        hipLaunchKernelGGL(k1, grid, block, lds, stream, a.vol, a.bricks, a.tf, a.skip, a.cells, frame, a.cam,
-                           a.render, a.raycast, a.stats, a.touched);
+        vr_launch_kernel(k1, grid, block, lds, stream, start_ev, p1_ev, a.vol, a.bricks, a.tf, a.skip, a.cells, frame, a.cam,
+                         a.render, a.raycast, a.stats, a.touched);
     }
     e = hipGetLastError();
-    if (e == hipSuccess && a.mid_event) e = hipEventRecord(a.mid_event, stream);
-    if (e != hipSuccess || a.frame.round_budget == 0) return e;
+    if (e == hipSuccess && start_ev) *a.start_bound = true;
+    if (e == hipSuccess && p1_ev && p1_ev == a.stop_event) *a.stop_bound = true;
+    if (e == hipSuccess && a.mid_event && p1_ev != a.mid_event) e = hipEventRecord(a.mid_event, stream);
+    if (e != hipSuccess || p1_last) return e;
     if (a.frame.order) {   // longest rays first (keys: last frame's phase-2 rounds per pixel)
         hipLaunchKernelGGL(vr_cont_hist_kernel, dim3(128), block, 0, stream, a.frame.cont,
                            a.frame.cont_count, a.frame.sort_ws);
@@ -2178,9 +2189,11 @@ hipError_t launch_variant(const RaycastLaunch &a, hipStream_t stream)
     }
     // phase 2: persistent grid; exits at once when nothing was suspended
     dim3 grid2(cus * (uint32_t)nb2);
-    hipLaunchKernelGGL(k2, grid2, dim3(waves2 * 64), lds2, stream, a.vol, a.bricks, a.tf, a.skip, a.cells, frame, a.cam,
-                       a.render, a.raycast, a.stats, a.touched);
-    return hipGetLastError();
+    vr_launch_kernel(k2, grid2, dim3(waves2 * 64), lds2, stream, nullptr, bind_stop ? a.stop_event : nullptr, a.vol, a.bricks,
+                     a.tf, a.skip, a.cells, frame, a.cam, a.render, a.raycast, a.stats, a.touched);
+    e = hipGetLastError();
+    if (e == hipSuccess && bind_stop) *a.stop_bound = true;
+    return e;
 }
 
 template <typename VT>
@@ -2195,8 +2208,10 @@ hipError_t launch_typed(const RaycastLaunch &a, hipStream_t stream)
                     a.raycast.aerial != 0 || a.render.useLinear == 0;
 #ifdef VR_EXPERIMENTS
     if (a.frame.lds_stage && !xs && a.instr == 0 && a.use_ess && sizeof(VT) == 1 && !a.raycast.contours &&
-        !a.raycast.aerial && a.frame.n_wave_tiles)
+        !a.raycast.aerial && a.frame.n_wave_tiles) {
+        if (a.bind_events && a.start_bound && hipEventRecord(a.start_event, stream) == hipSuccess) *a.start_bound = true;
         return launch_staged(a, stream);
+    }
 #endif
     // the default kernels read the footprint volume when the host has provided one for this frame
     if (!xs && a.instr == 0 && a.vol.fp) {
@@ -2273,9 +2288,11 @@ hipError_t vr_launch_raycast(const RaycastLaunch &a, hipStream_t stream)
     default: return hipErrorInvalidValue;
     }
     if (e == hipSuccess && a.render.imgEss && a.hit_out && a.frame.n_wave_tiles) {
-        hipLaunchKernelGGL(vr_hit_resolve_kernel, dim3((a.frame.n_wave_tiles + kBlockDim - 1) / kBlockDim),
-                           dim3(kBlockDim), 0, stream, a.frame, a.hit_out);
+        const bool bind_stop = a.bind_events && a.stop_event && a.stop_bound;
+        vr_launch_kernel(vr_hit_resolve_kernel, dim3((a.frame.n_wave_tiles + kBlockDim - 1) / kBlockDim),
+                         dim3(kBlockDim), 0, stream, nullptr, bind_stop ? a.stop_event : nullptr, a.frame, a.hit_out);
         e = hipGetLastError();
+        if (e == hipSuccess && bind_stop) *a.stop_bound = true;
     }
     return e;
 }

@@ -112,6 +112,7 @@ struct vrhip_renderer {
     uint32_t ctrl_sel = 0;            // the block the next set of launches uses
     bool ctrl_clean[2] = {false, false};   // that block is known to hold zeroes
     bool phase_timing = false;        // vrhip_set_phase_timing: an event between the phases of a frame
+    int event_bind = 2;               // VRHIP_EVENT_BIND (launch_timed)
     bool frame_timing = true;         // vrhip_set_frame_timing: events around a frame's launches (vrhip_last_kernel_seconds)
     uint16_t *cost = nullptr;         // per pixel: phase-2 rounds of the previous frame (sort key)
     uint32_t *order = nullptr;        // sorted permutation of the suspended rays
@@ -980,8 +981,24 @@ int launch_timed(vrhip_renderer *r, const RaycastLaunch &a)
         const int rc = ensure_patch_classes(r, &b);   // (before the frame's timing starts: once per camera)
         if (rc) return rc;
     }
-    if (r->frame_timing) VR_HIP(r, hipEventRecord(r->ev0, r->stream));
-    b.mid_event = r->phase_timing && r->frame_timing ? r->evm : nullptr;   // (an event between two launches costs ~6 us of GPU time)
+    // The frame's events are bound to its launches (hipExtLaunchKernelGGL: the first launch's start, phase 1's end, the
+    // last launch's end) -- a RECORDED event is a marker packet of its own between two launches, ~6 us of GPU time
+    // each; VRHIP_EVENT_BIND=0 records them (A/B), =1 binds the ends only.  What the launchers did not bind -- no
+    // launch at all, an experiment's launcher -- is recorded here.
+    bool start_bound = false, stop_bound = false;
+    b.bind_events = r->event_bind;
+    if (r->frame_timing) {
+        b.stop_event = r->ev1;
+        b.stop_bound = &stop_bound;
+        if (r->event_bind >= 2) {
+            b.start_event = r->ev0;
+            b.start_bound = &start_bound;
+        } else {
+            VR_HIP(r, hipEventRecord(r->ev0, r->stream));
+            start_bound = true;
+        }
+    }
+    b.mid_event = r->phase_timing && r->frame_timing ? r->evm : nullptr;
     r->phase_timed = r->phase_timing && r->frame_timing;
     if (b.frame.hit_in) {
         VR_HIP(r, hipMemsetAsync(r->hit_any, 0, (size_t)r->hit_w * r->hit_h, r->stream));
@@ -997,7 +1014,8 @@ int launch_timed(vrhip_renderer *r, const RaycastLaunch &a)
     // nothing ran: then the other block keeps whatever it held, and the next set clears it with a memset
     r->ctrl_sel ^= 1u;
     r->ctrl_clean[r->ctrl_sel] = b.frame.n_wave_tiles != 0;
-    if (r->frame_timing) VR_HIP(r, hipEventRecord(r->ev1, r->stream));
+    if (r->frame_timing && !start_bound) VR_HIP(r, hipEventRecord(r->ev0, r->stream));
+    if (r->frame_timing && !stop_bound) VR_HIP(r, hipEventRecord(r->ev1, r->stream));
     r->timed = r->frame_timing;
     if (b.frame.hit_in) std::swap(r->hit_in, r->hit_out);   // runRaycast, volumerendercl.cpp:524-530
     return VRHIP_OK;
@@ -1295,11 +1313,16 @@ int vrhip_create(int device_id, vrhip_renderer **out)
     vrhip_renderer *r = new vrhip_renderer();
     r->device = device_id;
     hipDeviceProp_t prop;
+    // the frame's timing events order nothing for the host (results leave by stream-ordered copies that fence for
+    // themselves): no system-scope fence -- a write-back of the L2 -- when one of them completes.  VRHIP_EVENT_FENCE=1: A/B
+    const unsigned ev_flags = getenv("VRHIP_EVENT_FENCE") && atoi(getenv("VRHIP_EVENT_FENCE")) ? hipEventDefault
+                                                                                                 : hipEventDisableSystemFence;
     if ((e = hipSetDevice(device_id)) != hipSuccess ||
         (e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&r->own_stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipEventCreate(&r->ev0)) != hipSuccess || (e = hipEventCreate(&r->ev1)) != hipSuccess ||
-        (e = hipEventCreate(&r->evm)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&r->ev0, ev_flags)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&r->ev1, ev_flags)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&r->evm, ev_flags)) != hipSuccess ||
         (e = hipEventCreate(&r->evb0)) != hipSuccess ||
         (e = hipEventCreate(&r->evb1)) != hipSuccess ||
         (e = hipMalloc((void **)&r->stats_dev, sizeof(DevStats))) != hipSuccess ||
@@ -1335,6 +1358,7 @@ int vrhip_create(int device_id, vrhip_renderer **out)
         return e ? (atoi(e) == 3 ? 3 : atoi(e) == 2 ? 2 : 0) : dflt;
     };
     if (const char *e = getenv("VRHIP_FRAME_TIMING")) r->frame_timing = atoi(e) != 0;   // A/B (tools/ab_env.sh)
+    if (const char *e = getenv("VRHIP_EVENT_BIND")) r->event_bind = atoi(e);
     r->occ_force = r->occ_force_split = occ_env("VRHIP_OCC", 0);
     r->occ_force = occ_env("VRHIP_OCC_P1", r->occ_force);
     r->occ_force_split = occ_env("VRHIP_OCC_P2", r->occ_force_split);
