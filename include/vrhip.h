@@ -75,8 +75,9 @@ typedef struct vrhip_pathtrace_params {
  * technique 0: samples = executions of the inner loop body (volumeraycast.cl:790-880), bricks =
  * DDA steps / steps skipped by ESS.  technique 1: samples_taken = tracking steps inside the
  * volume (sample_interaction :419-431); the two brick counters are reused for the opacity-bound
- * culling: bricks_visited = steps whose bound was consulted, bricks_skipped = steps whose voxel
- * fetch was skipped; samples_nominal and samples_shaded stay 0. */
+ * culling: bricks_visited = steps whose bound was consulted (their cell's or, in a leap, their
+ * macro cell's), bricks_skipped = steps whose voxel fetch was skipped, samples_nominal = those of
+ * them that were taken in leaps over a macro cell; samples_shaded stays 0. */
 typedef struct vrhip_stats {
     uint64_t samples_taken;
     uint64_t samples_nominal;

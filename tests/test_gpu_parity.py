@@ -74,8 +74,9 @@ def _compare(vr, vol, fmt, tff, W, H, ess=True, pathtrace=False):
     if pathtrace:
         # technique 1 reuses the two brick counters for its majorant-grid culling (steps whose
         # bound was consulted / whose voxel fetch was skipped); the oracle has no such grid
-        assert gstats["bricks_skipped"] <= gstats["bricks_visited"] <= gstats["samples_taken"]
-        gstats = dict(gstats, bricks_visited=0, bricks_skipped=0)
+        # (and samples_nominal for the steps among them that were taken in leaps over a macro cell)
+        assert gstats["samples_nominal"] <= gstats["bricks_skipped"] <= gstats["bricks_visited"] <= gstats["samples_taken"]
+        gstats = dict(gstats, bricks_visited=0, bricks_skipped=0, samples_nominal=0)
     assert gstats == rstats
     # the production (uninstrumented) instantiation of the same frame
     vr.setStatsEnabled(False)
@@ -321,6 +322,48 @@ def test_pathtrace_culling_is_exact(vr, monkeypatch):
         r2.close()
     np.testing.assert_array_equal(got, plain)
     assert st2["samples_taken"] == st["samples_taken"] and st2["bricks_skipped"] == 0
+
+
+def test_pathtrace_leaps_are_exact(vr, monkeypatch):
+    """A walk takes all its steps inside a macro cell (4^3 cells of the bound grid) whose bound is below its threshold
+    at once (vr_pathtrace.hip): image, step count and culled steps are those of the kernel that takes them one by one
+    (VRHIP_PT_NO_LEAP), on a field with large empty regions and on noise, three accumulating iterations each -- and most
+    steps of the first are taken in leaps."""
+    table = common.tffs()["default"]
+    zz, yy, xx = np.meshgrid(np.linspace(-1, 1, 128), np.linspace(-1, 1, 144), np.linspace(-1, 1, 160), indexing="ij")
+    ball = np.clip(1.0 - np.sqrt(xx * xx + yy * yy + zz * zz) / 0.5, 0, 1).astype(np.float32)   # empty beyond r = 0.5
+    for name, vol in (("sphere", ball), ("noise", common.noise_volume((96, 80, 72), FLOAT, seed=21, smooth=True))):
+        W, H = 160, 120
+        out = {}
+        for leap in (True, False):
+            if leap:
+                monkeypatch.delenv("VRHIP_PT_NO_LEAP", raising=False)
+            else:
+                monkeypatch.setenv("VRHIP_PT_NO_LEAP", "1")
+            r2 = VolumeRenderCL()
+            r2.initialize()
+            try:
+                _setup(r2, vol, FLOAT, table, common.views()["rot30"], technique=1)
+                r2.setStatsEnabled(True)
+                frames, stats = [], []
+                for it in range(3):
+                    frames.append(r2.runRaycastNoGL(W, H).copy())
+                    stats.append(r2.getStats())
+                r2.setStatsEnabled(False)
+                r2.setIteration(0)
+                plain = r2.runRaycastNoGL(W, H).copy()       # the production kernel
+            finally:
+                r2.close()
+            out[leap] = (frames, stats, plain)
+        for a, b in zip(out[True][0], out[False][0]):
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(out[True][2], out[False][2])
+        np.testing.assert_array_equal(out[True][2], out[True][0][0])
+        for sa, sb in zip(out[True][1], out[False][1]):
+            assert sb["samples_nominal"] == 0
+            assert dict(sa, samples_nominal=0) == sb, name
+        if name == "sphere":
+            assert out[True][1][0]["samples_nominal"] > 0.5 * out[True][1][0]["samples_taken"], out[True][1][0]
 
 
 def test_pathtrace_tiles_equal_full_frame(vr):
@@ -1625,8 +1668,9 @@ def test_config5_size_pathtrace_matches_oracle():
                 assert np.abs(got.astype(np.float64) - ref).max() <= TOL, "stats=%s iteration %d" % (stats, it)
                 if stats:
                     g = r.getStats()
-                    assert g["bricks_skipped"] <= g["bricks_visited"] <= g["samples_taken"]
-                    assert dict(g, bricks_visited=0, bricks_skipped=0) == rstats
+                    assert g["samples_nominal"] <= g["bricks_skipped"] <= g["bricks_visited"] <= g["samples_taken"]
+                    assert dict(g, bricks_visited=0, bricks_skipped=0, samples_nominal=0) == rstats
+                    assert g["samples_nominal"] > 0.5 * g["samples_taken"]   # most steps are taken in leaps
                     assert g["bricks_skipped"] > 0.9 * g["samples_taken"]     # the sphere culls too
         r.setStatsEnabled(False)
         r.setSeed(SEED)

@@ -411,6 +411,34 @@ hipError_t vr_launch_cell_reduce(const float2 *fine, const CellView &grid, float
     return hipGetLastError();
 }
 
+namespace {
+// one thread per macro cell: the maximum of the bounds of its (up to) 4 x 4 x 4 cells
+__global__ __launch_bounds__(kThreads) void vr_cell_coarse_bounds_kernel(CellView g, float *cbound)
+{
+    const size_t n = (size_t)g.ccx * g.ccy * g.ccz;
+    const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const int X = (int)(i % (size_t)g.ccx), Y = (int)((i / (size_t)g.ccx) % (size_t)g.ccy), Z = (int)(i / ((size_t)g.ccx * g.ccy));
+    constexpr int E = 1 << kLeapShift;
+    float m = 0.f;   // (bounds are opacities: >= 0)
+    for (int z = Z * E; z < (Z + 1) * E && z < g.cz; ++z)
+        for (int y = Y * E; y < (Y + 1) * E && y < g.cy; ++y)
+            for (int x = X * E; x < (X + 1) * E && x < g.cx; ++x) {
+                const float b = g.bound[((size_t)z * g.cy + y) * g.cx + x];
+                m = (b > m || b != b) ? b : m;   // (a NaN bound rules nothing out: it must survive the maximum)
+            }
+    cbound[i] = m;
+}
+} // namespace
+
+hipError_t vr_launch_cell_coarse_bounds(const CellView &grid, float *cbound, hipStream_t stream)
+{
+    const size_t n = (size_t)grid.ccx * grid.ccy * grid.ccz;
+    hipLaunchKernelGGL(vr_cell_coarse_bounds_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                       stream, grid, cbound);
+    return hipGetLastError();
+}
+
 hipError_t vr_launch_cell_bmask(const VolView &vol, const CellView &grid, int bw, int bh, int bd,
                                 unsigned long long *bmask, hipStream_t stream)
 {

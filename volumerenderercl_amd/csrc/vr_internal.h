@@ -224,6 +224,11 @@ struct CellView {
     // cell that overlaps sub-block (i, j, k) is empty.  nullptr: not available (brick edge < 4).
     const unsigned long long *bmask;
     int bex, bey, bez;      // log2 of the brick edge per axis (>= 2)
+    // The bounds once more, per macro cell of 4 x 4 x 4 cells (kLeapShift): the maximum of its cells' bounds -- what
+    // lets a tracking walk leap over all its steps inside a macro cell at once (vr_pathtrace.hip).  ccx * ccy * ccz
+    // floats, x fastest; nullptr = no leaps.
+    const float *cbound;
+    int ccx, ccy, ccz;
 };
 
 struct DevStats {
@@ -302,6 +307,9 @@ hipError_t vr_launch_cell_bounds(const float2 *minmax, const CellView &grid, flo
                                  uint32_t *empty_bits, hipStream_t stream);
 // (min, max) of the coarse grid `grid` (cx.., shift) from those of the fine one (ecx.., eshift < shift)
 hipError_t vr_launch_cell_reduce(const float2 *fine, const CellView &grid, float2 *coarse, hipStream_t stream);
+// CellView::cbound from CellView::bound (grid.cx/cy/cz, grid.ccx/ccy/ccz set)
+constexpr int kLeapShift = 2;
+hipError_t vr_launch_cell_coarse_bounds(const CellView &grid, float *cbound, hipStream_t stream);
 // CellView::bmask from CellView::empty for the bw x bh x bd brick grid (grid.bex.. set)
 hipError_t vr_launch_cell_bmask(const VolView &vol, const CellView &grid, int bw, int bh, int bd,
                                 unsigned long long *bmask, hipStream_t stream);

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
 
     const uint32_t lane = threadIdx.x & 63u;
     const int tffn = (int)tf.tff_n;
-    unsigned long long c_taken = 0, c_hit = 0, c_culled = 0;
+    unsigned long long c_taken = 0, c_hit = 0, c_culled = 0, c_leaped = 0;
     // The instrumented traffic variant (INSTR 2) reproduces the reference's fetch set: no culling.
     // INSTR 3 records the micro-bricks of the fetches the culling lets through -- what the production
     // kernel needs from the volume (vrhip_count_fetched).
@@ -117,6 +117,7 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
     vol.touched = touched;
     // the traffic-instrumented variant must not touch speculative voxels: one step per round
     constexpr int B = INSTR >= 2 ? 1 : kPtBatch;
+    const bool leap = cull && grid.cbound != nullptr;   // leaps over macro cells (stage 2)
 
     PtPixel px = {};
     int state = P_FETCH;
@@ -203,6 +204,8 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
             }
             // majorant cull: no value a fetch in this cell can return maps to an opacity that
             // reaches the walk's threshold -> the step is a rejection whatever the voxels hold
+            float lax = 0.f, lbx = 0.f, lay = 0.f, lby = 0.f, laz = 0.f, lbz = 0.f, lcb = 0.f;   // (for the leap below)
+            uint32_t lcx = 0, lcy = 0, lcz = 0;
             if (cull) {
                 // cell of step k from the walk's voxel-space line u'(t) = a + b * t, in cells (one fma,
                 // one conversion and one clamp per axis).  u' = p * res: the fetch's low-corner texel is
@@ -225,7 +228,12 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
                     const uint32_t y = (uint32_t)(int)__builtin_amdgcn_fmed3f(__builtin_fmaf(by, tk[k], ay), 0.f, my);
                     const uint32_t z = (uint32_t)(int)__builtin_amdgcn_fmed3f(__builtin_fmaf(bz, tk[k], az), 0.f, mz);
                     bnd[k] = grid.bound[(z * (uint32_t)grid.cy + y) * (uint32_t)grid.cx + x];
+                    if (k == B - 1 && leap) {   // the macro cell of the batch's last step, and its bound
+                        lcx = x >> kLeapShift; lcy = y >> kLeapShift; lcz = z >> kLeapShift;
+                        lcb = grid.cbound[(lcz * (uint32_t)grid.ccy + lcy) * (uint32_t)grid.ccx + lcx];
+                    }
                 }
+                lax = ax; lbx = bx; lay = ay; lby = by; laz = az; lbz = bz;
 #pragma unroll
                 for (int k = 0; k < B; ++k) need[k] = need[k] && !(bnd[k] < px.thr);
             }
@@ -274,6 +282,65 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
                 run = st && !stop;
             }
             if (walking && !run) state |= P_ENDED;
+
+            // ---- the leap: a walk whose batch ended with a rejected step in a macro cell (4^3 cells) whose bound is
+            // below its threshold takes ALL its further steps inside that macro cell at once.  Exact, because
+            //  * every one of those steps is a rejection: its cell lies in the macro cell, so its bound is below the
+            //    threshold -- and it lies in the macro cell because the last step taken does, the landing step does
+            //    (checked below with the stepping code's own arithmetic) and a step's cell coordinate
+            //    trunc(med3(fma(b, t, a))) is monotone in t, as is its position org + wdir * t, axis by axis: what holds
+            //    at both ends of a stretch of the walk (the same macro cell, inside the volume) holds in between;
+            //  * t after n steps is known in closed form while it stays in its binade: t + s is rounded to a multiple of
+            //    ulp(t), s / ulp(t) = q + f with the same q and f at every step, so every step adds inc = q (f < 1/2) or
+            //    q + 1 (f > 1/2) ulps to the bit pattern of t (f = 1/2 -- a tie, resolved by the parity of the sum --
+            //    takes no leap); a leap never crosses the binade's top;
+            //  * the step counter stays within the limit of 512 (:430).
+            // The number of steps comes from the macro cell's exit along the walk's line in cell space and the room in
+            // the binade, both estimated (reciprocals) and then VERIFIED: landing cell, landing position, bit pattern.
+            if (leap) {
+                const float sst = -px.dt;
+                const uint32_t ti = __float_as_uint(px.t), si = __float_as_uint(sst);
+                const int et = (int)(ti >> 23), es = (int)(si >> 23);   // (a sign bit makes the exponent >= 256)
+                const int dsh = et - es;
+                bool can = run && lcb < px.thr && et > 0 && et < 255 && es > 0 && dsh >= 1 && dsh <= 24;
+                if (__ballot(can)) {
+                    const uint32_t sh = (uint32_t)dsh & 31u;
+                    const uint32_t ms = (si & 0x7fffffu) | 0x800000u;
+                    const uint32_t q = ms >> sh, rem = ms & ((1u << sh) - 1u), half = (1u << sh) >> 1;
+                    const uint32_t inc = q + (rem > half ? 1u : 0u);
+                    can = can && rem != half;
+                    const uint32_t room = (ti | 0x7fffffu) - ti;   // ulps to the top of the binade
+                    const float n_room = inc ? (float)room * __builtin_amdgcn_rcpf((float)inc) : 1024.f;
+                    // where the line leaves the macro cell [4 C, 4 C + 4) per axis, in cells
+                    const float ex = (float)((lcx + (lbx > 0.f ? 1u : 0u)) << kLeapShift);
+                    const float ey = (float)((lcy + (lby > 0.f ? 1u : 0u)) << kLeapShift);
+                    const float ez = (float)((lcz + (lbz > 0.f ? 1u : 0u)) << kLeapShift);
+                    const float tx = lbx != 0.f ? (ex - lax) * __builtin_amdgcn_rcpf(lbx) : 3.0e38f;
+                    const float ty = lby != 0.f ? (ey - lay) * __builtin_amdgcn_rcpf(lby) : 3.0e38f;
+                    const float tz = lbz != 0.f ? (ez - laz) * __builtin_amdgcn_rcpf(lbz) : 3.0e38f;
+                    const float t_out = vmin(tx, vmin(ty, tz));
+                    const float n_cell = (t_out - px.t) * __builtin_amdgcn_rcpf(sst);
+                    const float n_f = vmin(vmin(n_cell, n_room) - 2.f, (float)(512u - px.cnt));   // (cnt <= 512 while `run`)
+                    const uint32_t n = n_f >= 1.f ? (uint32_t)n_f : 0u;
+                    // verification
+                    const bool fits = __umulhi(n, inc) == 0u && n * inc <= room && px.cnt + n <= 512u;
+                    const float tn = __uint_as_float(ti + n * inc);
+                    const f3 pn = add3(px.org, scale3(px.wdir, tn));
+                    const float gmx = (float)(grid.cx - 1), gmy = (float)(grid.cy - 1), gmz = (float)(grid.cz - 1);
+                    const uint32_t xn = (uint32_t)(int)__builtin_amdgcn_fmed3f(__builtin_fmaf(lbx, tn, lax), 0.f, gmx);
+                    const uint32_t yn = (uint32_t)(int)__builtin_amdgcn_fmed3f(__builtin_fmaf(lby, tn, lay), 0.f, gmy);
+                    const uint32_t zn = (uint32_t)(int)__builtin_amdgcn_fmed3f(__builtin_fmaf(lbz, tn, laz), 0.f, gmz);
+                    const bool ok = can && n != 0u && fits && in_volume(pn) && (xn >> kLeapShift) == lcx &&
+                                    (yn >> kLeapShift) == lcy && (zn >> kLeapShift) == lcz;
+                    px.t = ok ? tn : px.t;
+                    px.cnt += ok ? n : 0u;
+                    if (INSTR) {
+                        c_taken += ok ? n : 0u;
+                        c_culled += ok ? n : 0u;
+                        c_leaped += ok ? n : 0u;
+                    }
+                }
+            }
         }
 
         // ---- stage 3: trace_volume's control flow (:463-503) for lanes whose walk ended -- again
@@ -362,6 +429,8 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
         // technique 1 reuses the two brick counters: steps whose bound was consulted / culled
         s = wave_sum(c_culled);
         if (lane == 0 && s) atomicAdd(&stats->v[4], s);
+        s = wave_sum(c_leaped);   // samples_nominal: the steps taken in leaps (among the culled ones)
+        if (lane == 0 && s) atomicAdd(&stats->v[1], s);
         s = wave_sum(cull ? c_taken : 0ull);
         if (lane == 0 && s) atomicAdd(&stats->v[3], s);
     }

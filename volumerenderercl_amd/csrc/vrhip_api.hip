@@ -80,6 +80,7 @@ struct vrhip_renderer {
     bool cells_have_bound = false, cells_have_empty = false;   // r->cells' tables match volume, time step and TF
     bool pt_dirty = true;          // cells out of date (volume, timestep or TF changed)
     bool pt_cull = true;           // VRHIP_PT_NO_CULL=1 disables the path tracer's culling
+    bool pt_leap = true;           // VRHIP_PT_NO_LEAP=1: no leaps over macro cells (A/B)
     bool skip_empty = true;        // VRHIP_NO_EMPTY_SKIP=1 disables the ray caster's empty runs
     bool skip_empty_force = false; // VRHIP_EMPTY_SKIP=1: also where it is not expected to pay (see ray_skip_empty)
 
@@ -681,20 +682,28 @@ int ensure_cells(vrhip_renderer *r, bool need_bound, bool need_empty)
     if (s.pt_minmax_valid) coarse_mm = s.pt_minmax;
 
     // ---- with the transfer function: bounds, empty bits
+    // (the macro cells' bounds -- CellView::cbound -- sit behind the cells' in the same allocation)
+    g.ccx = (g.cx + (1 << kLeapShift) - 1) >> kLeapShift;
+    g.ccy = (g.cy + (1 << kLeapShift) - 1) >> kLeapShift;
+    g.ccz = (g.cz + (1 << kLeapShift) - 1) >> kLeapShift;
+    const size_t n_macro = (size_t)g.ccx * g.ccy * g.ccz;
     if (need_bound && !r->cells_have_bound) {
-        if (n_cells > r->cell_cap) {
+        if (n_cells + n_macro > r->cell_cap) {
             VR_HIP(r, hipStreamSynchronize(r->stream));
             if (r->cell_bound) VR_HIP(r, hipFree(r->cell_bound));
             r->cell_bound = nullptr;
             r->cell_cap = 0;
-            VR_HIP(r, hipMalloc((void **)&r->cell_bound, n_cells * sizeof(float)));
-            r->cell_cap = n_cells;
+            VR_HIP(r, hipMalloc((void **)&r->cell_bound, (n_cells + n_macro) * sizeof(float)));
+            r->cell_cap = n_cells + n_macro;
         }
         VR_HIP(r, vr_launch_cell_bounds(coarse_mm, g, inv_max_of(r->format), make_tf_view(r),
                                         r->cell_sparse, r->cell_bound, nullptr, r->stream));
+        g.bound = r->cell_bound;
+        VR_HIP(r, vr_launch_cell_coarse_bounds(g, r->cell_bound + n_cells, r->stream));
         r->cells_have_bound = true;
     }
     g.bound = r->cells_have_bound ? r->cell_bound : nullptr;
+    g.cbound = (r->cells_have_bound && r->pt_leap) ? r->cell_bound + n_cells : nullptr;
     if (need_empty && !r->cells_have_empty) {
         if (n_fine > r->empty_cap) {
             VR_HIP(r, hipStreamSynchronize(r->stream));
@@ -898,7 +907,7 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
     a->raycast = r->raycast;
     a->pathtrace = r->pathtrace;
     a->cells = r->cells;
-    if (!r->pt_cull) a->cells.bound = nullptr;
+    if (!r->pt_cull) a->cells.bound = a->cells.cbound = nullptr;
     // the empty bits are those of TF(channel 0): not what a CL_RG / CL_RGBA sample's opacity is
     if (!ray_skip_empty(r)) { a->cells.empty = nullptr; a->cells.bmask = nullptr; }
     a->format = r->format;
@@ -1363,6 +1372,7 @@ int vrhip_create(int device_id, vrhip_renderer **out)
     r->occ_force = occ_env("VRHIP_OCC_P1", r->occ_force);
     r->occ_force_split = occ_env("VRHIP_OCC_P2", r->occ_force_split);
     if (getenv("VRHIP_PT_NO_CULL")) r->pt_cull = false;        // experiments: no opacity-bound culling
+    if (getenv("VRHIP_PT_NO_LEAP")) r->pt_leap = false;        // A/B: every tracking step on its own
     if (getenv("VRHIP_NO_EMPTY_SKIP")) r->skip_empty = false;  // experiments: no empty-run skipping
     if (getenv("VRHIP_EMPTY_SKIP")) r->skip_empty_force = true;   // ... or everywhere
     if (getenv("VRHIP_NO_FOOTPRINT")) r->use_fp = false;       // plain volume layout only
