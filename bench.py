@@ -716,7 +716,7 @@ def main():
             gpu_st = vr.getStats()
             vr.setStatsEnabled(False)
             if technique == 1:   # the path tracer's brick counters count its culling, not bricks
-                gpu_st = dict(gpu_st, bricks_visited=0, bricks_skipped=0)
+                gpu_st = dict(gpu_st, bricks_visited=0, bricks_skipped=0, samples_nominal=0)   # (and its leaps)
             single = float(max(np.abs(gpu_img.astype(np.float64) - ref_img).max(),
                                np.abs(gpu_img_i.astype(np.float64) - ref_img).max()))
             parity = {

@@ -308,7 +308,10 @@ hipError_t vr_launch_cell_bounds(const float2 *minmax, const CellView &grid, flo
 // (min, max) of the coarse grid `grid` (cx.., shift) from those of the fine one (ecx.., eshift < shift)
 hipError_t vr_launch_cell_reduce(const float2 *fine, const CellView &grid, float2 *coarse, hipStream_t stream);
 // CellView::cbound from CellView::bound (grid.cx/cy/cz, grid.ccx/ccy/ccz set)
-constexpr int kLeapShift = 2;
+#ifndef VR_LEAP_SHIFT
+#define VR_LEAP_SHIFT 2
+#endif
+constexpr int kLeapShift = VR_LEAP_SHIFT;
 hipError_t vr_launch_cell_coarse_bounds(const CellView &grid, float *cbound, hipStream_t stream);
 // CellView::bmask from CellView::empty for the bw x bh x bd brick grid (grid.bex.. set)
 hipError_t vr_launch_cell_bmask(const VolView &vol, const CellView &grid, int bw, int bh, int bd,

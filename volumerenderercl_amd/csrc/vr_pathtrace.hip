@@ -25,7 +25,7 @@
 namespace {
 
 #ifndef VR_PT_BATCH
-#define VR_PT_BATCH 6
+#define VR_PT_BATCH 4
 #endif
 constexpr int kPtBatch = VR_PT_BATCH;
 
@@ -35,6 +35,10 @@ enum : int { P_FETCH = 0, P_PRIMARY = 1, P_SCATTER = 2, P_SHADOW = 3, P_WRITE = 
 #endif
 // lanes that must wait for the (divergent) refill / shading code before it is worth running
 constexpr int kStageMin = VR_PT_STAGE_MIN;
+#ifndef VR_PT_SHADE_MIN
+#define VR_PT_SHADE_MIN VR_PT_STAGE_MIN
+#endif
+constexpr int kShadeMin = VR_PT_SHADE_MIN;   // the same for stage 3 (walk ends: shading, next walk, pixel write)
 
 VR_DEV bool in_volume(f3 p)   // volumeraycast.cl:93-96
 {
@@ -320,7 +324,10 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
                     const float tz = lbz != 0.f ? (ez - laz) * __builtin_amdgcn_rcpf(lbz) : 3.0e38f;
                     const float t_out = vmin(tx, vmin(ty, tz));
                     const float n_cell = (t_out - px.t) * __builtin_amdgcn_rcpf(sst);
-                    const float n_f = vmin(vmin(n_cell, n_room) - 2.f, (float)(512u - px.cnt));   // (cnt <= 512 while `run`)
+                    #ifndef VR_LEAP_MARGIN
+#define VR_LEAP_MARGIN 1.f
+#endif
+                    const float n_f = vmin(vmin(n_cell, n_room) - VR_LEAP_MARGIN, (float)(512u - px.cnt));   // (cnt <= 512 while `run`)
                     const uint32_t n = n_f >= 1.f ? (uint32_t)n_f : 0u;
                     // verification
                     const bool fits = __umulhi(n, inc) == 0u && n * inc <= room && px.cnt + n <= 512u;
@@ -347,7 +354,7 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
         //      only when enough lanes wait, or no lane walks any more
         const unsigned long long pend = __ballot((state & P_ENDED) != 0);
         walk_m = __ballot(state >= P_PRIMARY && state <= P_SHADOW);
-        const bool shade = pend && ((int)__builtin_popcountll(pend) >= kStageMin || !walk_m);
+        const bool shade = pend && ((int)__builtin_popcountll(pend) >= kShadeMin || !walk_m);
         if (shade && (state & P_ENDED)) {
             const int ended = state & ~P_ENDED;
             bool start_shadow = false;
