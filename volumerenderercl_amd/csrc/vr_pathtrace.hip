@@ -127,6 +127,7 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
     int state = P_FETCH;
     uint32_t patch_taken = 64;         // pixels of the current patch already handed out (wave-uniform)
     bool drained = false;              // queue exhausted (wave-uniform)
+    bool first_patch = true;
     WaveTile wt = {0, 0, 0};
 
     // Exit condition reached by every wave: the queue head only grows, every walk ends after at
@@ -141,9 +142,16 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
             unsigned long long idle = idle_m;
             while (idle && !drained) {
                 if (patch_taken >= 64) {
+                    // (a wave's first patch is its own by position, the later ones are drawn behind those: no queue
+                    // of 3 072 waves at one counter when the kernel starts -- see vr_raycast_rays_kernel)
                     uint32_t q = 0;
-                    if (lane == 0) q = atomicAdd(fr.queue_head, 1u);
-                    q = __builtin_amdgcn_readfirstlane(q);
+                    if (first_patch) {
+                        q = blockIdx.x * (kBlockDim / 64u) + (threadIdx.x >> 6);
+                    } else {
+                        if (lane == 0) q = atomicAdd(fr.queue_head, 1u);
+                        q = __builtin_amdgcn_readfirstlane(q) + gridDim.x * (kBlockDim / 64u);
+                    }
+                    first_patch = false;
                     if (q >= fr.n_wave_tiles) { drained = true; break; }
                     patch_taken = 0;
                     wt = fr.queue[q];
