@@ -326,20 +326,23 @@ def test_pathtrace_culling_is_exact(vr, monkeypatch):
 
 def test_pathtrace_leaps_are_exact(vr, monkeypatch):
     """A walk takes all its steps inside a macro cell (4^3 cells of the bound grid) whose bound is below its threshold
-    at once (vr_pathtrace.hip): image, step count and culled steps are those of the kernel that takes them one by one
-    (VRHIP_PT_NO_LEAP), on a field with large empty regions and on noise, three accumulating iterations each -- and most
-    steps of the first are taken in leaps."""
+    at once -- or inside the cube of macro cells around it that are free as well (vr_pathtrace.hip): image, step count and
+    culled steps are those of the kernel that takes every step on its own (VRHIP_PT_NO_LEAP) and of the one whose leaps
+    stay inside one macro cell (VRHIP_PT_NO_FAR_LEAP), on a field with large empty regions and on noise, three
+    accumulating iterations each -- and most steps of the first are taken in leaps."""
     table = common.tffs()["default"]
     zz, yy, xx = np.meshgrid(np.linspace(-1, 1, 128), np.linspace(-1, 1, 144), np.linspace(-1, 1, 160), indexing="ij")
     ball = np.clip(1.0 - np.sqrt(xx * xx + yy * yy + zz * zz) / 0.5, 0, 1).astype(np.float32)   # empty beyond r = 0.5
     for name, vol in (("sphere", ball), ("noise", common.noise_volume((96, 80, 72), FLOAT, seed=21, smooth=True))):
         W, H = 160, 120
         out = {}
-        for leap in (True, False):
-            if leap:
-                monkeypatch.delenv("VRHIP_PT_NO_LEAP", raising=False)
-            else:
+        for mode in ("far", "near", "none"):
+            monkeypatch.delenv("VRHIP_PT_NO_LEAP", raising=False)
+            monkeypatch.delenv("VRHIP_PT_NO_FAR_LEAP", raising=False)
+            if mode == "none":
                 monkeypatch.setenv("VRHIP_PT_NO_LEAP", "1")
+            elif mode == "near":
+                monkeypatch.setenv("VRHIP_PT_NO_FAR_LEAP", "1")
             r2 = VolumeRenderCL()
             r2.initialize()
             try:
@@ -354,16 +357,19 @@ def test_pathtrace_leaps_are_exact(vr, monkeypatch):
                 plain = r2.runRaycastNoGL(W, H).copy()       # the production kernel
             finally:
                 r2.close()
-            out[leap] = (frames, stats, plain)
-        for a, b in zip(out[True][0], out[False][0]):
-            np.testing.assert_array_equal(a, b)
-        np.testing.assert_array_equal(out[True][2], out[False][2])
-        np.testing.assert_array_equal(out[True][2], out[True][0][0])
-        for sa, sb in zip(out[True][1], out[False][1]):
-            assert sb["samples_nominal"] == 0
-            assert dict(sa, samples_nominal=0) == sb, name
+            out[mode] = (frames, stats, plain)
+        for mode in ("far", "near"):
+            for a, b in zip(out[mode][0], out["none"][0]):
+                np.testing.assert_array_equal(a, b)
+            np.testing.assert_array_equal(out[mode][2], out["none"][2])
+            np.testing.assert_array_equal(out[mode][2], out[mode][0][0])
+            for sa, sb in zip(out[mode][1], out["none"][1]):
+                assert sb["samples_nominal"] == 0
+                assert dict(sa, samples_nominal=0) == sb, (name, mode)
         if name == "sphere":
-            assert out[True][1][0]["samples_nominal"] > 0.5 * out[True][1][0]["samples_taken"], out[True][1][0]
+            far, near = out["far"][1][0], out["near"][1][0]
+            assert near["samples_nominal"] > 0.5 * near["samples_taken"], near
+            assert far["samples_nominal"] > near["samples_nominal"], (far, near)   # the cube reaches further
 
 
 def test_pathtrace_tiles_equal_full_frame(vr):

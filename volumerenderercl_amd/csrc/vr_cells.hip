@@ -431,6 +431,58 @@ __global__ __launch_bounds__(kThreads) void vr_cell_coarse_bounds_kernel(CellVie
 }
 } // namespace
 
+namespace {
+// CellView::cdist, pass 0: 1 = the macro cell is free at level j (bound < j / 8), 0 = it is not
+__global__ __launch_bounds__(kThreads) void vr_leap_radius_init_kernel(const float *cbound, size_t n, uint8_t *d)
+{
+    const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const float tau = (float)(blockIdx.y + 1u) * 0.125f;
+    d[(size_t)blockIdx.y * n + i] = cbound[i] < tau ? 1 : 0;   // (a NaN bound is not free)
+}
+// pass r >= 1: a macro cell whose cube of radius r - 1 is free (d == r) and whose 26 neighbours' cubes of radius
+// r - 1 are free as well (d >= r; neighbours outside the grid do not exist) has a free cube of radius r (d = r + 1)
+__global__ __launch_bounds__(kThreads) void vr_leap_radius_pass_kernel(const uint8_t *in, uint8_t *out, int cx, int cy, int cz,
+                                                                       int r)
+{
+    const size_t n = (size_t)cx * cy * cz;
+    const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *src = in + (size_t)blockIdx.y * n;
+    uint8_t v = src[i];
+    if (v == (uint8_t)r) {
+        const int X = (int)(i % (size_t)cx), Y = (int)((i / (size_t)cx) % (size_t)cy), Z = (int)(i / ((size_t)cx * cy));
+        bool all = true;
+        for (int dz = -1; dz <= 1; ++dz)
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int x = X + dx, y = Y + dy, z = Z + dz;
+                    if (x < 0 || y < 0 || z < 0 || x >= cx || y >= cy || z >= cz) continue;
+                    all = all && src[((size_t)z * cy + y) * cx + x] >= (uint8_t)r;
+                }
+        if (all) v = (uint8_t)(r + 1);
+    }
+    out[(size_t)blockIdx.y * n + i] = v;
+}
+} // namespace
+
+hipError_t vr_launch_cell_leap_radius(const CellView &grid, const float *cbound, uint8_t *dist, const uint8_t **result,
+                                      hipStream_t stream)
+{
+    const size_t n = (size_t)grid.ccx * grid.ccy * grid.ccz;
+    const dim3 g((unsigned)((n + kThreads - 1) / kThreads), kLeapLevels);
+    uint8_t *buf[2] = {dist, dist + (size_t)kLeapLevels * n};
+    hipLaunchKernelGGL(vr_leap_radius_init_kernel, g, dim3(kThreads), 0, stream, cbound, n, buf[0]);
+    int cur = 0;
+    for (int r = 1; r <= kLeapRadius; ++r) {
+        hipLaunchKernelGGL(vr_leap_radius_pass_kernel, g, dim3(kThreads), 0, stream, (const uint8_t *)buf[cur], buf[cur ^ 1],
+                           grid.ccx, grid.ccy, grid.ccz, r);
+        cur ^= 1;
+    }
+    *result = buf[cur];
+    return hipGetLastError();
+}
+
 hipError_t vr_launch_cell_coarse_bounds(const CellView &grid, float *cbound, hipStream_t stream)
 {
     const size_t n = (size_t)grid.ccx * grid.ccy * grid.ccz;

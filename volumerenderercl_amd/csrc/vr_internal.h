@@ -229,6 +229,12 @@ struct CellView {
     // floats, x fastest; nullptr = no leaps.
     const float *cbound;
     int ccx, ccy, ccz;
+    // ... and how far the macro cells around one are free as well, for kLeapLevels thresholds tau_j = j / 8, j = 1..7:
+    // cdist[(j - 1) * ccx * ccy * ccz + C] = 0 when macro cell C has a bound >= tau_j, else 1 + the largest R <= kLeapRadius
+    // such that every macro cell of the grid within Chebyshev distance R of C has a bound < tau_j.  A walk with
+    // threshold thr reads level j = floor(8 thr) (tau_j <= thr) and may leap through that whole cube.  nullptr: leaps
+    // stay inside one macro cell.
+    const uint8_t *cdist;
 };
 
 struct DevStats {
@@ -313,6 +319,11 @@ hipError_t vr_launch_cell_reduce(const float2 *fine, const CellView &grid, float
 #endif
 constexpr int kLeapShift = VR_LEAP_SHIFT;
 hipError_t vr_launch_cell_coarse_bounds(const CellView &grid, float *cbound, hipStream_t stream);
+constexpr int kLeapLevels = 7, kLeapRadius = 15;
+// CellView::cdist from `cbound`: `dist` holds 2 x kLeapLevels x ccx*ccy*ccz bytes (two buffers the erosion passes
+// alternate between); returns in *result the buffer that holds the table at the end
+hipError_t vr_launch_cell_leap_radius(const CellView &grid, const float *cbound, uint8_t *dist, const uint8_t **result,
+                                      hipStream_t stream);
 // CellView::bmask from CellView::empty for the bw x bh x bd brick grid (grid.bex.. set)
 hipError_t vr_launch_cell_bmask(const VolView &vol, const CellView &grid, int bw, int bh, int bd,
                                 unsigned long long *bmask, hipStream_t stream);

@@ -35,6 +35,13 @@ enum : int { P_FETCH = 0, P_PRIMARY = 1, P_SCATTER = 2, P_SHADOW = 3, P_WRITE = 
 #endif
 // lanes that must wait for the (divergent) refill / shading code before it is worth running
 constexpr int kStageMin = VR_PT_STAGE_MIN;
+#ifndef VR_LEAP_MARGIN
+#define VR_LEAP_MARGIN 1.f
+#endif
+#ifndef VR_LEAP_PIECES
+#define VR_LEAP_PIECES 1
+#endif
+constexpr int kLeapPieces = VR_LEAP_PIECES;   // closed-form stretches of a leap (one binade each)
 #ifndef VR_PT_SHADE_MIN
 #define VR_PT_SHADE_MIN VR_PT_STAGE_MIN
 #endif
@@ -92,8 +99,13 @@ struct PtPixel {   // the pixel a lane is working on
     float adens;
 };
 
+#ifdef VR_PT_WAVES_PER_EU   // A/B builds: more waves per SIMD at fewer registers
+#define VR_PT_OCC __attribute__((amdgpu_waves_per_eu(VR_PT_WAVES_PER_EU, VR_PT_WAVES_PER_EU)))
+#else
+#define VR_PT_OCC
+#endif
 template <typename VT, int INSTR>
-__global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
+__global__ __launch_bounds__(kBlockDim) VR_PT_OCC void vr_pathtrace_kernel(
     VolView vv, TfView tf, CellView grid, FrameView fr, vrhip_camera_params cam,
     vrhip_rendering_params rp, vrhip_pathtrace_params pt, DevStats *stats, uint32_t *touched)
 {
@@ -217,7 +229,7 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
             // majorant cull: no value a fetch in this cell can return maps to an opacity that
             // reaches the walk's threshold -> the step is a rejection whatever the voxels hold
             float lax = 0.f, lbx = 0.f, lay = 0.f, lby = 0.f, laz = 0.f, lbz = 0.f, lcb = 0.f;   // (for the leap below)
-            uint32_t lcx = 0, lcy = 0, lcz = 0;
+            uint32_t lcx = 0, lcy = 0, lcz = 0, lrad = 0;
             if (cull) {
                 // cell of step k from the walk's voxel-space line u'(t) = a + b * t, in cells (one fma,
                 // one conversion and one clamp per axis).  u' = p * res: the fetch's low-corner texel is
@@ -242,7 +254,13 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
                     bnd[k] = grid.bound[(z * (uint32_t)grid.cy + y) * (uint32_t)grid.cx + x];
                     if (k == B - 1 && leap) {   // the macro cell of the batch's last step, and its bound
                         lcx = x >> kLeapShift; lcy = y >> kLeapShift; lcz = z >> kLeapShift;
-                        lcb = grid.cbound[(lcz * (uint32_t)grid.ccy + lcy) * (uint32_t)grid.ccx + lcx];
+                        const uint32_t ci = (lcz * (uint32_t)grid.ccy + lcy) * (uint32_t)grid.ccx + lcx;
+                        lcb = grid.cbound[ci];
+                        if (grid.cdist) {   // how far the macro cells around are free at the level below the walk's threshold
+                            const uint32_t j = (uint32_t)(px.thr * 8.f);   // tau_j = j / 8 <= thr (exact: a power of two)
+                            const uint32_t jj = j < (uint32_t)kLeapLevels ? j : (uint32_t)kLeapLevels;
+                            if (jj) lrad = grid.cdist[(size_t)(jj - 1u) * ((size_t)grid.ccx * grid.ccy * grid.ccz) + ci];
+                        }
                     }
                 }
                 lax = ax; lbx = bx; lay = ay; lby = by; laz = az; lbz = bz;
@@ -296,16 +314,18 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
             if (walking && !run) state |= P_ENDED;
 
             // ---- the leap: a walk whose batch ended with a rejected step in a macro cell (4^3 cells) whose bound is
-            // below its threshold takes ALL its further steps inside that macro cell at once.  Exact, because
-            //  * every one of those steps is a rejection: its cell lies in the macro cell, so its bound is below the
-            //    threshold -- and it lies in the macro cell because the last step taken does, the landing step does
+            // below its threshold takes ALL its further steps inside that macro cell at once -- or inside the cube of
+            // macro cells around it that CellView::cdist says are free as well.  Exact, because
+            //  * every one of those steps is a rejection: its cell lies in the macro cell (the cube), so its bound is below
+            //    the threshold -- and it lies in there because the last step taken does, the landing step does
             //    (checked below with the stepping code's own arithmetic) and a step's cell coordinate
             //    trunc(med3(fma(b, t, a))) is monotone in t, as is its position org + wdir * t, axis by axis: what holds
             //    at both ends of a stretch of the walk (the same macro cell, inside the volume) holds in between;
             //  * t after n steps is known in closed form while it stays in its binade: t + s is rounded to a multiple of
             //    ulp(t), s / ulp(t) = q + f with the same q and f at every step, so every step adds inc = q (f < 1/2) or
             //    q + 1 (f > 1/2) ulps to the bit pattern of t (f = 1/2 -- a tie, resolved by the parity of the sum --
-            //    takes no leap); a leap never crosses the binade's top;
+            //    has no closed form and ends the stretch); at the binade's top one real step t + s crosses over, and the next
+            //    stretch has its own inc;
             //  * the step counter stays within the limit of 512 (:430).
             // The number of steps comes from the macro cell's exit along the walk's line in cell space and the room in
             // the binade, both estimated (reciprocals) and then VERIFIED: landing cell, landing position, bit pattern.
@@ -313,40 +333,71 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
                 const float sst = -px.dt;
                 const uint32_t ti = __float_as_uint(px.t), si = __float_as_uint(sst);
                 const int et = (int)(ti >> 23), es = (int)(si >> 23);   // (a sign bit makes the exponent >= 256)
-                const int dsh = et - es;
-                bool can = run && lcb < px.thr && et > 0 && et < 255 && es > 0 && dsh >= 1 && dsh <= 24;
+                // (lrad != 0: the macro cell and those within lrad - 1 around it have bounds < tau_j <= thr)
+                const bool can = run && (lrad != 0u || lcb < px.thr) && et > 0 && et < 255 && es > 0 && es < 255;
                 if (__ballot(can)) {
-                    const uint32_t sh = (uint32_t)dsh & 31u;
-                    const uint32_t ms = (si & 0x7fffffu) | 0x800000u;
-                    const uint32_t q = ms >> sh, rem = ms & ((1u << sh) - 1u), half = (1u << sh) >> 1;
-                    const uint32_t inc = q + (rem > half ? 1u : 0u);
-                    can = can && rem != half;
-                    const uint32_t room = (ti | 0x7fffffu) - ti;   // ulps to the top of the binade
-                    const float n_room = inc ? (float)room * __builtin_amdgcn_rcpf((float)inc) : 1024.f;
-                    // where the line leaves the macro cell [4 C, 4 C + 4) per axis, in cells
-                    const float ex = (float)((lcx + (lbx > 0.f ? 1u : 0u)) << kLeapShift);
-                    const float ey = (float)((lcy + (lby > 0.f ? 1u : 0u)) << kLeapShift);
-                    const float ez = (float)((lcz + (lbz > 0.f ? 1u : 0u)) << kLeapShift);
+                    // -- how many steps: to where the line leaves the cube of macro cells [C - R, C + R] per axis, in cells
+                    // (R = 0: the macro cell [4 C, 4 C + 4) itself), cut at the volume's own faces (cell coordinate 0 and
+                    // res / E: a walk that leaves the volume inside the cube lands just before it does, instead of failing
+                    // the check below and taking no leap at all) -- and within the step limit
+                    const int R = lrad ? (int)lrad - 1 : 0;
+                    const float inv_e = __uint_as_float((uint32_t)(127 - grid.shift) << 23);
+                    const float ux = vol.fw * inv_e, uy = vol.fh * inv_e, uz = vol.fd * inv_e;
+                    const float ex = __builtin_amdgcn_fmed3f((float)(((int)lcx + (lbx > 0.f ? R + 1 : -R)) * (1 << kLeapShift)), 0.f, ux);
+                    const float ey = __builtin_amdgcn_fmed3f((float)(((int)lcy + (lby > 0.f ? R + 1 : -R)) * (1 << kLeapShift)), 0.f, uy);
+                    const float ez = __builtin_amdgcn_fmed3f((float)(((int)lcz + (lbz > 0.f ? R + 1 : -R)) * (1 << kLeapShift)), 0.f, uz);
                     const float tx = lbx != 0.f ? (ex - lax) * __builtin_amdgcn_rcpf(lbx) : 3.0e38f;
                     const float ty = lby != 0.f ? (ey - lay) * __builtin_amdgcn_rcpf(lby) : 3.0e38f;
                     const float tz = lbz != 0.f ? (ez - laz) * __builtin_amdgcn_rcpf(lbz) : 3.0e38f;
                     const float t_out = vmin(tx, vmin(ty, tz));
                     const float n_cell = (t_out - px.t) * __builtin_amdgcn_rcpf(sst);
-                    #ifndef VR_LEAP_MARGIN
-#define VR_LEAP_MARGIN 1.f
-#endif
-                    const float n_f = vmin(vmin(n_cell, n_room) - VR_LEAP_MARGIN, (float)(512u - px.cnt));   // (cnt <= 512 while `run`)
-                    const uint32_t n = n_f >= 1.f ? (uint32_t)n_f : 0u;
-                    // verification
-                    const bool fits = __umulhi(n, inc) == 0u && n * inc <= room && px.cnt + n <= 512u;
-                    const float tn = __uint_as_float(ti + n * inc);
+                    const float n_f = vmin(n_cell - VR_LEAP_MARGIN, (float)(512u - px.cnt));   // (cnt <= 512 while `run`)
+                    uint32_t left = (can && n_f >= 1.f) ? (uint32_t)n_f : 0u;
+                    // -- the steps themselves, on the bit pattern of t: kLeapPieces stretches in closed form, each within the
+                    // binade t is in (inc ulps per step; none on a tie), with one real step t + s between two of them --
+                    // the step that crosses into the next binade when the stretch before it reached the top
+                    const uint32_t ms = (si & 0x7fffffu) | 0x800000u;
+                    uint32_t tb = ti, n = 0;
+#pragma unroll
+                    for (int piece = 0; piece < kLeapPieces; ++piece) {
+                        const int e_t = (int)(tb >> 23), dsh = e_t - es;
+                        const bool closed = dsh >= 1 && dsh <= 24 && e_t < 255;
+                        const uint32_t sh = (uint32_t)dsh & 31u;
+                        const uint32_t q = ms >> sh, rem = ms & ((1u << sh) - 1u), half = (1u << sh) >> 1;
+                        const uint32_t inc = q + (rem > half ? 1u : 0u);
+                        const uint32_t room = (tb | 0x7fffffu) - tb;   // ulps to the top of the binade
+                        // k = min(left, floor(room / inc)): the quotient from a reciprocal, exact after one correction
+                        // each way when it matters (quotients up to left + 4 <= 516; a larger estimate is >= left for sure)
+                        uint32_t k = (uint32_t)((float)room * __builtin_amdgcn_rcpf((float)(inc ? inc : 1u)));
+                        if (k > left + 4u) {
+                            k = left;
+                        } else {
+                            k -= (k * inc > room) ? 1u : 0u;
+                            k += ((k + 1u) * inc <= room) ? 1u : 0u;
+                            k = k < left ? k : left;
+                        }
+                        k = (closed && rem != half && __umulhi(k, inc) == 0u && k * inc <= room) ? k : 0u;
+                        tb += k * inc;
+                        left -= k;
+                        n += k;
+                        if (piece + 1 < kLeapPieces) {
+                            const bool one = left != 0u;
+                            tb = one ? __float_as_uint(__uint_as_float(tb) + sst) : tb;
+                            left -= one ? 1u : 0u;
+                            n += one ? 1u : 0u;
+                        }
+                    }
+                    // -- the landing, with the stepping code's own arithmetic
+                    const float tn = __uint_as_float(tb);
                     const f3 pn = add3(px.org, scale3(px.wdir, tn));
                     const float gmx = (float)(grid.cx - 1), gmy = (float)(grid.cy - 1), gmz = (float)(grid.cz - 1);
                     const uint32_t xn = (uint32_t)(int)__builtin_amdgcn_fmed3f(__builtin_fmaf(lbx, tn, lax), 0.f, gmx);
                     const uint32_t yn = (uint32_t)(int)__builtin_amdgcn_fmed3f(__builtin_fmaf(lby, tn, lay), 0.f, gmy);
                     const uint32_t zn = (uint32_t)(int)__builtin_amdgcn_fmed3f(__builtin_fmaf(lbz, tn, laz), 0.f, gmz);
-                    const bool ok = can && n != 0u && fits && in_volume(pn) && (xn >> kLeapShift) == lcx &&
-                                    (yn >> kLeapShift) == lcy && (zn >> kLeapShift) == lcz;
+                    const int ddx = (int)(xn >> kLeapShift) - (int)lcx, ddy = (int)(yn >> kLeapShift) - (int)lcy,
+                              ddz = (int)(zn >> kLeapShift) - (int)lcz;
+                    const bool ok = can && n != 0u && px.cnt + n <= 512u && in_volume(pn) && ddx >= -R && ddx <= R &&
+                                    ddy >= -R && ddy <= R && ddz >= -R && ddz <= R;
                     px.t = ok ? tn : px.t;
                     px.cnt += ok ? n : 0u;
                     if (INSTR) {
@@ -375,7 +426,11 @@ __global__ __launch_bounds__(kBlockDim) void vr_pathtrace_kernel(
                     px.hit_pos = px.apos;
                     const f3 sp = mk3(px.apos.x * 0.5f + 0.5f, px.apos.y * 0.5f + 0.5f,
                                       px.apos.z * 0.5f + 0.5f);
+#ifdef VR_DIAG_NO_GRAD   // diagnostic build (wrong image): what do the gradient neighbourhoods of the interactions cost?
+                    const float4 gq = make_float4(sp.x, sp.y, sp.z, 0.f);
+#else
                     const float4 gq = gradient_tff<VT, VI>(vol, s_tff, tffn, sp);
+#endif
                     const float g0 = -gq.x, g1 = -gq.y, g2 = -gq.z, g3 = -gq.w;
                     const float glen = sqrtf((((g0 * g0) + (g1 * g1)) + (g2 * g2)) + (g3 * g3));
                     if (glen > 0.5f) {   // :483-486 high gradient: Phong

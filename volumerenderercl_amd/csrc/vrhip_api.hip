@@ -81,6 +81,10 @@ struct vrhip_renderer {
     bool pt_dirty = true;          // cells out of date (volume, timestep or TF changed)
     bool pt_cull = true;           // VRHIP_PT_NO_CULL=1 disables the path tracer's culling
     bool pt_leap = true;           // VRHIP_PT_NO_LEAP=1: no leaps over macro cells (A/B)
+    bool pt_leap_far = true;       // VRHIP_PT_NO_FAR_LEAP=1: leaps stay inside one macro cell (A/B)
+    uint8_t *cell_dist = nullptr;  // CellView::cdist (two buffers)
+    const uint8_t *cell_dist_table = nullptr;
+    size_t cell_dist_cap = 0;
     bool skip_empty = true;        // VRHIP_NO_EMPTY_SKIP=1 disables the ray caster's empty runs
     bool skip_empty_force = false; // VRHIP_EMPTY_SKIP=1: also where it is not expected to pay (see ray_skip_empty)
 
@@ -700,10 +704,21 @@ int ensure_cells(vrhip_renderer *r, bool need_bound, bool need_empty)
                                         r->cell_sparse, r->cell_bound, nullptr, r->stream));
         g.bound = r->cell_bound;
         VR_HIP(r, vr_launch_cell_coarse_bounds(g, r->cell_bound + n_cells, r->stream));
+        // how far the macro cells around one are free too (CellView::cdist)
+        if (2 * (size_t)kLeapLevels * n_macro > r->cell_dist_cap) {
+            VR_HIP(r, hipStreamSynchronize(r->stream));
+            if (r->cell_dist) VR_HIP(r, hipFree(r->cell_dist));
+            r->cell_dist = nullptr;
+            r->cell_dist_cap = 0;
+            VR_HIP(r, hipMalloc((void **)&r->cell_dist, 2 * (size_t)kLeapLevels * n_macro));
+            r->cell_dist_cap = 2 * (size_t)kLeapLevels * n_macro;
+        }
+        VR_HIP(r, vr_launch_cell_leap_radius(g, r->cell_bound + n_cells, r->cell_dist, &r->cell_dist_table, r->stream));
         r->cells_have_bound = true;
     }
     g.bound = r->cells_have_bound ? r->cell_bound : nullptr;
     g.cbound = (r->cells_have_bound && r->pt_leap) ? r->cell_bound + n_cells : nullptr;
+    g.cdist = (g.cbound && r->pt_leap_far) ? r->cell_dist_table : nullptr;
     if (need_empty && !r->cells_have_empty) {
         if (n_fine > r->empty_cap) {
             VR_HIP(r, hipStreamSynchronize(r->stream));
@@ -907,7 +922,7 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
     a->raycast = r->raycast;
     a->pathtrace = r->pathtrace;
     a->cells = r->cells;
-    if (!r->pt_cull) a->cells.bound = a->cells.cbound = nullptr;
+    if (!r->pt_cull) { a->cells.bound = a->cells.cbound = nullptr; a->cells.cdist = nullptr; }
     // the empty bits are those of TF(channel 0): not what a CL_RG / CL_RGBA sample's opacity is
     if (!ray_skip_empty(r)) { a->cells.empty = nullptr; a->cells.bmask = nullptr; }
     a->format = r->format;
@@ -1373,6 +1388,7 @@ int vrhip_create(int device_id, vrhip_renderer **out)
     r->occ_force_split = occ_env("VRHIP_OCC_P2", r->occ_force_split);
     if (getenv("VRHIP_PT_NO_CULL")) r->pt_cull = false;        // experiments: no opacity-bound culling
     if (getenv("VRHIP_PT_NO_LEAP")) r->pt_leap = false;        // A/B: every tracking step on its own
+    if (getenv("VRHIP_PT_NO_FAR_LEAP")) r->pt_leap_far = false;
     if (getenv("VRHIP_NO_EMPTY_SKIP")) r->skip_empty = false;  // experiments: no empty-run skipping
     if (getenv("VRHIP_EMPTY_SKIP")) r->skip_empty_force = true;   // ... or everywhere
     if (getenv("VRHIP_NO_FOOTPRINT")) r->use_fp = false;       // plain volume layout only
@@ -1417,6 +1433,7 @@ void vrhip_destroy(vrhip_renderer *r)
     if (r->near_scratch) (void)hipFree(r->near_scratch);
     if (r->patch_class) (void)hipFree(r->patch_class);
     if (r->cell_bound) (void)hipFree(r->cell_bound);
+    if (r->cell_dist) (void)hipFree(r->cell_dist);
     if (r->cell_empty) (void)hipFree(r->cell_empty);
     if (r->cell_sparse) (void)hipFree(r->cell_sparse);
     if (r->cell_bmask) (void)hipFree(r->cell_bmask);
