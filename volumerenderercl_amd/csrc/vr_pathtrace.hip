@@ -24,8 +24,19 @@
 
 namespace {
 
+// Diagnostic build only (-DVR_STAMPS, tools/pt_stamps.py): where a wave of the path tracer spends its time -- summed shader
+// clock per stage (a stamp waits for the memory queue, so a stage owns the latency of what it issued), calls, lifetime.
+#ifdef VR_STAMPS
+__device__ unsigned long long g_pt_stamps[16];
+#define PT_STAMP(i) do { const unsigned long long n_ = vr_stamp(); pt_acc[i] += n_ - pt_last; pt_last = n_; } while (0)
+#define PT_COUNT(i) pt_acc[i] += 1
+#else
+#define PT_STAMP(i)
+#define PT_COUNT(i)
+#endif
+
 #ifndef VR_PT_BATCH
-#define VR_PT_BATCH 4
+#define VR_PT_BATCH 6
 #endif
 constexpr int kPtBatch = VR_PT_BATCH;
 
@@ -42,6 +53,10 @@ constexpr int kStageMin = VR_PT_STAGE_MIN;
 #define VR_LEAP_PIECES 1
 #endif
 constexpr int kLeapPieces = VR_LEAP_PIECES;   // closed-form stretches of a leap (one binade each)
+#ifndef VR_LEAP_CHAIN
+#define VR_LEAP_CHAIN 1
+#endif
+constexpr int kLeapChain = VR_LEAP_CHAIN;     // leaps of a walk per round, each from the landing of the one before
 #ifndef VR_PT_SHADE_MIN
 #define VR_PT_SHADE_MIN VR_PT_STAGE_MIN
 #endif
@@ -147,7 +162,11 @@ __global__ __launch_bounds__(kBlockDim) VR_PT_OCC void vr_pathtrace_kernel(
     // The lanes by state, as wave masks kept across the rounds (a round in which nobody is handed a pixel or shaded --
     // most rounds -- recomputes only the two that stage 2 changes): idle (P_FETCH), walking, walk ended (P_ENDED).
     unsigned long long idle_m = ~0ull, walk_m = 0ull;
+#ifdef VR_STAMPS
+    unsigned long long pt_acc[16] = {0}, pt_last = vr_stamp(), pt_first = pt_last, pt_drained = 0;
+#endif
     for (;;) {
+        PT_STAMP(6);   // loop control
         // ---- stage 1: hand out pixels to idle lanes -- when enough lanes are idle to pay for the
         //      ray set-up code, or when nothing else is left to do
         if (!drained && idle_m && ((int)__builtin_popcountll(idle_m) >= kStageMin || !walk_m)) {
@@ -209,6 +228,11 @@ __global__ __launch_bounds__(kBlockDim) VR_PT_OCC void vr_pathtrace_kernel(
             }
             idle_m = idle;
             walk_m = __ballot(state >= P_PRIMARY && state <= P_SHADOW);
+            PT_STAMP(0);
+            PT_COUNT(8);
+#ifdef VR_STAMPS
+            if (drained && !pt_drained) pt_drained = pt_last;
+#endif
         }
 
         // ---- stage 2: kPtBatch consecutive tracking steps of every walking lane (:419-431)
@@ -229,7 +253,7 @@ __global__ __launch_bounds__(kBlockDim) VR_PT_OCC void vr_pathtrace_kernel(
             // majorant cull: no value a fetch in this cell can return maps to an opacity that
             // reaches the walk's threshold -> the step is a rejection whatever the voxels hold
             float lax = 0.f, lbx = 0.f, lay = 0.f, lby = 0.f, laz = 0.f, lbz = 0.f, lcb = 0.f;   // (for the leap below)
-            uint32_t lcx = 0, lcy = 0, lcz = 0, lrad = 0;
+            uint32_t lcx = 0, lcy = 0, lcz = 0, lrad = 0, llev = 0xffffffffu;
             if (cull) {
                 // cell of step k from the walk's voxel-space line u'(t) = a + b * t, in cells (one fma,
                 // one conversion and one clamp per axis).  u' = p * res: the fetch's low-corner texel is
@@ -259,7 +283,10 @@ __global__ __launch_bounds__(kBlockDim) VR_PT_OCC void vr_pathtrace_kernel(
                         if (grid.cdist) {   // how far the macro cells around are free at the level below the walk's threshold
                             const uint32_t j = (uint32_t)(px.thr * 8.f);   // tau_j = j / 8 <= thr (exact: a power of two)
                             const uint32_t jj = j < (uint32_t)kLeapLevels ? j : (uint32_t)kLeapLevels;
-                            if (jj) lrad = grid.cdist[(size_t)(jj - 1u) * ((size_t)grid.ccx * grid.ccy * grid.ccz) + ci];
+                            if (jj) {
+                                llev = (jj - 1u) * (uint32_t)(grid.ccx * grid.ccy * grid.ccz);
+                                lrad = grid.cdist[llev + ci];
+                            }
                         }
                     }
                 }
@@ -267,6 +294,8 @@ __global__ __launch_bounds__(kBlockDim) VR_PT_OCC void vr_pathtrace_kernel(
 #pragma unroll
                 for (int k = 0; k < B; ++k) need[k] = need[k] && !(bnd[k] < px.thr);
             }
+            PT_STAMP(1);   // positions, cells, bound loads
+            PT_COUNT(9);
             // fetch and transfer function -- behind ONE wave-uniform test: with the cull, seven rounds in eight need
             // neither for any lane, and a guard per step is a handful of scalar instructions each
             bool any_need = !cull;
@@ -286,6 +315,7 @@ __global__ __launch_bounds__(kBlockDim) VR_PT_OCC void vr_pathtrace_kernel(
                 for (int k = 0; k < B; ++k)
                     if (need[k] || !cull) al[k] = tff_linear_alpha(s_tff, tffn, dens[k]);
             }
+            PT_STAMP(2);   // fetch + TF
             // the walk's exit conditions, in step order -- as selects, not branches (the bodies are assignments; as
             // nested ifs they were ~25 scalar mask instructions per step): step k happens while `run`; it leaves the
             // volume (:426-427), exceeds the step limit (:430-431) or is accepted (:432), in that order
@@ -312,6 +342,7 @@ __global__ __launch_bounds__(kBlockDim) VR_PT_OCC void vr_pathtrace_kernel(
                 run = st && !stop;
             }
             if (walking && !run) state |= P_ENDED;
+            PT_STAMP(3);   // exit conditions
 
             // ---- the leap: a walk whose batch ended with a rejected step in a macro cell (4^3 cells) whose bound is
             // below its threshold takes ALL its further steps inside that macro cell at once -- or inside the cube of
@@ -329,13 +360,20 @@ __global__ __launch_bounds__(kBlockDim) VR_PT_OCC void vr_pathtrace_kernel(
             //  * the step counter stays within the limit of 512 (:430).
             // The number of steps comes from the macro cell's exit along the walk's line in cell space and the room in
             // the binade, both estimated (reciprocals) and then VERIFIED: landing cell, landing position, bit pattern.
-            if (leap) {
+            // A leap that lands (one step short of its cube's face) in a macro cell with free macro cells around it starts
+            // the next one from there -- the landing step is a rejected step in a known macro cell like the batch's last
+            // one -- for the price of that macro cell's two table entries (a dependent load, but from tables of a few
+            // hundred KB) instead of a whole round: kLeapChain hops at most.
+            bool go = run;
+#pragma unroll 1
+            for (int hop = 0; leap && hop < kLeapChain; ++hop) {
                 const float sst = -px.dt;
                 const uint32_t ti = __float_as_uint(px.t), si = __float_as_uint(sst);
                 const int et = (int)(ti >> 23), es = (int)(si >> 23);   // (a sign bit makes the exponent >= 256)
                 // (lrad != 0: the macro cell and those within lrad - 1 around it have bounds < tau_j <= thr)
-                const bool can = run && (lrad != 0u || lcb < px.thr) && et > 0 && et < 255 && es > 0 && es < 255;
-                if (__ballot(can)) {
+                const bool can = go && (lrad != 0u || lcb < px.thr) && et > 0 && et < 255 && es > 0 && es < 255;
+                if (!__ballot(can)) break;
+                {
                     // -- how many steps: to where the line leaves the cube of macro cells [C - R, C + R] per axis, in cells
                     // (R = 0: the macro cell [4 C, 4 C + 4) itself), cut at the volume's own faces (cell coordinate 0 and
                     // res / E: a walk that leaves the volume inside the cube lands just before it does, instead of failing
@@ -405,10 +443,24 @@ __global__ __launch_bounds__(kBlockDim) VR_PT_OCC void vr_pathtrace_kernel(
                         c_culled += ok ? n : 0u;
                         c_leaped += ok ? n : 0u;
                     }
+                    // the next hop: from the landing's macro cell, if the tables say there is room around it
+                    go = false;
+                    if (hop + 1 < kLeapChain && grid.cdist) {
+                        const bool more = ok && px.cnt < 512u && llev != 0xffffffffu;
+                        if (!__ballot(more)) break;
+                        if (more) {
+                            lcx = xn >> kLeapShift; lcy = yn >> kLeapShift; lcz = zn >> kLeapShift;
+                            const uint32_t ci = (lcz * (uint32_t)grid.ccy + lcy) * (uint32_t)grid.ccx + lcx;
+                            lrad = grid.cdist[llev + ci];
+                            lcb = 0.f;                 // (lrad != 0 says the cell is free at the walk's level; 0: no hop)
+                            go = lrad >= 2u;           // a cube of radius >= 1: further than the one step left in this cell
+                        }
+                    }
                 }
             }
         }
 
+        PT_STAMP(4);   // leap
         // ---- stage 3: trace_volume's control flow (:463-503) for lanes whose walk ended -- again
         //      only when enough lanes wait, or no lane walks any more
         const unsigned long long pend = __ballot((state & P_ENDED) != 0);
@@ -487,10 +539,22 @@ __global__ __launch_bounds__(kBlockDim) VR_PT_OCC void vr_pathtrace_kernel(
         if (shade) {
             idle_m = __ballot(state == P_FETCH);
             walk_m = __ballot(state >= P_PRIMARY && state <= P_SHADOW);
+            PT_STAMP(5);   // walk ends: shading, next walk, pixel write
+            PT_COUNT(10);
         }
         if (drained && idle_m == ~0ull) break;
     }
 
+#ifdef VR_STAMPS
+    if (lane == 0) {
+        const unsigned long long end_ = vr_stamp();
+        for (int i_ = 0; i_ < 11; ++i_) atomicAdd(&g_pt_stamps[i_], pt_acc[i_]);
+        atomicAdd(&g_pt_stamps[11], end_ - pt_first);                              // wave lifetime
+        atomicAdd(&g_pt_stamps[12], pt_drained ? end_ - pt_drained : 0ull);        // ... of it after the queue was empty
+        atomicMax(&g_pt_stamps[13], end_ - pt_first);                              // the longest wave
+        atomicAdd(&g_pt_stamps[14], 1ull);
+    }
+#endif
     if (INSTR) {
         unsigned long long s = wave_sum(c_taken);
         if (lane == 0 && s) atomicAdd(&stats->v[0], s);
@@ -531,6 +595,21 @@ hipError_t launch_pt(const RaycastLaunch &a, hipStream_t stream)
     if (e == hipSuccess && a.mid_event) e = hipEventRecord(a.mid_event, stream);
     return e;
 }
+
+#ifdef VR_STAMPS
+} // namespace
+extern "C" int vrhip_debug_pt_stamps(unsigned long long out[16], int reset)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pt_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_pt_stamps), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+namespace {
+#endif
 
 template <typename VT>
 hipError_t launch_pt_typed(const RaycastLaunch &a, hipStream_t stream)
