@@ -155,6 +155,7 @@ __global__ __launch_bounds__(kBlockDim) VR_PT_OCC void vr_pathtrace_kernel(
     uint32_t patch_taken = 64;         // pixels of the current patch already handed out (wave-uniform)
     bool drained = false;              // queue exhausted (wave-uniform)
     bool first_patch = true;
+
     WaveTile wt = {0, 0, 0};
 
     // Exit condition reached by every wave: the queue head only grows, every walk ends after at
@@ -465,7 +466,16 @@ __global__ __launch_bounds__(kBlockDim) VR_PT_OCC void vr_pathtrace_kernel(
         //      only when enough lanes wait, or no lane walks any more
         const unsigned long long pend = __ballot((state & P_ENDED) != 0);
         walk_m = __ballot(state >= P_PRIMARY && state <= P_SHADOW);
-        const bool shade = pend && ((int)__builtin_popcountll(pend) >= kShadeMin || !walk_m);
+        // (once the queue is empty nothing new will join the lanes that wait: a walk's end is handled at once, or its
+        // pixel's next walk would start only when every other walk of the wave has ended -- walks in series, not side by side)
+#ifndef VR_PT_DRAIN_SHADE_MIN
+#define VR_PT_DRAIN_SHADE_MIN 1
+#endif
+        // (A wave learns that the queue is empty when it next draws from it, not before.  Looking at the queue's head
+        // every few rounds instead -- thousands of waves reading the one address the draws update -- was measured at 2.4x
+        // the kernel's time.)
+        const int shade_min = drained ? VR_PT_DRAIN_SHADE_MIN : kShadeMin;
+        const bool shade = pend && ((int)__builtin_popcountll(pend) >= shade_min || !walk_m);
         if (shade && (state & P_ENDED)) {
             const int ended = state & ~P_ENDED;
             bool start_shadow = false;
