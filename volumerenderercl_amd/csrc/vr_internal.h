@@ -157,7 +157,8 @@ struct FrameView {
     // first non-skipped brick; rays that never reach one get their (background) pixel there and
     // phase 1 only visits the patches listed in `live`.  nullptr: phase 1 walks the whole queue.
     LiveTile *live;
-    uint32_t *live_count;  // zeroed before each launch
+    uint32_t *live_count;  // zeroed before each launch (the list of live PATCHES, FrameView::live)
+    uint32_t *live_list_count;   // kLiveLists counters, kLiveStride words apart (the lists of live RAYS, live_rays)
     // Default kernels: the pre-pass lists the live RAYS instead (with the DDA state they have
     // reached; live_count counts them) and phase 1 runs on that list, one lane per ray, lanes
     // refilled as rays end (vr_raycast_rays_kernel).  nullptr: the patch list above.
@@ -187,7 +188,19 @@ struct FrameView {
     uint32_t env_w, env_h;
 };
 constexpr uint32_t kSortBins = 256;
-constexpr uint32_t kControlWords = 4 + 2 * kSortBins;   // queue head, cont count, cont head, pad, sort_ws
+// The pre-pass's ray list is kLiveLists lists, work item q appending to list q % kLiveLists through a counter of its
+// own, each counter in a cache line of its own (kLiveStride words apart): waves that run side by side walk neighbouring
+// work items, so their appends meet at kLiveLists addresses instead of one (one counter: 193 us of a 20-frame set's
+// 580 us of pre-pass).  Phase 1 reads the lists interleaved, 64 rays from each in turn (vr_raycast_rays_kernel), which
+// keeps the queue's order: all lists grow at the same pace.  List k sits at live_rays + k * live_list_cap(items).
+#ifdef VR_EXPERIMENTS   // (the opt-in march kernel of the A/B builds reads one list)
+constexpr uint32_t kLiveLists = 1, kLiveStride = 32;
+#else
+constexpr uint32_t kLiveLists = 8, kLiveStride = 32;
+#endif
+constexpr uint32_t kLiveBase = 4 + 2 * kSortBins;        // first list counter, in control words
+constexpr uint32_t kControlWords = kLiveBase + kLiveLists * kLiveStride;   // queue head, cont count, cont head, live-tile count, sort_ws, list counters
+__host__ __device__ inline uint32_t live_list_cap(uint32_t n_items) { return ((n_items + kLiveLists - 1u) / kLiveLists) * 64u; }
 // first kernel of a set of launches, first workgroup: the control words of the next set (FrameView::next_ctrl)
 #define VR_ZERO_NEXT_CTRL(fr)                                                                              \
     do {                                                                                                   \

@@ -1184,14 +1184,17 @@ __global__ __launch_bounds__(kBlockDim) void vr_dda_prepass_kernel(
         // ray list for phase 1 (vr_raycast_rays_kernel): the live rays with the DDA state they have
         // reached, so that phase 1 neither repeats the walk nor carries the patch's dead lanes
         if (m) {
+            // (list q % kLiveLists: vr_internal.h)
+            const uint32_t list = q % kLiveLists;
             uint32_t base = 0;
-#ifdef VR_DIAG_NO_LIVE_ATOMIC   // diagnostic build (WRONG frames: the list is not compact and its count stays 0, so the
-            base = q * 64u;     // marching kernels leave at once): what does the pre-pass cost without its one shared counter?
+#ifdef VR_DIAG_NO_LIVE_ATOMIC   // diagnostic build (WRONG frames: the lists are not compact and their counts stay 0, so the
+            base = (q / kLiveLists) * 64u;   // marching kernels leave at once): what does the pre-pass cost without its counters?
 #else
             if (lane == (uint32_t)__builtin_ctzll(m))
-                base = atomicAdd(fr.live_count, (uint32_t)__builtin_popcountll(m));
+                base = atomicAdd(fr.live_list_count + list * kLiveStride, (uint32_t)__builtin_popcountll(m));
             base = __shfl(base, __builtin_ctzll(m), 64);
 #endif
+            base += list * live_list_cap(fr.n_wave_tiles);
             if (live) {
                 ContRec r;
                 r.pix = gx | (gy << 16);
@@ -1238,8 +1241,20 @@ __global__ __launch_bounds__(WAVES * 64) void vr_raycast_rays_kernel(
     VolView vv, BrickView bricks, TfView tf, SkipView skip, CellView cells, FrameView fr,
     vrhip_camera_params cam, vrhip_rendering_params rp, vrhip_raycast_params rc)
 {
-    const uint32_t n_rays = *fr.live_count;   // written by the pre-pass (previous kernel on the stream)
+    // The pre-pass (previous kernel on the stream) has written kLiveLists lists; they are read interleaved, 64 rays from
+    // each in turn: virtual ray v is ray (v / 64 / kLiveLists) * 64 + v % 64 of list (v / 64) % kLiveLists, and there are
+    // kLiveLists * 64 * ceil(longest list / 64) virtual rays (those beyond a list's end do not exist: idle lanes).
+    __shared__ uint32_t s_live_n[kLiveLists];
+    uint32_t longest = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kLiveLists; ++k) {
+        const uint32_t n_k = fr.live_list_count[k * kLiveStride];
+        longest = n_k > longest ? n_k : longest;
+        if (threadIdx.x == k) s_live_n[k] = n_k;
+    }
+    const uint32_t n_rays = ((longest + 63u) >> 6) * kLiveLists * 64u;
     if (n_rays == 0) return;
+    const uint32_t list_cap = live_list_cap(fr.n_wave_tiles);
     extern __shared__ float4 s_mem[];
     float *s_stage = reinterpret_cast<float *>(s_mem) + (threadIdx.x >> 6) * kStageFloatsPerWave;
     float4 *s_tff = s_mem + WAVES * kStageFloatsPerWave / 4;
@@ -1308,10 +1323,12 @@ __global__ __launch_bounds__(WAVES * 64) void vr_raycast_rays_kernel(
                     first_draw = false;
                     if (base + n_idle >= n_rays) drained = true;
                     if (idle) {
-                        const uint32_t ri = base + (uint32_t)__builtin_popcountll(idle_m & ((1ull << lane) - 1ull));
-                        have = ri < n_rays;
+                        const uint32_t v = base + (uint32_t)__builtin_popcountll(idle_m & ((1ull << lane) - 1ull));
+                        const uint32_t chunk = v >> 6, list = chunk % kLiveLists;
+                        const uint32_t pos = ((chunk / kLiveLists) << 6) | (v & 63u);
+                        have = v < n_rays && pos < s_live_n[list];
                         if (have) {
-                            const ContRec rec = fr.live_rays[ri];
+                            const ContRec rec = fr.live_rays[list * list_cap + pos];
                             gx = rec.pix & 0xffffu;
                             gy = rec.pix >> 16;
                             out_index = rec.out_index;

@@ -845,7 +845,7 @@ int ensure_queue(vrhip_renderer *r, uint32_t W, uint32_t H, uint32_t tile_w, uin
         VR_HIP(r, hipMalloc((void **)&r->order, need * sizeof(uint32_t)));
         if (r->live_rays) VR_HIP(r, hipFree(r->live_rays));
         r->live_rays = nullptr;
-        VR_HIP(r, hipMalloc((void **)&r->live_rays, need * sizeof(ContRec)));
+        VR_HIP(r, hipMalloc((void **)&r->live_rays, (size_t)kLiveLists * live_list_cap((uint32_t)q.size()) * sizeof(ContRec)));
         r->cont_cap = need;
     }
     return VRHIP_OK;
@@ -900,6 +900,7 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
     a->frame.march_micro = r->march_micro;
     a->frame.march_fill = r->march_fill;
     a->frame.live_count = ctrl + 3;
+    a->frame.live_list_count = ctrl + kLiveBase;
     a->frame.cost = r->sort_cont ? r->cost : nullptr;
     a->frame.order = r->sort_cont && r->cost ? r->order : nullptr;
     a->frame.sort_ws = ctrl + 4;
