@@ -159,6 +159,7 @@ struct FrameView {
     LiveTile *live;
     uint32_t *live_count;  // zeroed before each launch (the list of live PATCHES, FrameView::live)
     uint32_t *live_list_count;   // kLiveLists counters, kLiveStride words apart (the lists of live RAYS, live_rays)
+    uint32_t *draw_count;        // kDrawCounters counters, kLiveStride words apart (the persistent kernels' draws)
     // Default kernels: the pre-pass lists the live RAYS instead (with the DDA state they have
     // reached; live_count counts them) and phase 1 runs on that list, one lane per ray, lanes
     // refilled as rays end (vr_raycast_rays_kernel).  nullptr: the patch list above.
@@ -199,7 +200,12 @@ constexpr uint32_t kLiveLists = 1, kLiveStride = 32;
 constexpr uint32_t kLiveLists = 8, kLiveStride = 32;
 #endif
 constexpr uint32_t kLiveBase = 4 + 2 * kSortBins;        // first list counter, in control words
-constexpr uint32_t kControlWords = kLiveBase + kLiveLists * kLiveStride;   // queue head, cont count, cont head, live-tile count, sort_ws, list counters
+// ... and the persistent kernels draw their work through kDrawCounters counters instead of one (FrameView::draw_count, a
+// cache line each): counter k hands out the work units G + kDrawCounters j + k behind the G units the waves own by
+// position; a wave starts at counter (its number mod kDrawCounters) and moves on when one has run out.
+constexpr uint32_t kDrawCounters = 8;
+constexpr uint32_t kDrawBase = kLiveBase + kLiveLists * kLiveStride;
+constexpr uint32_t kControlWords = kDrawBase + kDrawCounters * kLiveStride;   // queue head, cont count, cont head, live-tile count, sort_ws, list counters, draw counters
 __host__ __device__ inline uint32_t live_list_cap(uint32_t n_items) { return ((n_items + kLiveLists - 1u) / kLiveLists) * 64u; }
 // first kernel of a set of launches, first workgroup: the control words of the next set (FrameView::next_ctrl)
 #define VR_ZERO_NEXT_CTRL(fr)                                                                              \

@@ -155,6 +155,7 @@ __global__ __launch_bounds__(kBlockDim) VR_PT_OCC void vr_pathtrace_kernel(
     uint32_t patch_taken = 64;         // pixels of the current patch already handed out (wave-uniform)
     bool drained = false;              // queue exhausted (wave-uniform)
     bool first_patch = true;
+    uint32_t sub = (blockIdx.x * (kBlockDim / 64u) + (threadIdx.x >> 6)) % kDrawCounters, sub_tried = 0;   // (stage 1's counters)
 
     WaveTile wt = {0, 0, 0};
 
@@ -180,8 +181,18 @@ __global__ __launch_bounds__(kBlockDim) VR_PT_OCC void vr_pathtrace_kernel(
                     if (first_patch) {
                         q = blockIdx.x * (kBlockDim / 64u) + (threadIdx.x >> 6);
                     } else {
-                        if (lane == 0) q = atomicAdd(fr.queue_head, 1u);
-                        q = __builtin_amdgcn_readfirstlane(q) + gridDim.x * (kBlockDim / 64u);
+                        // -- through one of kDrawCounters counters (a cache line each): counter k hands out the patches
+                        // G + 8 j + k, a wave starts at k = its number mod 8 and moves on to the next counter when one has
+                        // run out.  (One counter for 3 072 waves: +7 % on the sphere, +12 % on the shells.)
+                        const uint32_t G = gridDim.x * (kBlockDim / 64u);
+                        for (;;) {
+                            uint32_t j = 0;
+                            if (lane == 0) j = atomicAdd(fr.draw_count + sub * kLiveStride, 1u);
+                            j = __builtin_amdgcn_readfirstlane(j);
+                            q = G + j * kDrawCounters + sub;
+                            if (q < fr.n_wave_tiles || ++sub_tried >= kDrawCounters) break;
+                            sub = (sub + 1u) % kDrawCounters;
+                        }
                     }
                     first_patch = false;
                     if (q >= fr.n_wave_tiles) { drained = true; break; }

@@ -901,6 +901,7 @@ void fill_launch(vrhip_renderer *r, uint32_t width, uint32_t height, uint32_t ou
     a->frame.march_fill = r->march_fill;
     a->frame.live_count = ctrl + 3;
     a->frame.live_list_count = ctrl + kLiveBase;
+    a->frame.draw_count = ctrl + kDrawBase;
     a->frame.cost = r->sort_cont ? r->cost : nullptr;
     a->frame.order = r->sort_cont && r->cost ? r->order : nullptr;
     a->frame.sort_ws = ctrl + 4;
